@@ -1,0 +1,391 @@
+// api.hip -- the C ABI of libgigs_hip.so (declared in include/gigs_hip.h).
+//
+// Host-side orchestration only; it mirrors CudaRasterizer::Rasterizer::forward / backward
+// (R/cuda_rasterizer/rasterizer_impl.cu:486-803): preprocess -> inclusive scan -> 4-byte D2H
+// read of num_rendered -> duplicate -> radix sort -> tile ranges -> blend, with the scratch
+// chunks obtained from the caller through allocation callbacks.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "../../include/gigs_hip.h"
+#include "gigs_common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local float g_stage_ms[8];
+thread_local int g_stage_n = 0;
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return fail(GIGS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+// CHECK_CUDA of the reference (auxiliary.h:178-185): in debug mode synchronise and report
+// after every stage.
+#define STAGE_CHECK(name)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = hipGetLastError();                                                     \
+    if (_e == hipSuccess && debug) _e = hipStreamSynchronize(s);                           \
+    if (_e != hipSuccess)                                                                  \
+      return fail(GIGS_ERR_HIP, "stage '%s' failed: %s", name, hipGetErrorString(_e));     \
+  } while (0)
+
+// temp-storage sizes of rocPRIM depend only on the element count: memoise them
+std::mutex g_size_mu;
+std::map<int, size_t> g_scan_sizes, g_sort_sizes;
+size_t scan_size_cached(int P) {
+  std::lock_guard<std::mutex> lk(g_size_mu);
+  auto it = g_scan_sizes.find(P);
+  if (it != g_scan_sizes.end()) return it->second;
+  const size_t v = gigs::scan_temp_bytes(P);
+  g_scan_sizes[P] = v;
+  return v;
+}
+size_t sort_size_cached(int R) {
+  // sizes are monotone in R within a rocPRIM config; cache by power-of-two bucket to keep the
+  // map small and the binning chunk stable between iterations
+  int bucket = 1024;
+  while (bucket < R) bucket <<= 1;
+  std::lock_guard<std::mutex> lk(g_size_mu);
+  auto it = g_sort_sizes.find(bucket);
+  if (it != g_sort_sizes.end()) return it->second;
+  const size_t v = gigs::sort_temp_bytes(bucket);
+  g_sort_sizes[bucket] = v;
+  return v;
+}
+
+// R/cuda_rasterizer/rasterizer_impl.cu:35-50
+uint32_t higher_msb(uint32_t n) {
+  uint32_t msb = sizeof(n) * 4;
+  uint32_t step = msb;
+  while (step > 1) {
+    step /= 2;
+    if (n >> msb) msb += step;
+    else msb -= step;
+  }
+  if (n >> msb) msb++;
+  return msb;
+}
+
+struct StageTimer {
+  hipStream_t s;
+  bool on;
+  hipEvent_t ev[9];
+  int n = 0;
+  StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
+    if (on)
+      for (auto& e : ev) hipEventCreate(&e);
+  }
+  void mark() {
+    if (on && n < 9) hipEventRecord(ev[n++], s);
+  }
+  void finish() {
+    if (!on) return;
+    hipStreamSynchronize(s);
+    g_stage_n = 0;
+    for (int i = 1; i < n; i++) hipEventElapsedTime(&g_stage_ms[g_stage_n++], ev[i - 1], ev[i]);
+    for (auto& e : ev) hipEventDestroy(e);
+    on = false;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* gigs_last_error(void) { return g_err; }
+const char* gigs_build_arch(void) { return "gfx950"; }
+
+size_t gigs_required_geom(int P) {
+  if (P < 0) { fail(GIGS_ERR_INVALID, "P < 0"); return 0; }
+  return gigs::required_bytes<gigs::GeomState>((size_t)P, scan_size_cached(P));
+}
+size_t gigs_required_image(int width, int height) {
+  const size_t N = (size_t)width * height;
+  const size_t T = (size_t)((width + GIGS_BLOCK_X - 1) / GIGS_BLOCK_X) * ((height + GIGS_BLOCK_Y - 1) / GIGS_BLOCK_Y);
+  return gigs::required_bytes<gigs::ImageState>(N, T);
+}
+size_t gigs_required_binning(int R) {
+  if (R < 0) { fail(GIGS_ERR_INVALID, "R < 0"); return 0; }
+  return gigs::required_bytes<gigs::BinningState>((size_t)R, sort_size_cached(R));
+}
+
+long long gigs_geom_offset(int P, int which) {
+  char* base = nullptr;
+  char* p = base;
+  gigs::GeomState g = gigs::GeomState::fromChunk(p, (size_t)P, 0);
+  const void* ptrs[] = {g.depths, g.pos_view, g.means2D, g.cov3D, g.conic_opacity, g.rgb,
+                        g.clamped, g.tiles_touched, g.point_offsets, g.internal_radii, g.brec, g.grec};
+  if (which < 0 || which >= (int)(sizeof(ptrs) / sizeof(ptrs[0]))) return -1;
+  return (long long)((const char*)ptrs[which] - base);
+}
+long long gigs_binning_offset(int R, int which) {
+  char* base = nullptr;
+  char* p = base;
+  gigs::BinningState b = gigs::BinningState::fromChunk(p, (size_t)R, 0);
+  const void* ptrs[] = {b.keys_unsorted, b.values_unsorted, b.keys, b.point_list};
+  if (which < 0 || which >= 4) return -1;
+  return (long long)((const char*)ptrs[which] - base);
+}
+long long gigs_image_offset(int width, int height, int which) {
+  const size_t N = (size_t)width * height;
+  const size_t T = (size_t)((width + GIGS_BLOCK_X - 1) / GIGS_BLOCK_X) * ((height + GIGS_BLOCK_Y - 1) / GIGS_BLOCK_Y);
+  char* base = nullptr;
+  char* p = base;
+  gigs::ImageState s = gigs::ImageState::fromChunk(p, N, T);
+  const void* ptrs[] = {s.final_T, s.n_contrib, s.ranges};
+  if (which < 0 || which >= 3) return -1;
+  return (long long)((const char*)ptrs[which] - base);
+}
+
+int gigs_last_stage_ms(float* ms, int n) {
+  const int c = g_stage_n < n ? g_stage_n : n;
+  for (int i = 0; i < c; i++) ms[i] = g_stage_ms[i];
+  return c;
+}
+
+int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer,
+                 void* binning_user, gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M,
+                 const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* opacities,
+                 const float* normal, const float* albedo, const float* roughness,
+                 const float* metallic, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                 int prefiltered, int argmax_depth, int inference, float* out_color,
+                 float* out_opacity, float* out_depth, float* out_normal, float* out_normal_view,
+                 float* out_pos, float* out_albedo, float* out_roughness, float* out_metallic,
+                 int* radii, int debug, void* stream) {
+  (void)prefiltered;  // the reference only uses it to trap on an impossible state (auxiliary.h:167-171)
+  hipStream_t s = (hipStream_t)stream;
+  if (P < 0 || width <= 0 || height <= 0) return fail(GIGS_ERR_INVALID, "bad P / image size");
+  if (P == 0) return 0;  // rasterize_points.cu:190-191: outputs stay as the caller initialised them
+  if (!geometryBuffer || !binningBuffer || !imageBuffer) return fail(GIGS_ERR_INVALID, "null allocation callback");
+  if (!means3D || !opacities || !normal || !albedo || !roughness || !metallic || !viewmatrix ||
+      !projmatrix || !cam_pos || !background)
+    return fail(GIGS_ERR_INVALID, "null required input");
+  if (!shs && !colors_precomp) return fail(GIGS_ERR_INVALID, "provide SHs or precomputed colors");
+  if (!cov3D_precomp && (!scales || !rotations)) return fail(GIGS_ERR_INVALID, "provide scales+rotations or cov3D_precomp");
+  if (!colors_precomp && (M <= 0 || (D + 1) * (D + 1) > M || D > 3)) return fail(GIGS_ERR_INVALID, "SH degree %d needs (D+1)^2 <= M=%d, D <= 3", D, M);
+
+  gigs::FwdArgs a;
+  a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
+  a.gx = (width + GIGS_BLOCK_X - 1) / GIGS_BLOCK_X;
+  a.gy = (height + GIGS_BLOCK_Y - 1) / GIGS_BLOCK_Y;
+  a.focal_y = height / (2.0f * tan_fovy);
+  a.focal_x = width / (2.0f * tan_fovx);
+  a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.scale_modifier = scale_modifier;
+  a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
+  a.normal = normal; a.albedo = albedo; a.roughness = roughness; a.metallic = metallic;
+  a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
+  a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos; a.background = background;
+  a.argmax_depth = argmax_depth; a.inference = inference;
+
+  const size_t scan_sz = scan_size_cached(P);
+  const size_t geom_bytes = gigs::required_bytes<gigs::GeomState>((size_t)P, scan_sz);
+  char* geom_chunk = geometryBuffer(geom_bytes, geom_user);
+  if (!geom_chunk) return fail(GIGS_ERR_ALLOC, "geometry buffer allocation of %zu bytes failed", geom_bytes);
+  gigs::GeomState geom = gigs::GeomState::fromChunk(geom_chunk, (size_t)P, scan_sz);
+  if (radii == nullptr) radii = geom.internal_radii;
+
+  const size_t N = (size_t)width * height, T = (size_t)a.gx * a.gy;
+  const size_t img_bytes = gigs::required_bytes<gigs::ImageState>(N, T);
+  char* img_chunk = imageBuffer(img_bytes, image_user);
+  if (!img_chunk) return fail(GIGS_ERR_ALLOC, "image buffer allocation of %zu bytes failed", img_bytes);
+  gigs::ImageState img = gigs::ImageState::fromChunk(img_chunk, N, T);
+
+  StageTimer tm(s, debug == 2);
+  tm.mark();
+  gigs::launch_preprocess_fwd(a, geom, radii, s);
+  STAGE_CHECK("preprocess");
+  tm.mark();
+  HIP_TRY(gigs::scan_tiles(geom, P, s));
+  STAGE_CHECK("scan");
+  tm.mark();
+
+  // the one blocking read of the forward (rasterizer_impl.cu:589): sizes the binning chunk
+  uint32_t num_rendered_u = 0;
+  HIP_TRY(hipMemcpyAsync(&num_rendered_u, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (num_rendered_u > 0x7fffffffu) return fail(GIGS_ERR_INVALID, "num_rendered overflows int");
+  const int num_rendered = (int)num_rendered_u;
+
+  const size_t sort_sz = sort_size_cached(num_rendered);
+  const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)num_rendered, sort_sz);
+  char* bin_chunk = binningBuffer(bin_bytes, binning_user);
+  if (!bin_chunk) return fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
+  gigs::BinningState bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, sort_sz);
+
+  gigs::launch_duplicate(P, radii, a.gx, a.gy, geom, bin, s);
+  STAGE_CHECK("duplicateWithKeys");
+  tm.mark();
+  const int bit = (int)higher_msb(a.gx * a.gy);
+  if (num_rendered > 0) HIP_TRY(gigs::sort_pairs(bin, num_rendered, 32 + bit, s));
+  STAGE_CHECK("sort");
+  tm.mark();
+  HIP_TRY(hipMemsetAsync(img.ranges, 0, T * sizeof(uint2), s));
+  gigs::launch_tile_ranges(num_rendered, bin, img.ranges, s);
+  STAGE_CHECK("identifyTileRanges");
+  tm.mark();
+  gigs::launch_blend_fwd(a, geom, bin, img, out_color, out_opacity, out_depth, out_normal,
+                         out_normal_view, out_pos, out_albedo, out_roughness, out_metallic, s);
+  STAGE_CHECK("render");
+  tm.mark();
+  tm.finish();
+  return num_rendered;
+}
+
+int gigs_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                  const float* means3D, const float* shs, const float* colors_precomp,
+                  const float* normal, const float* albedo, const float* roughness,
+                  const float* metallic, const float* scales, const float* rotations,
+                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                  const float* cam_pos, const int* radii, float scale_modifier, float tan_fovx,
+                  float tan_fovy, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                  const float* dL_dpix_depth, const float* dL_dpix, const float* dL_dpix_opacity,
+                  const float* dL_dpix_normal, const float* dL_dpix_albedo,
+                  const float* dL_dpix_roughness, const float* dL_dpix_metallic, float* dL_dmean2D,
+                  float* dL_dconic, float* dL_ddepth, float* dL_dopacity, float* dL_dnormal,
+                  float* dL_dalbedo, float* dL_droughness, float* dL_dmetallic, float* dL_dcolor,
+                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                  float* dL_drot, int debug, void* stream) {
+  (void)normal; (void)albedo; (void)roughness; (void)metallic;  // already packed in the blend record
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) return 0;
+  if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(GIGS_ERR_INVALID, "bad sizes");
+  if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GIGS_ERR_INVALID, "null scratch buffer");
+  if (!dL_dpix_depth || !dL_dpix || !dL_dpix_opacity || !dL_dpix_normal || !dL_dpix_albedo ||
+      !dL_dpix_roughness || !dL_dpix_metallic)
+    return fail(GIGS_ERR_INVALID, "null incoming gradient");
+  if (!dL_dmean2D || !dL_dconic || !dL_ddepth || !dL_dopacity || !dL_dnormal || !dL_dalbedo ||
+      !dL_droughness || !dL_dmetallic || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
+      (shs && !dL_dsh))
+    return fail(GIGS_ERR_INVALID, "null gradient output");
+
+  gigs::BwdArgs a;
+  a.P = P; a.D = D; a.M = M; a.R = R; a.W = width; a.H = height;
+  a.gx = (width + GIGS_BLOCK_X - 1) / GIGS_BLOCK_X;
+  a.gy = (height + GIGS_BLOCK_Y - 1) / GIGS_BLOCK_Y;
+  a.focal_y = height / (2.0f * tan_fovy);
+  a.focal_x = width / (2.0f * tan_fovx);
+  a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.scale_modifier = scale_modifier;
+  a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
+  a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix;
+  a.projmatrix = projmatrix; a.cam_pos = cam_pos; a.background = background;
+  a.dL_dpix_depth = dL_dpix_depth; a.dL_dpix = dL_dpix; a.dL_dpix_opacity = dL_dpix_opacity;
+  a.dL_dpix_normal = dL_dpix_normal; a.dL_dpix_albedo = dL_dpix_albedo;
+  a.dL_dpix_roughness = dL_dpix_roughness; a.dL_dpix_metallic = dL_dpix_metallic;
+  a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_ddepth = dL_ddepth;
+  a.dL_dopacity = dL_dopacity; a.dL_dnormal = dL_dnormal; a.dL_dalbedo = dL_dalbedo;
+  a.dL_droughness = dL_droughness; a.dL_dmetallic = dL_dmetallic; a.dL_dcolor = dL_dcolor;
+  a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale;
+  a.dL_drot = dL_drot;
+
+  // re-derive the same pointers the forward carved (rasterizer_impl.cu:722-724)
+  const size_t N = (size_t)width * height, T = (size_t)a.gx * a.gy;
+  char* gp = geom_buffer;
+  gigs::GeomState geom = gigs::GeomState::fromChunk(gp, (size_t)P, scan_size_cached(P));
+  char* bp = binning_buffer;
+  gigs::BinningState bin = gigs::BinningState::fromChunk(bp, (size_t)R, 0);
+  char* ip = image_buffer;
+  gigs::ImageState img = gigs::ImageState::fromChunk(ip, N, T);
+  a.radii = radii ? radii : geom.internal_radii;
+
+  StageTimer tm(s, debug == 2);
+  tm.mark();
+  HIP_TRY(hipMemsetAsync(geom.grec, 0, (size_t)P * GIGS_GREC * sizeof(float), s));
+  gigs::launch_blend_bwd(a, geom, bin, img, s);
+  STAGE_CHECK("render backward");
+  tm.mark();
+  gigs::launch_preprocess_bwd(a, geom, s);
+  STAGE_CHECK("preprocess backward");
+  tm.mark();
+  tm.finish();
+  return 0;
+}
+
+int gigs_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, uint8_t* present, void* stream) {
+  (void)projmatrix;
+  if (P == 0) return 0;
+  if (P < 0 || !means3D || !viewmatrix || !present) return fail(GIGS_ERR_INVALID, "bad argument");
+  gigs::launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int gigs_depth_to_normal(int width, int height, float focal_x, float focal_y,
+                         const float* viewmatrix, const float* depth, float* normal,
+                         float* depth_pos, void* stream) {
+  if (width <= 0 || height <= 0 || !viewmatrix || !depth || !normal || !depth_pos)
+    return fail(GIGS_ERR_INVALID, "bad argument");
+  gigs::launch_depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depth, normal, depth_pos, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius, float bias,
+              float thick, float delta, int step, int start, const float* normal_view,
+              const float* pos, float* occlusion, void* stream) {
+  if (width <= 0 || height <= 0 || !normal_view || !pos || !occlusion) return fail(GIGS_ERR_INVALID, "bad argument");
+  const int rc = gigs::launch_ssao(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
+                                   normal_view, pos, occlusion, (hipStream_t)stream);
+  if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
+  if (rc) return fail(GIGS_ERR_HIP, "ray table upload failed");
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, float bias,
+             float thick, float delta, int step, int start, const float* normal_view,
+             const float* pos, const float* rgb, const float* albedo, const float* roughness,
+             const float* metallic, const float* F0, float* color, float* abd, void* stream) {
+  if (width <= 0 || height <= 0 || !normal_view || !pos || !rgb || !albedo || !metallic || !F0 || !color || !abd)
+    return fail(GIGS_ERR_INVALID, "bad argument");
+  const int rc = gigs::launch_ssr(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
+                                  normal_view, pos, rgb, albedo, roughness, metallic, F0, color, abd, (hipStream_t)stream);
+  if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
+  if (rc) return fail(GIGS_ERR_HIP, "ray table upload failed");
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int gigs_median3x3(int channels, int height, int width, const float* in, float* out, void* stream) {
+  if (channels <= 0 || width <= 0 || height <= 0 || !in || !out) return fail(GIGS_ERR_INVALID, "bad argument");
+  gigs::launch_median3x3(channels, height, width, in, out, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int gigs_median3x3_backward(int channels, int height, int width, const float* in,
+                            const float* grad_out, float* grad_in, void* stream) {
+  if (channels <= 0 || width <= 0 || height <= 0 || !in || !grad_out || !grad_in) return fail(GIGS_ERR_INVALID, "bad argument");
+  gigs::launch_median3x3_bwd(channels, height, width, in, grad_out, grad_in, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int gigs_bilateral3x3(int channels, int height, int width, float sigma_color, float sigma_x,
+                      float sigma_y, const float* in, float* out, void* stream) {
+  if ((channels != 1 && channels != 3) || width <= 1 || height <= 1 || !in || !out)
+    return fail(GIGS_ERR_INVALID, "bilateral3x3 supports 1 or 3 channels and images larger than 1x1");
+  gigs::launch_bilateral3x3(channels, height, width, sigma_color, sigma_x, sigma_y, in, out, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

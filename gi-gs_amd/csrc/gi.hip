@@ -1,0 +1,507 @@
+// gi.hip -- screen-space passes over the G-buffer: depth->normal, SSAO, SSR (indirect
+// diffuse) and the two 3x3 filters the operator applies between them.
+//
+// Reference behaviour restated (R/ = submodules/diff-gaussian-rasterization):
+//   depthmapToNormalCUDA  R/cuda_rasterizer/forward.cu:914-1032  (get_position ssr.h:103-118)
+//   SSAOCUDA              forward.cu:635-724                      (get_coord   ssr.h:120-135)
+//   SSRCUDA               forward.cu:726-909                      (fresnelSchlick ssr.h:13-16)
+//   kornia median_blur / bilateral_blur as called at
+//   R/diff_gaussian_rasterization/__init__.py:478, 491, 504 (kornia is third party and
+//   unpinned in the reference: parity unpinned, definitions in include/gigs_hip.h)
+//
+// MI355X design for SSAO / SSR (the dominant cost at start < step: rays * steps dependent
+// gathers per pixel):
+//   * the (phi, theta) ray set is pixel-invariant.  The host builds it ONCE per `delta` with
+//     the reference's fp32 loop accumulation (`phi += d*pi`, `theta += d*pi/2`) and libm
+//     sinf/cosf, and keeps it in a small per-device table.  In the kernel the ray index is
+//     wave-uniform, so the table is read with scalar loads (s_load_dwordx4/x8) into SGPRs
+//     and costs no vector memory or LDS traffic; the loop-count subtleties (16 not 17 theta
+//     samples at delta = 0.0625) are decided on the host exactly as the oracle decides them;
+//   * 8x8 pixels per wave so the z-plane gathers of neighbouring lanes share cache lines (the
+//     z plane is 2.5 MB at 800x800 and stays L2 resident);
+//   * per-step arithmetic keeps the reference's operation order and IEEE division, so pixel
+//     coordinates (roundf of a projected float) are bit-identical to the oracle's; the only
+//     exact rewrite is `x / step` -> `x * (1/step)` when step is a power of two;
+//   * SSR reads the rgb planes only on a hit (the reference reads them every step but uses
+//     them only on a hit: forward.cu:820-826).
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+#include "gigs_common.h"
+
+namespace gigs {
+
+constexpr float kPiF = 3.14159265358979323846f;
+
+// ------------------------------------------------------------------------------------------
+// depth -> normal
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ v3 get_position(int x, int y, float cx, float cy, float fx, float fy,
+                                           float depth) {
+  const v3 dir = {((float)x - cx) / fx, ((float)y - cy) / fy, 1.0f};
+  return dir * depth;
+}
+
+__global__ void __launch_bounds__(256)
+depth_to_normal_kernel(int W, int H, float fx, float fy, const float* __restrict__ vm,
+                       const float* __restrict__ depth_map, float* __restrict__ normal_out,
+                       float* __restrict__ depth_pos) {
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x <= 0 || x >= W - 1 || y <= 0 || y >= H - 1) return;
+  const size_t HW = (size_t)H * W;
+  const size_t pix_id = (size_t)W * y + x;
+  const float depth_thresh = 0.01f;
+  const float depth = depth_map[pix_id];
+  const float cx = float(W) / 2.0f, cy = float(H) / 2.0f;
+  const v3 pos = get_position(x, y, cx, cy, fx, fy, depth);
+  depth_pos[pix_id] = pos.x;
+  depth_pos[HW + pix_id] = pos.y;
+  depth_pos[2 * HW + pix_id] = pos.z;
+  if (depth < depth_thresh) return;
+  // 5x5 validity window (forward.cu:979-986)
+  const int pad = 2;
+  for (int dx = -pad; dx < pad + 1; ++dx) {
+    if (x + dx < 0 || x + dx > W - 1) return;
+    for (int dy = -pad; dy < pad + 1; ++dy) {
+      if (y + dy < 0 || y + dy > H - 1) return;
+      if (depth_map[(ptrdiff_t)pix_id + (ptrdiff_t)W * dy + dx] < depth_thresh) return;
+    }
+  }
+#define DP(dx, dy) depth_map[(ptrdiff_t)pix_id + (ptrdiff_t)W * (dy) + (dx)]
+  const v3 pos_aa = get_position(x, y - 1, cx, cy, fx, fy, DP(0, -1));
+  const v3 pos_bb = get_position(x + 1, y, cx, cy, fx, fy, DP(1, 0));
+  const v3 pos_cc = get_position(x, y + 1, cx, cy, fx, fy, DP(0, 1));
+  const v3 pos_dd = get_position(x - 1, y, cx, cy, fx, fy, DP(-1, 0));
+  const v3 pos_ab = get_position(x + 1, y - 1, cx, cy, fx, fy, DP(1, -1));
+  const v3 pos_bc = get_position(x + 1, y + 1, cx, cy, fx, fy, DP(1, 1));
+  const v3 pos_cd = get_position(x - 1, y + 1, cx, cy, fx, fy, DP(-1, 1));
+  const v3 pos_da = get_position(x - 1, y - 1, cx, cy, fx, fy, DP(-1, -1));
+#undef DP
+  const v3 edge_a = pos_da - pos_ab, edge_b = pos_ab - pos_bc, edge_c = pos_bc - pos_cd,
+           edge_d = pos_cd - pos_da;
+  const v3 edge_ac = pos_cc - pos_aa, edge_bd = pos_dd - pos_bb;
+  const v3 edge_cdab = pos_ab - pos_cd, edge_bcad = pos_da - pos_bc;
+  const v3 n1 = cross3(edge_a, edge_d), n2 = cross3(edge_d, edge_c), n3 = cross3(edge_c, edge_b);
+  const v3 n4 = cross3(edge_b, edge_a), n5 = cross3(edge_ac, edge_bd), n6 = cross3(edge_bcad, edge_cdab);
+  const v3 sum = normalize3(n1) + normalize3(n2) + normalize3(n3) + normalize3(n4) + normalize3(n5) + normalize3(n6);
+  const float inv6 = 1.0f / 6.0f;  // float3 / float multiplies by the reciprocal (vec_math.h:476)
+  const v3 normal = sum * inv6;
+  normal_out[pix_id] = vm[0] * normal.x + vm[1] * normal.y + vm[2] * normal.z;
+  normal_out[HW + pix_id] = vm[4] * normal.x + vm[5] * normal.y + vm[6] * normal.z;
+  normal_out[2 * HW + pix_id] = vm[8] * normal.x + vm[9] * normal.y + vm[10] * normal.z;
+}
+
+void launch_depth_to_normal(int W, int H, float fx, float fy, const float* viewmatrix,
+                            const float* depth, float* normal, float* depth_pos, hipStream_t s) {
+  dim3 grid((W + 15) / 16, (H + 15) / 16);
+  hipLaunchKernelGGL(depth_to_normal_kernel, grid, dim3(256), 0, s, W, H, fx, fy, viewmatrix,
+                     depth, normal, depth_pos);
+}
+
+// ------------------------------------------------------------------------------------------
+// Ray table: per ray two float4 -- {ts.x, ts.y, ts.z, cos(theta)}, {sin(theta), w, 0, 0}
+// with ts = normalize(sin t cos p, sin t sin p, cos t) and w = cos t * sin t.
+// ------------------------------------------------------------------------------------------
+struct RayTable {
+  float delta = -1.0f;
+  int nrays = 0;
+  float sum_w = 0.0f;  // SSAO's nrSamples, accumulated in fp32 in ray order
+  float4* dev = nullptr;
+  size_t cap = 0;
+};
+static std::mutex g_ray_mu;
+static RayTable g_ray[16];
+
+static int get_ray_table(float delta, hipStream_t s, RayTable& out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -2;
+  std::lock_guard<std::mutex> lk(g_ray_mu);
+  RayTable& t = g_ray[dev];
+  if (t.delta != delta || t.dev == nullptr) {
+    if (!(delta > 1e-4f)) return -1;  // would not terminate / absurd table
+    std::vector<float4> h;
+    const float sampleDelta = delta * kPiF;
+    float sum_w = 0.0f;
+    for (float phi = 0.0f; (double)phi < 2.0 * (double)kPiF; phi += sampleDelta) {
+      for (float theta = 0.0f; (double)theta <= 0.5 * (double)kPiF;
+           theta = (float)((double)theta + (double)sampleDelta * 0.5)) {
+        const float ct = cosf(theta), st = sinf(theta);
+        float tx = st * cosf(phi), ty = st * sinf(phi), tz = ct;
+        const float inv = 1.0f / sqrtf(tx * tx + ty * ty + tz * tz);
+        tx *= inv; ty *= inv; tz *= inv;
+        const float w = ct * st;
+        sum_w += w;
+        h.push_back(make_float4(tx, ty, tz, ct));
+        h.push_back(make_float4(st, w, 0.0f, 0.0f));
+        if (h.size() > (1u << 21)) return -1;
+      }
+    }
+    const size_t bytes = h.size() * sizeof(float4);
+    if (bytes > t.cap) {
+      // one-time (per device, per larger delta) internal allocation; never freed
+      float4* p = nullptr;
+      if (hipMalloc(&p, bytes) != hipSuccess) return -2;
+      t.dev = p;  // an older, smaller table is intentionally leaked: a kernel may still read it
+      t.cap = bytes;
+    }
+    if (hipMemcpyAsync(t.dev, h.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
+    if (hipStreamSynchronize(s) != hipSuccess) return -2;  // h is pageable and goes out of scope
+    t.delta = delta;
+    t.nrays = (int)(h.size() / 2);
+    t.sum_w = sum_w;
+  }
+  out = t;
+  return 0;
+}
+
+struct GiParams {
+  int W, H;
+  float fx, fy, radius, bias, thick;
+  int step, start;
+  float inv_step;  // exact 1/step when step is a power of two
+  int nrays;
+};
+
+// Marches one ray; returns true on a hit and the pixel index of the hit in `q`.
+template <bool kPow2>
+__device__ __forceinline__ bool march(const GiParams& p, v3 pos, float a, v3 sv, float cx, float cy,
+                                      const float* __restrict__ pos_z, int& q) {
+  for (int j = p.start; j < p.step; ++j) {
+    const float fj = (float)j;
+    // pos + sampleVec * j * (1 + z/100) * (1 + z/100) * radius / step, left to right (forward.cu:693)
+    float mx = sv.x * fj, my = sv.y * fj, mz = sv.z * fj;
+    mx = mx * a; my = my * a; mz = mz * a;
+    mx = mx * a; my = my * a; mz = mz * a;
+    mx = mx * p.radius; my = my * p.radius; mz = mz * p.radius;
+    if (kPow2) {
+      mx = mx * p.inv_step; my = my * p.inv_step; mz = mz * p.inv_step;
+    } else {
+      const float fs = (float)p.step;
+      mx = mx / fs; my = my / fs; mz = mz / fs;
+    }
+    const float spx = pos.x + mx, spy = pos.y + my, spz = pos.z + mz;
+    // get_coord (ssr.h:120-135)
+    const float den = spz + 0.0000001f;
+    const float qx = spx / den, qy = spy / den;
+    const int ix = f2i(roundf(qx * p.fx + cx));
+    const int iy = f2i(roundf(qy * p.fy + cy));
+    if (ix < 0 || ix > p.W - 1) return false;
+    if (iy < 0 || iy > p.H - 1) return false;
+    const int idx = p.W * iy + ix;
+    const float sampleDepth = pos_z[idx];
+    if (sampleDepth <= spz + p.bias && sampleDepth >= spz - p.thick) {
+      q = idx;
+      return true;
+    }
+  }
+  return false;
+}
+
+struct Tbn { v3 t, b, n; };
+__device__ __forceinline__ Tbn make_tbn(v3 normal_un) {
+  Tbn r;
+  r.n = normalize3(normal_un);
+  const v3 up = {0.0f, 1.0f, 0.0f};
+  const float rndot = dot3(up, r.n);
+  const v3 untangent = {up.x - r.n.x * rndot, up.y - r.n.y * rndot, up.z - r.n.z * rndot};
+  r.t = normalize3(untangent);
+  r.b = normalize3(cross3(r.n, r.t));
+  return r;
+}
+// transformVec3x3(ts, TBN) with TBN rows (t, b, n): auxiliary.h:90-98
+__device__ __forceinline__ v3 tbn_apply(const Tbn& m, float x, float y, float z) {
+  return {m.t.x * x + m.b.x * y + m.n.x * z, m.t.y * x + m.b.y * y + m.n.y * z,
+          m.t.z * x + m.b.z * y + m.n.z * z};
+}
+
+__device__ __forceinline__ bool gi_pixel(int W, int H, int& x, int& y) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  return x < W && y < H;
+}
+
+template <bool kPow2>
+__global__ void __launch_bounds__(256)
+ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
+            const float* __restrict__ nrm, const float* __restrict__ pos_map,
+            float* __restrict__ occlusion) {
+  int x, y;
+  if (!gi_pixel(p.W, p.H, x, y)) return;
+  const size_t HW = (size_t)p.H * p.W;
+  const size_t pix_id = (size_t)p.W * y + x;
+  const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
+  const v3 pos = {pos_map[pix_id], pos_map[HW + pix_id], pos_map[2 * HW + pix_id]};
+  const float* pos_z = pos_map + 2 * HW;
+  const float a = 1 + pos.z / 100;
+  const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
+  float occ = 0.0f;
+  if (p.start < p.step) {
+    for (int r = 0; r < p.nrays; r++) {
+      const float4 r0 = rays[2 * r];      // wave-uniform -> scalar loads
+      const float4 r1 = rays[2 * r + 1];
+      const v3 sv = tbn_apply(tbn, r0.x, r0.y, r0.z);
+      int q;
+      if (march<kPow2>(p, pos, a, sv, cx, cy, pos_z, q)) occ += r1.y;
+    }
+  }
+  if (sum_w > 0.0f)
+    occlusion[pix_id] = fmaxf(0.0f, fminf(1.0f, (float)(1.0 - (double)(occ / sum_w))));
+  else
+    occlusion[pix_id] = 1.0f;
+}
+
+template <bool kPow2>
+__global__ void __launch_bounds__(256)
+ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict__ nrm,
+           const float* __restrict__ pos_map, const float* __restrict__ rgb,
+           const float* __restrict__ albedo_map, const float* __restrict__ metallic_map,
+           const float* __restrict__ F0_map, float* __restrict__ color, float* __restrict__ abd) {
+  int x, y;
+  if (!gi_pixel(p.W, p.H, x, y)) return;
+  const size_t HW = (size_t)p.H * p.W;
+  const size_t pix_id = (size_t)p.W * y + x;
+  const v3 pos = {pos_map[pix_id], pos_map[HW + pix_id], pos_map[2 * HW + pix_id]};
+  const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
+  const v3 N = tbn.n;
+  const v3 alb = {albedo_map[pix_id], albedo_map[HW + pix_id], albedo_map[2 * HW + pix_id]};
+  const v3 F0 = {F0_map[pix_id], F0_map[HW + pix_id], F0_map[2 * HW + pix_id]};
+  const float metallic = metallic_map[pix_id];
+  const v3 V = normalize3({-pos.x, -pos.y, -pos.z});
+  // fresnelSchlick (ssr.h:13-16): pow evaluated in double
+  const float cosTheta = fmaxf(dot3(N, V), (float)0.0000001);
+  const float pw = (float)pow((double)fminf(fmaxf((float)(1.0 - (double)cosTheta), (float)0.000001), 1.0f), 5.0);
+  const v3 F = {F0.x + (1.0f - F0.x) * pw, F0.y + (1.0f - F0.y) * pw, F0.z + (1.0f - F0.z) * pw};
+  v3 kD = {(float)(1.0 - (double)F.x), (float)(1.0 - (double)F.y), (float)(1.0 - (double)F.z)};
+  kD.x = (float)((double)kD.x * (1.0 - (double)metallic));
+  kD.y = (float)((double)kD.y * (1.0 - (double)metallic));
+  kD.z = (float)((double)kD.z * (1.0 - (double)metallic));
+
+  const float* pos_z = pos_map + 2 * HW;
+  const float a = 1 + pos.z / 100;
+  const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
+  v3 diffuse = {0, 0, 0};
+  if (p.start < p.step) {
+    for (int r = 0; r < p.nrays; r++) {
+      const float4 r0 = rays[2 * r];
+      const float4 r1 = rays[2 * r + 1];
+      const v3 sv = tbn_apply(tbn, r0.x, r0.y, r0.z);
+      int q;
+      if (march<kPow2>(p, pos, a, sv, cx, cy, pos_z, q)) {
+        // rgb * cosf(theta) * sinf(theta), left to right (forward.cu:824-826)
+        diffuse.x += rgb[q] * r0.w * r1.x;
+        diffuse.y += rgb[HW + q] * r0.w * r1.x;
+        diffuse.z += rgb[2 * HW + q] * r0.w * r1.x;
+      }
+    }
+  }
+  const float nrSamples = (float)p.nrays;  // += 1 per ray in fp32 is exact below 2^24
+  v3 gd;
+  if (nrSamples > 0.0f) {
+    gd.x = (float)((double)(kPiF * diffuse.x) * (1.0 / (double)nrSamples) * (double)kD.x);
+    gd.y = (float)((double)(kPiF * diffuse.y) * (1.0 / (double)nrSamples) * (double)kD.y);
+    gd.z = (float)((double)(kPiF * diffuse.z) * (1.0 / (double)nrSamples) * (double)kD.z);
+    diffuse = {gd.x * alb.x, gd.y * alb.y, gd.z * alb.z};
+  } else {
+    diffuse = {(float)0.0000001, (float)0.0000001, (float)0.0000001};
+    gd = diffuse;
+  }
+  color[pix_id] = diffuse.x;
+  color[HW + pix_id] = diffuse.y;
+  color[2 * HW + pix_id] = diffuse.z;
+  abd[pix_id] = gd.x;
+  abd[HW + pix_id] = gd.y;
+  abd[2 * HW + pix_id] = gd.z;
+}
+
+static GiParams make_params(int W, int H, float fx, float fy, float radius, float bias, float thick,
+                            int step, int start, int nrays, bool& pow2) {
+  GiParams p;
+  p.W = W; p.H = H; p.fx = fx; p.fy = fy; p.radius = radius; p.bias = bias; p.thick = thick;
+  p.step = step; p.start = start; p.nrays = nrays;
+  pow2 = step > 0 && (step & (step - 1)) == 0 && step <= (1 << 20);
+  p.inv_step = pow2 ? 1.0f / (float)step : 0.0f;
+  return p;
+}
+
+int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, float thick,
+                float delta, int step, int start, const float* normal, const float* pos,
+                float* occlusion, hipStream_t s) {
+  RayTable t;
+  const int rc = get_ray_table(delta, s, t);
+  if (rc) return rc;
+  bool pow2;
+  const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
+  dim3 grid((W + 15) / 16, (H + 15) / 16);
+  if (pow2)
+    hipLaunchKernelGGL(ssao_kernel<true>, grid, dim3(256), 0, s, p, t.dev, t.sum_w, normal, pos, occlusion);
+  else
+    hipLaunchKernelGGL(ssao_kernel<false>, grid, dim3(256), 0, s, p, t.dev, t.sum_w, normal, pos, occlusion);
+  return 0;
+}
+
+int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float thick,
+               float delta, int step, int start, const float* normal, const float* pos,
+               const float* rgb, const float* albedo, const float* /*roughness*/,
+               const float* metallic, const float* F0, float* color, float* abd, hipStream_t s) {
+  RayTable t;
+  const int rc = get_ray_table(delta, s, t);
+  if (rc) return rc;
+  bool pow2;
+  const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
+  dim3 grid((W + 15) / 16, (H + 15) / 16);
+  if (pow2)
+    hipLaunchKernelGGL(ssr_kernel<true>, grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd);
+  else
+    hipLaunchKernelGGL(ssr_kernel<false>, grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// 3x3 filters
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(float& a, float& b) {
+  const float lo = fminf(a, b), hi = fmaxf(a, b);
+  a = lo;
+  b = hi;
+}
+// median of 9 by the classic 19-exchange network (NaN-free inputs)
+__device__ __forceinline__ float median9(float* v) {
+  cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+  cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+  cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+  cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+  cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
+  cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+  cswap(v[4], v[2]);
+  return v[4];
+}
+
+__device__ __forceinline__ bool load_taps(const float* __restrict__ src, int H, int W, int y, int x,
+                                          float* v) {
+  bool has_nan = false;
+  int k = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++) {
+      const int yy = y + dy, xx = x + dx;
+      const float t = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0.0f : src[(size_t)yy * W + xx];
+      has_nan |= (t != t);
+      v[k++] = t;
+    }
+  return has_nan;
+}
+
+__global__ void __launch_bounds__(256)
+median3x3_kernel(int H, int W, const float* __restrict__ in, float* __restrict__ out) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const float* src = in + (size_t)blockIdx.z * H * W;
+  float v[9];
+  const bool has_nan = load_taps(src, H, W, y, x, v);
+  out[(size_t)blockIdx.z * H * W + (size_t)y * W + x] = has_nan ? __builtin_nanf("") : median9(v);
+}
+
+// Gradient of the median: the whole output gradient goes to the first tap (row-major tap
+// order) whose value equals the median; NaN windows pass no gradient.
+__global__ void __launch_bounds__(256)
+median3x3_bwd_kernel(int H, int W, const float* __restrict__ in, const float* __restrict__ gout,
+                     float* __restrict__ gin) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const size_t plane = (size_t)blockIdx.z * H * W;
+  const float* src = in + plane;
+  float v[9], s[9];
+  const bool has_nan = load_taps(src, H, W, y, x, v);
+  if (has_nan) return;
+#pragma unroll
+  for (int k = 0; k < 9; k++) s[k] = v[k];
+  const float med = median9(s);
+  const float g = gout[plane + (size_t)y * W + x];
+  if (g == 0.0f) return;
+  int k = 0;
+  for (int dy = -1; dy <= 1; dy++)
+    for (int dx = -1; dx <= 1; dx++, k++) {
+      if (v[k] == med) {
+        const int yy = y + dy, xx = x + dx;
+        if (!(yy < 0 || yy >= H || xx < 0 || xx >= W)) atomicAdd(gin + plane + (size_t)yy * W + xx, g);
+        return;  // a padding tap selected: gradient is dropped
+      }
+    }
+}
+
+void launch_median3x3(int C, int H, int W, const float* in, float* out, hipStream_t s) {
+  dim3 grid((W + 63) / 64, (H + 3) / 4, C);
+  hipLaunchKernelGGL(median3x3_kernel, grid, dim3(256), 0, s, H, W, in, out);
+}
+void launch_median3x3_bwd(int C, int H, int W, const float* in, const float* gout, float* gin,
+                          hipStream_t s) {
+  dim3 grid((W + 63) / 64, (H + 3) / 4, C);
+  hipLaunchKernelGGL(median3x3_bwd_kernel, grid, dim3(256), 0, s, H, W, in, gout, gin);
+}
+
+struct BilatK { float ky[3], kx[3]; float color_scale; };
+
+template <int C>
+__global__ void __launch_bounds__(256)
+bilateral3x3_kernel(int H, int W, BilatK kk, const float* __restrict__ in, float* __restrict__ out) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const size_t HW = (size_t)H * W;
+  float ctr[C], num[C];
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    ctr[c] = in[c * HW + (size_t)y * W + x];
+    num[c] = 0.0f;
+  }
+  float den = 0.0f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++) {
+      int yy = y + dy, xx = x + dx;
+      yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);  // reflect
+      xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+      float tap[C], dist = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        tap[c] = in[c * HW + (size_t)yy * W + xx];
+        dist += fabsf(tap[c] - ctr[c]);
+      }
+      const float color_k = expf(kk.color_scale * (dist * dist));
+      const float k = (kk.ky[dy + 1] * kk.kx[dx + 1]) * color_k;
+#pragma unroll
+      for (int c = 0; c < C; c++) num[c] += tap[c] * k;
+      den += k;
+    }
+#pragma unroll
+  for (int c = 0; c < C; c++) out[c * HW + (size_t)y * W + x] = num[c] / den;
+}
+
+void launch_bilateral3x3(int C, int H, int W, float sigma_color, float sx, float sy,
+                         const float* in, float* out, hipStream_t s) {
+  BilatK kk;
+  auto k1d = [](float sigma, float* k) {
+    float sum = 0;
+    for (int i = 0; i < 3; i++) {
+      const float xv = (float)(i - 1);
+      k[i] = expf(-(xv * xv) / (2.0f * sigma * sigma));
+      sum += k[i];
+    }
+    for (int i = 0; i < 3; i++) k[i] /= sum;
+  };
+  k1d(sy, kk.ky);
+  k1d(sx, kk.kx);
+  kk.color_scale = -0.5f / (sigma_color * sigma_color);
+  dim3 grid((W + 63) / 64, (H + 3) / 4, 1);
+  if (C == 1) hipLaunchKernelGGL(bilateral3x3_kernel<1>, grid, dim3(256), 0, s, H, W, kk, in, out);
+  else if (C == 3) hipLaunchKernelGGL(bilateral3x3_kernel<3>, grid, dim3(256), 0, s, H, W, kk, in, out);
+}
+
+}  // namespace gigs

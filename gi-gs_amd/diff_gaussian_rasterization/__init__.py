@@ -1,0 +1,522 @@
+"""Drop-in for the reference's `diff_gaussian_rasterization` package on MI355X.
+
+Same public names, argument order, return tuples and error messages as
+submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py ("R/…/__init__.py")
+of piotrmwojcik/GI-GS:
+
+    GaussianRasterizationSettings   R/…/__init__.py:31-51
+    GaussianRasterizer              :375-537   (forward 12-tuple, markVisible)
+    Gaussian_SSR                    :696-743
+    _C.{rasterize_gaussians, rasterize_gaussians_backward, mark_visible, depth_to_normal,
+        SSAO, SSR}                  R/ext.cpp:16-23, R/rasterize_points.cu
+
+but every kernel behind it is the HIP implementation in libgigs_hip.so, reached through the
+C ABI of include/gigs_hip.h with raw device pointers and the current torch stream.  The
+kornia 3x3 median / bilateral blurs the reference calls inside `GaussianRasterizer.forward`
+(:478, :491, :504) are HIP kernels as well (`filters`).  There is no CPU path: tensors must
+live on a HIP device and the shared library must be present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+from types import SimpleNamespace
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _PKG_ROOT not in sys.path:
+    sys.path.insert(0, _PKG_ROOT)
+
+import gigs_lib  # noqa: E402
+from gigs_lib import GigsError  # noqa: E402,F401
+
+_lib = gigs_lib.lib()  # fail at import time if the native library is missing
+
+NUM_CHANNELS = 3
+
+
+def cpu_deep_copy_tuple(input_tuple: Tuple) -> Tuple:
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    radius: float
+    bias: float
+    thick: float
+    delta: float
+    step: int
+    start: int
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    inference: bool
+    argmax_depth: bool
+
+
+# ------------------------------------------------------------------------------------------
+# pointer plumbing
+# ------------------------------------------------------------------------------------------
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must be a CUDA/HIP tensor: diff_gaussian_rasterization (gigs-hip) has no CPU path")
+
+
+def _fptr(t: Optional[torch.Tensor], name: str, device=None) -> Tuple[Optional[int], Optional[torch.Tensor]]:
+    """float32 device pointer of `t`, or NULL for None / empty (the reference's empty-tensor
+    convention, R/…/__init__.py:435-445).  Returns (ptr, keepalive)."""
+    if t is None or t.numel() == 0:
+        return None, None
+    _need_gpu(t, name)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.contiguous().float()
+    return t.data_ptr(), t
+
+
+class _Scratch:
+    """One resizable byte buffer + the ctypes callback that hands it to the library; the
+    counterpart of resizeFunctional (R/rasterize_points.cu:31-37)."""
+
+    def __init__(self, device):
+        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+
+        def _alloc(nbytes, _user):
+            try:
+                self.t.resize_(int(nbytes))
+                return self.t.data_ptr()
+            except Exception:  # noqa: BLE001 - reported by the library as GIGS_ERR_ALLOC
+                return 0
+
+        self.cb = gigs_lib.ALLOC_FN(_alloc)
+
+
+# ------------------------------------------------------------------------------------------
+# `_C` functions
+# ------------------------------------------------------------------------------------------
+def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo, roughness, metallic,
+                         scales, rotations, cov3Ds_precomp, sh, campos, viewmatrix, projmatrix,
+                         scale_modifier, tanfovx, tanfovy, image_height, image_width, sh_degree,
+                         prefiltered, argmax_depth, inference, debug):
+    """_C.rasterize_gaussians: 25 positional args -> 14-tuple (R/rasterize_points.cu:130-252)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _need_gpu(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    fopts = dict(dtype=torch.float32, device=dev)
+    out_color = torch.zeros((NUM_CHANNELS, H, W), **fopts)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    out_opacity = torch.zeros((1, H, W), **fopts)
+    out_depth = torch.zeros((1, H, W), **fopts)
+    out_normal = torch.zeros((NUM_CHANNELS, H, W), **fopts)
+    out_normal_view = torch.zeros((NUM_CHANNELS, H, W), **fopts)
+    out_pos = torch.zeros((NUM_CHANNELS, H, W), **fopts)
+    out_albedo = torch.zeros((NUM_CHANNELS, H, W), **fopts)
+    out_roughness = torch.zeros((1, H, W), **fopts)
+    out_metallic = torch.zeros((1, H, W), **fopts)
+    geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+    rendered = 0
+    if P != 0:
+        M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
+        keep = []
+
+        def p(t, name):
+            ptr, k = _fptr(t, name)
+            keep.append(k)
+            return ptr
+
+        with torch.cuda.device(dev):
+            rendered = _lib.gigs_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(sh_degree), M, p(bg, "bg"), W, H,
+                p(means3D, "means3D"), p(sh, "sh"), p(colors_precomp, "colors_precomp"),
+                p(opacities, "opacities"), p(normal, "normal"), p(albedo, "albedo"),
+                p(roughness, "roughness"), p(metallic, "metallic"), p(scales, "scales"),
+                float(scale_modifier), p(rotations, "rotations"), p(cov3Ds_precomp, "cov3Ds_precomp"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+                float(tanfovx), float(tanfovy), int(bool(prefiltered)), int(bool(argmax_depth)),
+                int(bool(inference)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
+                out_normal.data_ptr(), out_normal_view.data_ptr(), out_pos.data_ptr(),
+                out_albedo.data_ptr(), out_roughness.data_ptr(), out_metallic.data_ptr(),
+                radii.data_ptr(), int(debug), _stream())
+        gigs_lib.check(rendered, "rasterize_gaussians")
+    return (rendered, out_color, radii, geom.t, binning.t, img.t, out_opacity, out_depth, out_normal,
+            out_normal_view, out_pos, out_albedo, out_roughness, out_metallic)
+
+
+def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, albedo, roughness,
+                                  metallic, scales, rotations, cov3Ds_precomp, sh, campos, viewmatrix,
+                                  projmatrix, scale_modifier, tanfovx, tanfovy, sh_degree, grad_depth,
+                                  grad_color, grad_opacity, grad_normal, grad_albedo, grad_roughness,
+                                  grad_metallic, geomBuffer, binningBuffer, imgBuffer, num_rendered, debug):
+    """_C.rasterize_gaussians_backward: 31 args -> 12 tensors (R/rasterize_points.cu:254-364)."""
+    _need_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(grad_color.size(1)), int(grad_color.size(2))
+    M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, NUM_CHANNELS)
+    dL_dconic, dL_ddepth, dL_dopacity = z(P, 2, 2), z(P, 1), z(P, 1)
+    dL_dnormal, dL_dalbedo, dL_droughness, dL_dmetallic = z(P, 3), z(P, 3), z(P, 1), z(P, 1)
+    dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
+    if P != 0:
+        keep = []
+
+        def p(t, name):
+            ptr, k = _fptr(t, name)
+            keep.append(k)
+            return ptr
+
+        with torch.cuda.device(dev):
+            rc = _lib.gigs_backward(
+                P, int(sh_degree), M, int(num_rendered), p(bg, "bg"), W, H, p(means3D, "means3D"),
+                p(sh, "sh"), p(colors_precomp, "colors_precomp"), p(normal, "normal"), p(albedo, "albedo"),
+                p(roughness, "roughness"), p(metallic, "metallic"), p(scales, "scales"),
+                p(rotations, "rotations"), p(cov3Ds_precomp, "cov3Ds_precomp"), p(viewmatrix, "viewmatrix"),
+                p(projmatrix, "projmatrix"), p(campos, "campos"), radii.data_ptr(), float(scale_modifier),
+                float(tanfovx), float(tanfovy), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                imgBuffer.data_ptr(), p(grad_depth, "grad_depth"), p(grad_color, "grad_color"),
+                p(grad_opacity, "grad_opacity"), p(grad_normal, "grad_normal"), p(grad_albedo, "grad_albedo"),
+                p(grad_roughness, "grad_roughness"), p(grad_metallic, "grad_metallic"),
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_ddepth.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dnormal.data_ptr(), dL_dalbedo.data_ptr(), dL_droughness.data_ptr(),
+                dL_dmetallic.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
+                dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
+                dL_drotations.data_ptr(), int(debug), _stream())
+        gigs_lib.check(rc, "rasterize_gaussians_backward")
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dnormal, dL_dalbedo, dL_droughness, dL_dmetallic,
+            dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+
+
+def _mark_visible(means3D, viewmatrix, projmatrix):
+    _need_gpu(means3D, "means3D")
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        m, k0 = _fptr(means3D, "means3D")
+        v, k1 = _fptr(viewmatrix, "viewmatrix")
+        pr, k2 = _fptr(projmatrix, "projmatrix")
+        with torch.cuda.device(means3D.device):
+            gigs_lib.check(_lib.gigs_mark_visible(P, m, v, pr, present.data_ptr(), _stream()), "mark_visible")
+    return present
+
+
+def _depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depthMap):
+    _need_gpu(depthMap, "depthMap")
+    dev = depthMap.device
+    normalMap = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
+    depth_pos = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
+    v, k0 = _fptr(viewmatrix, "viewmatrix")
+    d, k1 = _fptr(depthMap, "depthMap")
+    with torch.cuda.device(dev):
+        gigs_lib.check(_lib.gigs_depth_to_normal(int(width), int(height), float(focal_x), float(focal_y), v, d,
+                                                 normalMap.data_ptr(), depth_pos.data_ptr(), _stream()),
+                       "depth_to_normal")
+    return normalMap, depth_pos
+
+
+def _SSAO(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, out_normal, out_pos):
+    _need_gpu(out_normal, "out_normal")
+    dev = out_normal.device
+    occlusion = torch.ones((1, height, width), dtype=torch.float32, device=dev)
+    n, k0 = _fptr(out_normal, "out_normal")
+    ps, k1 = _fptr(out_pos, "out_pos")
+    with torch.cuda.device(dev):
+        gigs_lib.check(_lib.gigs_ssao(int(width), int(height), float(focal_x), float(focal_y), float(radius),
+                                      float(bias), float(thick), float(delta), int(step), int(start), n, ps,
+                                      occlusion.data_ptr(), _stream()), "SSAO")
+    return occlusion
+
+
+def _SSR(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, out_normal, out_pos,
+         out_rgb, out_albedo, out_roughness, out_metallic, out_F0):
+    _need_gpu(out_roughness, "out_roughness")
+    dev = out_roughness.device
+    color = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
+    abd = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
+    ptrs, keep = [], []
+    for t, name in ((out_normal, "out_normal"), (out_pos, "out_pos"), (out_rgb, "out_rgb"),
+                    (out_albedo, "out_albedo"), (out_roughness, "out_roughness"),
+                    (out_metallic, "out_metallic"), (out_F0, "out_F0")):
+        ptr, k = _fptr(t, name)
+        ptrs.append(ptr)
+        keep.append(k)
+    with torch.cuda.device(dev):
+        gigs_lib.check(_lib.gigs_ssr(int(width), int(height), float(focal_x), float(focal_y), float(radius),
+                                     float(bias), float(thick), float(delta), int(step), int(start), *ptrs,
+                                     color.data_ptr(), abd.data_ptr(), _stream()), "SSR")
+    return color, abd
+
+
+def _SSR_BACKWARD(*_args):
+    # The reference exports BACKWARD::SSRCUDA (R/cuda_rasterizer/backward.cu:632-808) but never calls
+    # it: _SSR.backward is closed-form (R/…/__init__.py:666-673).  Kept as a named symbol only.
+    raise NotImplementedError(
+        "SSR_BACKWARD is unreachable in the reference (commented out at __init__.py:666-670); "
+        "Gaussian_SSR's backward is grad_albedo = grad_out * abd")
+
+
+def _lite_rasterize_gaussians(*_args):
+    # exported by the reference (R/ext.cpp:21) but called from nowhere in its Python
+    raise NotImplementedError("lite_rasterize_gaussians has no caller in the reference and is not built yet")
+
+
+_C = SimpleNamespace(
+    rasterize_gaussians=_rasterize_gaussians,
+    rasterize_gaussians_backward=_rasterize_gaussians_backward,
+    lite_rasterize_gaussians=_lite_rasterize_gaussians,
+    mark_visible=_mark_visible,
+    depth_to_normal=_depth_to_normal,
+    SSAO=_SSAO,
+    SSR=_SSR,
+    SSR_BACKWARD=_SSR_BACKWARD,
+)
+
+
+# ------------------------------------------------------------------------------------------
+# 3x3 filters (replace kornia.filters.median_blur / bilateral_blur for the (3, 3) case)
+# ------------------------------------------------------------------------------------------
+class _Median3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):  # x: [C, H, W]
+        _need_gpu(x, "input")
+        xc = x.contiguous().float()
+        out = torch.empty_like(xc)
+        Cn, H, W = xc.shape
+        with torch.cuda.device(xc.device):
+            gigs_lib.check(_lib.gigs_median3x3(Cn, H, W, xc.data_ptr(), out.data_ptr(), _stream()), "median3x3")
+        ctx.save_for_backward(xc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        gc = g.contiguous().float()
+        gin = torch.zeros_like(xc)
+        Cn, H, W = xc.shape
+        with torch.cuda.device(xc.device):
+            gigs_lib.check(_lib.gigs_median3x3_backward(Cn, H, W, xc.data_ptr(), gc.data_ptr(), gin.data_ptr(),
+                                                        _stream()), "median3x3_backward")
+        return gin
+
+
+def _median_blur(input: torch.Tensor, kernel_size=(3, 3)) -> torch.Tensor:
+    """kornia.filters.median_blur for [B, C, H, W] input and a (3, 3) kernel."""
+    if tuple(kernel_size) != (3, 3):
+        raise NotImplementedError("only the (3, 3) median used by GI-GS is implemented")
+    B, Cn, H, W = input.shape
+    return _Median3x3.apply(input.reshape(B * Cn, H, W)).reshape(B, Cn, H, W)
+
+
+def _bilateral_blur(input: torch.Tensor, kernel_size=(3, 3), sigma_color=1.0, sigma_space=(3.0, 3.0)):
+    """kornia.filters.bilateral_blur for [B, C, H, W], (3, 3) kernel, reflect border, L1 colour
+    distance (kornia defaults).  Forward only -- the reference applies it to a tensor without a
+    graph (R/…/__init__.py:491)."""
+    if tuple(kernel_size) != (3, 3):
+        raise NotImplementedError("only the (3, 3) bilateral used by GI-GS is implemented")
+    _need_gpu(input, "input")
+    B, Cn, H, W = input.shape
+    x = input.detach().contiguous().float()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        for b in range(B):
+            gigs_lib.check(_lib.gigs_bilateral3x3(Cn, H, W, float(sigma_color), float(sigma_space[1]),
+                                                  float(sigma_space[0]), x[b].data_ptr(), out[b].data_ptr(),
+                                                  _stream()), "bilateral3x3")
+    return out
+
+
+filters = SimpleNamespace(median_blur=_median_blur, bilateral_blur=_bilateral_blur)
+
+
+# ------------------------------------------------------------------------------------------
+# autograd glue (A14): argument re-ordering identical to R/…/__init__.py:54-372
+# ------------------------------------------------------------------------------------------
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, normal, albedo, roughness, metallic, sh, colors_precomp,
+                scales, rotations, cov3Ds_precomp, raster_settings):
+        args = (
+            raster_settings.bg, means3D, colors_precomp, opacities, normal, albedo, roughness, metallic,
+            scales, rotations, cov3Ds_precomp, sh, raster_settings.campos, raster_settings.viewmatrix,
+            raster_settings.projmatrix, raster_settings.scale_modifier, raster_settings.tanfovx,
+            raster_settings.tanfovy, raster_settings.image_height, raster_settings.image_width,
+            raster_settings.sh_degree, raster_settings.prefiltered, raster_settings.argmax_depth,
+            raster_settings.inference, raster_settings.debug,
+        )
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                res = _C.rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            res = _C.rasterize_gaussians(*args)
+        (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, opacity_map, depth, out_normal,
+         out_normal_view, out_pos, albedo_map, roughness_map, metallic_map) = res
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, normal, albedo, roughness, metallic, means3D, scales, rotations,
+                              cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return (color, radii, opacity_map, depth, out_normal, albedo_map, roughness_map, metallic_map,
+                out_normal_view, out_pos)
+
+    @staticmethod
+    def backward(ctx, grad_out_color, gard_radii=None, grad_out_opacity=None, grad_depth=None,
+                 grad_out_normal=None, grad_out_albedo=None, grad_out_roughness=None, grad_out_metallic=None,
+                 grad_out_normal_view=None, grad_out_pos=None):
+        num_rendered = ctx.num_rendered
+        raster_settings = ctx.raster_settings
+        (colors_precomp, normal, albedo, roughness, metallic, means3D, scales, rotations, cov3Ds_precomp,
+         radii, sh, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+        # grad_out_normal_view and grad_out_pos are dropped, as in the reference (:243-275)
+        args = (
+            raster_settings.bg, means3D, radii, colors_precomp, normal, albedo, roughness, metallic, scales,
+            rotations, cov3Ds_precomp, sh, raster_settings.campos, raster_settings.viewmatrix,
+            raster_settings.projmatrix, raster_settings.scale_modifier, raster_settings.tanfovx,
+            raster_settings.tanfovy, raster_settings.sh_degree, grad_depth, grad_out_color, grad_out_opacity,
+            grad_out_normal, grad_out_albedo, grad_out_roughness, grad_out_metallic, geomBuffer, binningBuffer,
+            imgBuffer, num_rendered, raster_settings.debug,
+        )
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                res = _C.rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            res = _C.rasterize_gaussians_backward(*args)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_normal, grad_albedo, grad_roughness,
+         grad_metallic, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations) = res
+        return (grad_means3D, grad_means2D, grad_opacities, grad_normal, grad_albedo, grad_roughness,
+                grad_metallic, grad_sh, grad_colors_precomp, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = _C.mark_visible(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, opacities, normal, albedo, roughness, metallic, shs=None,
+                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, derive_normal=True):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None
+        ):
+            raise Exception(
+                "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!"
+            )
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+
+        (color, radii, opacity_map, depth, out_normal, albedo_map, roughness_map, metallic_map,
+         out_normal_view, _) = _RasterizeGaussians.apply(
+            means3D, means2D, opacities, normal, albedo, roughness, metallic, shs, colors_precomp, scales,
+            rotations, cov3D_precomp, raster_settings)
+
+        focal_x = raster_settings.image_width / (2.0 * raster_settings.tanfovx)
+        focal_y = raster_settings.image_height / (2.0 * raster_settings.tanfovy)
+        if derive_normal:
+            depth_filter = filters.median_blur(depth.detach()[None, ...], (3, 3))[0]
+            normal_from_depth, depth_pos = _C.depth_to_normal(
+                raster_settings.image_width, raster_settings.image_height, focal_x, focal_y,
+                raster_settings.viewmatrix, depth_filter)
+        else:
+            normal_from_depth = torch.zeros_like(out_normal)
+            depth_pos = torch.zeros_like(out_normal)
+
+        normal_from_depth = filters.bilateral_blur(normal_from_depth[None, ...], (3, 3), 1, (3, 3))[0]
+
+        depth_pos_filter = filters.median_blur(depth_pos[None, ...], (3, 3))[0]
+        occlusion = _C.SSAO(
+            raster_settings.image_width, raster_settings.image_height, focal_x, focal_y,
+            raster_settings.radius, raster_settings.bias, raster_settings.thick, raster_settings.delta,
+            raster_settings.step, raster_settings.start, out_normal_view, depth_pos_filter)
+
+        return (color, radii, opacity_map, depth, normal_from_depth, out_normal, occlusion, albedo_map,
+                roughness_map, metallic_map, out_normal_view, depth_pos_filter)
+
+
+class _SSR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image_width, image_height, focal_x, focal_y, radius, bias, thick, delta, step, start,
+                normal, pos, rgb, albedo, roughness, metallic, F0):
+        (color, abd) = _C.SSR(image_width, image_height, focal_x, focal_y, radius, bias, thick, delta, step,
+                              start, normal, pos, rgb, albedo, roughness, metallic, F0)
+        ctx.save_for_backward(roughness, metallic, abd)
+        return (color, abd)
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_abd=None):
+        roughness, metallic, abd = ctx.saved_tensors
+        # closed form, R/…/__init__.py:671-673
+        grad_albedo = grad_out_color * abd
+        grad_roughness = torch.zeros_like(roughness)
+        grad_metallic = torch.zeros_like(metallic)
+        return (None, None, None, None, None, None, None, None, None, None, None, None, None,
+                grad_albedo, grad_roughness, grad_metallic, None)
+
+
+class Gaussian_SSR(nn.Module):
+    def __init__(self, tanfovx, tanfovy, image_width, image_height, radius, bias, thick, delta, step, start):
+        super().__init__()
+        self.tanfovx = tanfovx
+        self.tanfovy = tanfovy
+        self.image_width = image_width
+        self.image_height = image_height
+        self.radius = radius
+        self.bias = bias
+        self.thick = thick
+        self.delta = delta
+        self.step = step
+        self.start = start
+
+    def forward(self, normal, pos, rgb, albedo, roughness, metallic, F0):
+        focal_x = self.image_width / (2.0 * self.tanfovx)
+        focal_y = self.image_height / (2.0 * self.tanfovy)
+        (color, abd) = _SSR.apply(self.image_width, self.image_height, focal_x, focal_y, self.radius,
+                                  self.bias, self.thick, self.delta, self.step, self.start, normal, pos, rgb,
+                                  albedo, roughness, metallic, F0)
+        return (color, abd)

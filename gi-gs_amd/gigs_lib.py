@@ -1,0 +1,86 @@
+"""ctypes binding of libgigs_hip.so (C ABI in include/gigs_hip.h).
+
+This is the only place the product talks to native code.  There is NO fallback: if the
+shared library is missing or a call fails, an exception is raised -- the oracle under
+oracle/ is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgigs_hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+
+_f = C.c_void_p  # device pointers are passed as integers
+_i = C.c_int
+_fl = C.c_float
+
+# name -> (restype, argtypes); must list every symbol declared in include/gigs_hip.h
+SIGNATURES = {
+    "gigs_last_error": (C.c_char_p, []),
+    "gigs_build_arch": (C.c_char_p, []),
+    "gigs_required_geom": (C.c_size_t, [_i]),
+    "gigs_required_image": (C.c_size_t, [_i, _i]),
+    "gigs_required_binning": (C.c_size_t, [_i]),
+    "gigs_forward": (_i, [ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
+                          _i, _i, _i, _f, _i, _i,            # P D M background width height
+                          _f, _f, _f, _f, _f, _f, _f, _f,    # means3D shs colors opac normal albedo rough metal
+                          _f, _fl, _f, _f,                   # scales scale_modifier rotations cov3D
+                          _f, _f, _f, _fl, _fl,              # view proj campos tanfovx tanfovy
+                          _i, _i, _i,                        # prefiltered argmax_depth inference
+                          _f, _f, _f, _f, _f, _f, _f, _f, _f,  # 9 output planes
+                          _f, _i, C.c_void_p]),              # radii debug stream
+    "gigs_backward": (_i, [_i, _i, _i, _i, _f, _i, _i,       # P D M R background width height
+                           _f, _f, _f, _f, _f, _f, _f,       # means3D shs colors normal albedo rough metal
+                           _f, _f, _f, _f, _f, _f, _f,       # scales rotations cov3D view proj campos radii
+                           _fl, _fl, _fl,                    # scale_modifier tanfovx tanfovy
+                           _f, _f, _f,                       # geom binning image buffers
+                           _f, _f, _f, _f, _f, _f, _f,       # 7 incoming grads
+                           _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,  # 14 outputs
+                           _i, C.c_void_p]),
+    "gigs_mark_visible": (_i, [_i, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_depth_to_normal": (_i, [_i, _i, _fl, _fl, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_ssao": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, C.c_void_p]),
+    "gigs_ssr": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f,
+                      C.c_void_p]),
+    "gigs_median3x3": (_i, [_i, _i, _i, _f, _f, C.c_void_p]),
+    "gigs_median3x3_backward": (_i, [_i, _i, _i, _f, _f, _f, C.c_void_p]),
+    "gigs_bilateral3x3": (_i, [_i, _i, _i, _fl, _fl, _fl, _f, _f, C.c_void_p]),
+    "gigs_geom_offset": (C.c_longlong, [_i, _i]),
+    "gigs_binning_offset": (C.c_longlong, [_i, _i]),
+    "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),
+    "gigs_last_stage_ms": (_i, [C.POINTER(C.c_float), _i]),
+}
+
+_lib = None
+
+
+class GigsError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libgigs_hip.so (built by gi-gs_amd/build.py); raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python gi-gs_amd/build.py` "
+                "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        msg = lib().gigs_last_error().decode("utf-8", "replace")
+        raise GigsError(f"{what} failed ({rc}): {msg}")
+    return rc

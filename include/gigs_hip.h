@@ -1,0 +1,140 @@
+/* gigs_hip.h -- C ABI of libgigs_hip.so, the MI355X (gfx950) implementation of the GI-GS
+ * rasterizer hot path.
+ *
+ * Every entry point replaces one static method of `CudaRasterizer::Rasterizer`
+ * (reference: submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:20-199,
+ * "R/" below) or one kornia call the reference makes inside the operator.  All pointers
+ * are DEVICE pointers owned by the caller unless a parameter says "host".  Nothing is
+ * allocated or freed by the library; scratch memory is requested from the caller through
+ * `gigs_alloc_fn` callbacks, the C form of the reference's
+ * `std::function<char*(size_t)>` resize functors (R/rasterize_points.cu:31-37).
+ *
+ * Conventions
+ *   - return value: >= 0 on success (gigs_forward returns num_rendered), < 0 on error;
+ *     `gigs_last_error()` then returns a message (thread-local, host memory).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  The reference
+ *     launches on the legacy default stream; the stream argument is the only addition.
+ *   - image planes are planar CHW fp32 (R/cuda_rasterizer/forward.cu:608-610);
+ *     `viewmatrix` / `projmatrix` are the 16 floats of the row-vector matrices the
+ *     reference passes (scene/cameras.py:75-85).
+ *   - optional inputs (shs / colors_precomp, scales+rotations / cov3D_precomp) are NULL
+ *     when absent, like the null data_ptr of the reference's empty tensors
+ *     (R/diff_gaussian_rasterization/__init__.py:435-445).
+ */
+#ifndef GIGS_HIP_H_
+#define GIGS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIGS_OK 0
+#define GIGS_ERR_INVALID (-1)  /* bad argument (shape, null pointer, non-RGB without colours) */
+#define GIGS_ERR_HIP (-2)      /* a HIP call or kernel failed; see gigs_last_error()           */
+#define GIGS_ERR_ALLOC (-3)    /* an allocation callback returned NULL                        */
+
+/* Replaces std::function<char*(size_t)> (R/rasterize_points.cu:31-37): must return a device
+ * pointer to at least `nbytes` bytes that stays valid until the matching backward has run. */
+typedef char* (*gigs_alloc_fn)(size_t nbytes, void* user);
+
+const char* gigs_last_error(void);
+/* "gfx950" -- the only architecture the code objects are built for. */
+const char* gigs_build_arch(void);
+
+/* Scratch sizes: required<GeometryState>(P), required<ImageState>(N), required<BinningState>(R)
+ * (R/cuda_rasterizer/rasterizer_impl.h:67-73).  Need a visible GPU (rocPRIM temp-storage
+ * queries). Return 0 and set the error string on failure. */
+size_t gigs_required_geom(int P);
+size_t gigs_required_image(int width, int height);
+size_t gigs_required_binning(int num_rendered);
+
+/* Rasterizer::forward (R/cuda_rasterizer/rasterizer.h:24-63, rasterizer_impl.cu:486-672).
+ * Runs preprocess -> scan -> (one 4-byte D2H read of num_rendered) -> duplicate -> radix sort
+ * -> tile ranges -> G-buffer blend.  `background` is 3 floats.  `radii` may be NULL.
+ * Output planes must be zero-initialised by the caller when P == 0 (nothing is launched). */
+int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer,
+                 void* binning_user, gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M,
+                 const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* opacities,
+                 const float* normal, const float* albedo, const float* roughness,
+                 const float* metallic, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                 int prefiltered, int argmax_depth, int inference, float* out_color,
+                 float* out_opacity, float* out_depth, float* out_normal, float* out_normal_view,
+                 float* out_pos, float* out_albedo, float* out_roughness, float* out_metallic,
+                 int* radii, int debug, void* stream);
+
+/* Rasterizer::backward (rasterizer.h:103-150, rasterizer_impl.cu:676-803).  All dL_d* outputs
+ * must be zero-initialised by the caller (R/rasterize_points.cu:299-312); dL_dconic [P,2,2]
+ * and dL_ddepth [P] are the two scratch gradients the reference allocates but does not return. */
+int gigs_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                  const float* means3D, const float* shs, const float* colors_precomp,
+                  const float* normal, const float* albedo, const float* roughness,
+                  const float* metallic, const float* scales, const float* rotations,
+                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                  const float* cam_pos, const int* radii, float scale_modifier, float tan_fovx,
+                  float tan_fovy, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                  const float* dL_dpix_depth, const float* dL_dpix, const float* dL_dpix_opacity,
+                  const float* dL_dpix_normal, const float* dL_dpix_albedo,
+                  const float* dL_dpix_roughness, const float* dL_dpix_metallic, float* dL_dmean2D,
+                  float* dL_dconic, float* dL_ddepth, float* dL_dopacity, float* dL_dnormal,
+                  float* dL_dalbedo, float* dL_droughness, float* dL_dmetallic, float* dL_dcolor,
+                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                  float* dL_drot, int debug, void* stream);
+
+/* Rasterizer::markVisible (rasterizer.h:24-29 / rasterizer_impl.cu:141-153); present = bool[P]. */
+int gigs_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, uint8_t* present, void* stream);
+
+/* Rasterizer::depthToNormal (rasterizer_impl.cu:201-220 -> forward.cu:914-1032).
+ * `normal` and `depth_pos` ([3,H,W]) must be zero-initialised by the caller. */
+int gigs_depth_to_normal(int width, int height, float focal_x, float focal_y,
+                         const float* viewmatrix, const float* depth, float* normal,
+                         float* depth_pos, void* stream);
+
+/* Rasterizer::SSAO (rasterizer_impl.cu:222-253 -> forward.cu:635-724). occlusion = [1,H,W]. */
+int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius, float bias,
+              float thick, float delta, int step, int start, const float* normal_view,
+              const float* pos, float* occlusion, void* stream);
+
+/* Rasterizer::SSR (rasterizer_impl.cu:255-298 -> forward.cu:726-909). color, abd = [3,H,W]. */
+int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, float bias,
+             float thick, float delta, int step, int start, const float* normal_view,
+             const float* pos, const float* rgb, const float* albedo, const float* roughness,
+             const float* metallic, const float* F0, float* color, float* abd, void* stream);
+
+/* kornia.filters.median_blur(x[None], (3,3))[0] as called at
+ * R/diff_gaussian_rasterization/__init__.py:478, 504 (zero padding, NaN-propagating). */
+int gigs_median3x3(int channels, int height, int width, const float* in, float* out, void* stream);
+/* Backward of the above: routes each output gradient to the tap that was selected. */
+int gigs_median3x3_backward(int channels, int height, int width, const float* in,
+                            const float* grad_out, float* grad_in, void* stream);
+
+/* kornia.filters.bilateral_blur(x[None], (3,3), sigma_color, (sigma_y, sigma_x))[0]
+ * (…/__init__.py:491; reflect border, L1 colour distance). */
+int gigs_bilateral3x3(int channels, int height, int width, float sigma_color, float sigma_x,
+                      float sigma_y, const float* in, float* out, void* stream);
+
+/* Test/diagnostic views into the opaque scratch buffers (byte offsets from the buffer
+ * start, or -1).  `which`: geometry 0 depths f32[P], 1 pos_view f32[3P], 2 means2D f32[2P],
+ * 3 cov3D f32[6P], 4 conic_opacity f32[4P], 5 rgb f32[3P], 6 clamped u8[3P],
+ * 7 tiles_touched u32[P], 8 point_offsets u32[P];  binning 0 keys_unsorted u64[R],
+ * 1 values_unsorted u32[R], 2 keys u64[R], 3 point_list u32[R];  image 0 final_T f32[N],
+ * 1 n_contrib u32[N], 2 ranges u32[2T]. */
+long long gigs_geom_offset(int P, int which);
+long long gigs_binning_offset(int num_rendered, int which);
+long long gigs_image_offset(int width, int height, int which);
+
+/* Wall-clock-free per-stage timing of the last forward/backward issued with debug == 2:
+ * fills up to `n` floats with milliseconds (hipEvents on `stream`); returns the count.
+ * Order: preprocess, scan, duplicate, sort, ranges, blend_fwd | blend_bwd, preprocess_bwd. */
+int gigs_last_stage_ms(float* ms, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIGS_HIP_H_ */
