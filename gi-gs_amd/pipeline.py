@@ -1,0 +1,143 @@
+"""Host-side glue around the operator: the reference's `render()` post-processing and one
+stage-2 ("PBR + indirect") training step, restated so that bench.py and the tests exercise
+the same operator sequence as the reference's train.py.
+
+    render()            gaussian_renderer/__init__.py:30-220
+    stage2_step()       train.py:266-422 (render -> pbr_shading -> Gaussian_SSR -> L1 ->
+                        backward), without dataset / optimizer / densification
+    srgb conversions    train.py:54-81
+
+Everything numerical runs in the HIP library (rasterizer, filters, SSAO/SSR, shade) or in
+plain torch elementwise ops on the GPU; nothing here touches the CPU oracle.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, Gaussian_SSR,
+                                         filters)
+
+
+def linear_to_srgb(linear: torch.Tensor) -> torch.Tensor:  # train.py:54-68
+    eps = torch.finfo(torch.float32).eps
+    srgb0 = 323 / 25 * linear
+    srgb1 = (211 * torch.clamp(linear, min=eps) ** (5 / 12) - 11) / 200
+    return torch.where(linear <= 0.0031308, srgb0, srgb1)
+
+
+def srgb_to_linear(srgb: torch.Tensor) -> torch.Tensor:  # train.py:70-81
+    linear0 = 25 / 323 * srgb
+    linear1 = ((srgb + 0.055) / 1.055) ** 2.4
+    return torch.where(srgb <= 0.04045, linear0, linear1)
+
+
+def canonical_rays(cam: Dict, device) -> torch.Tensor:
+    """scene/__init__.py:137-169 (pixel centres at +0.5, unlike the rasterizer)."""
+    H, W = cam["image_height"], cam["image_width"]
+    fx = W / (2.0 * cam["tanfovx"])
+    fy = H / (2.0 * cam["tanfovy"])
+    x, y = torch.meshgrid(torch.arange(W, device=device), torch.arange(H, device=device), indexing="xy")
+    x = x.flatten()
+    y = y.flatten()
+    return F.pad(torch.stack([(x - W / 2 + 0.5) / fx, (y - H / 2 + 0.5) / fy], dim=-1), (0, 1), value=1.0)
+
+
+def make_settings(cam: Dict, sh_degree: int, bg: torch.Tensor, gi: Dict, device, inference=False,
+                  debug=False) -> GaussianRasterizationSettings:
+    as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(a, device=device)  # noqa: E731
+    return GaussianRasterizationSettings(
+        image_height=int(cam["image_height"]), image_width=int(cam["image_width"]), tanfovx=cam["tanfovx"],
+        tanfovy=cam["tanfovy"], radius=gi["radius"], bias=gi["bias"], thick=gi["thick"], delta=gi["delta"],
+        step=gi["step"], start=gi["start"], bg=bg, scale_modifier=1.0, viewmatrix=as_t(cam["viewmatrix"]),
+        projmatrix=as_t(cam["projmatrix"]), sh_degree=sh_degree, campos=as_t(cam["campos"]), prefiltered=False,
+        debug=debug, inference=inference, argmax_depth=False)
+
+
+def render(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tensor, gi: Dict,
+           inference: bool = False, derive_normal: bool = True, debug=False) -> Dict[str, torch.Tensor]:
+    """gaussian_renderer.render with pad_normal=False."""
+    means3D = g["means3D"]
+    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
+    st = make_settings(cam, sh_degree, bg, gi, means3D.device, inference=inference, debug=debug)
+    (rendered_image, radii, opacity_map, depth_map, normal_map_from_depth, normal_map, occlusion_map, albedo_map,
+     roughness_map, metallic_map, out_normal_view, depth_pos) = GaussianRasterizer(st)(
+        means3D=means3D, means2D=screenspace_points, opacities=g["opacities"], normal=g["normal"], shs=g["shs"],
+        albedo=g["albedo"], roughness=g["roughness"], metallic=g["metallic"], scales=g["scales"],
+        rotations=g["rotations"], derive_normal=derive_normal)
+    normal_from_depth_mask = (normal_map_from_depth != 0).all(0)
+    normal_mask = (normal_map != 0).all(0, keepdim=True)
+    normal_map_from_depth = torch.where(torch.norm(normal_map_from_depth, dim=0, keepdim=True) > 0,
+                                        F.normalize(normal_map_from_depth, dim=0, p=2), normal_map_from_depth)
+    normal_map = torch.where(torch.norm(normal_map, dim=0, keepdim=True) > 0, F.normalize(normal_map, dim=0, p=2),
+                             normal_map)
+    normal_map = filters.median_blur(normal_map[None, ...], (3, 3))[0]
+    R = st.viewmatrix[:3, :3]
+    normals_view = -(normal_map.permute(1, 2, 0) @ R).permute(2, 0, 1)
+    out_normal_view = torch.where(torch.norm(out_normal_view, dim=0, keepdim=True) > 0,
+                                  F.normalize(out_normal_view, dim=0, p=2), out_normal_view)
+    out_normal_view = filters.median_blur(out_normal_view[None, ...], (3, 3))[0]
+    return {
+        "render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+        "radii": radii, "opacity_map": opacity_map, "depth_map": depth_map,
+        "normal_map_from_depth": normal_map_from_depth, "normal_from_depth_mask": normal_from_depth_mask,
+        "normal_map": normals_view, "normal_mask": normal_mask, "albedo_map": albedo_map,
+        "roughness_map": roughness_map, "metallic_map": metallic_map, "occlusion_map": occlusion_map,
+        "out_normal_view": out_normal_view, "depth_pos": depth_pos,
+    }
+
+
+def view_dirs_for(cam: Dict, rays: torch.Tensor, device) -> torch.Tensor:
+    """train.py:299-308."""
+    H, W = cam["image_height"], cam["image_width"]
+    vm = cam["viewmatrix"] if isinstance(cam["viewmatrix"], torch.Tensor) else torch.as_tensor(cam["viewmatrix"], device=device)
+    c2w = torch.inverse(vm.T)
+    return -((F.normalize(rays[:, None, :], p=2, dim=-1) * c2w[None, :3, :3]).sum(dim=-1).reshape(H, W, 3))
+
+
+def stage2_step(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, gi: Dict, light, brdf_lut: torch.Tensor,
+                gt_image: torch.Tensor, rays: torch.Tensor, metallic: bool = True, indirect: bool = True,
+                gamma: bool = False, tone: bool = False) -> Dict[str, torch.Tensor]:
+    """One stage-2 iteration of train.py (:266-422) up to and including loss.backward()."""
+    from pbr import pbr_shading  # HIP-backed drop-in of the reference's pbr package
+
+    dev = g["means3D"].device
+    background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
+    res = render(cam, g, sh_degree, background, gi, derive_normal=True)
+    H, W = cam["image_height"], cam["image_width"]
+    normal_map, albedo_map = res["normal_map"], res["albedo_map"]
+    roughness_map = res["roughness_map"] * (1.0 - 0.04) + 0.04  # train.py:293-295
+    metallic_map = res["metallic_map"]
+    view_dirs = view_dirs_for(cam, rays, dev)
+    occlusion = (res["occlusion_map"] if indirect else torch.ones_like(roughness_map)).permute(1, 2, 0)
+    normal_mask = res["normal_mask"]
+    light.build_mips()
+    pbr_result = pbr_shading(light=light, normals=normal_map.permute(1, 2, 0).detach(), view_dirs=view_dirs,
+                             mask=normal_mask.permute(1, 2, 0), albedo=albedo_map.permute(1, 2, 0),
+                             roughness=roughness_map.permute(1, 2, 0),
+                             metallic=metallic_map.permute(1, 2, 0) if metallic else None, tone=tone, gamma=gamma,
+                             occlusion=occlusion.detach(), brdf_lut=brdf_lut)
+    render_direct = pbr_result["render_rgb"].permute(2, 0, 1)
+    render_direct = torch.where(normal_mask, render_direct, background[:, None, None])
+    ssr = Gaussian_SSR(cam["tanfovx"], cam["tanfovy"], W, H, gi["radius"], gi["bias"], gi["thick"], gi["delta"],
+                       gi["step"], gi["start"])
+    if metallic:
+        F0 = (1.0 - metallic_map) * 0.04 + albedo_map * metallic_map
+    else:
+        F0 = torch.ones_like(albedo_map) * 0.04
+        metallic_map = torch.zeros_like(roughness_map)
+    linear_rgb = srgb_to_linear(render_direct)
+    (IRR, _) = ssr(res["out_normal_view"].detach(), res["depth_pos"].detach(), linear_rgb.detach(), albedo_map,
+                   roughness_map, metallic_map, F0)
+    IRR = linear_to_srgb(IRR)
+    IRR = filters.median_blur(IRR[None, ...], (3, 3))[0]
+    render_rgb = render_direct + IRR
+    loss = torch.abs(render_rgb - gt_image).mean()  # utils/loss_utils.l1_loss
+    lamb_loss = (1.0 - roughness_map[normal_mask]).mean() + metallic_map[normal_mask].mean()
+    loss = loss + lamb_loss * 0.001
+    loss.backward()
+    return dict(loss=loss.detach(), render_rgb=render_rgb.detach(), render_direct=render_direct.detach(),
+                IRR=IRR.detach(), viewspace_points=res["viewspace_points"], radii=res["radii"])

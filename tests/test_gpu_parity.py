@@ -1,0 +1,417 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in Python package) against
+the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star / SURVEY 8(c)):
+  * bit-exact: radii, tiles_touched, point_offsets, depth sort keys, point_list, ranges;
+  * n_contrib: bit-exact except pixels where the ulp difference between OCML expf and glibc
+    expf flips one of the three threshold tests (alpha < 1/255, T(1-alpha) < 1e-4, power > 0);
+    those are counted and bounded (<= 1e-4 of the pixels) and excluded from the max-error check;
+  * fp32 planes and gradients: mean per-pixel L1 <= 1e-4 (tolerance stated by north_star).
+"""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from helpers import GAUSS_KEYS, focal, oracle_forward, random_pix_grads, small_scene
+
+pytestmark = pytest.mark.gpu
+
+L1_TOL = 1e-4  # north_star: "within 1e-4 per-pixel L1"
+DEV = "cuda:0"
+
+
+def _dgr():
+    import diff_gaussian_rasterization as dgr
+    return dgr
+
+
+def tt(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    if grad:
+        t.requires_grad_(True)
+    return t
+
+
+def settings(dgr, cam, sh_degree, bg=(0, 0, 0), gi=scenes.GI_DEFAULTS, inference=False, argmax_depth=False, debug=False):
+    return dgr.GaussianRasterizationSettings(
+        image_height=cam["image_height"], image_width=cam["image_width"], tanfovx=cam["tanfovx"],
+        tanfovy=cam["tanfovy"], radius=gi["radius"], bias=gi["bias"], thick=gi["thick"], delta=gi["delta"],
+        step=gi["step"], start=gi["start"], bg=tt(np.asarray(bg, np.float32)), scale_modifier=1.0,
+        viewmatrix=tt(cam["viewmatrix"]), projmatrix=tt(cam["projmatrix"]), sh_degree=sh_degree,
+        campos=tt(cam["campos"]), prefiltered=False, debug=debug, inference=inference, argmax_depth=argmax_depth)
+
+
+def hip_raw_forward(dgr, sc, cam, bg=(0, 0, 0), colors_precomp=None, cov3D_precomp=None, **kw):
+    """_C.rasterize_gaussians + views into the scratch buffers."""
+    st = settings(dgr, cam, sc["sh_degree"], bg=bg, **kw)
+    e = torch.Tensor([])
+    res = dgr._C.rasterize_gaussians(
+        st.bg, tt(sc["means3D"]), e if colors_precomp is None else tt(colors_precomp), tt(sc["opacities"]),
+        tt(sc["normal"]), tt(sc["albedo"]), tt(sc["roughness"]), tt(sc["metallic"]),
+        e if cov3D_precomp is not None else tt(sc["scales"]), e if cov3D_precomp is not None else tt(sc["rotations"]),
+        e if cov3D_precomp is None else tt(cov3D_precomp), e if colors_precomp is not None else tt(sc["shs"]),
+        st.campos, st.viewmatrix, st.projmatrix, 1.0, st.tanfovx, st.tanfovy, st.image_height, st.image_width,
+        st.sh_degree, False, st.argmax_depth, st.inference, st.debug)
+    torch.cuda.synchronize()
+    return res
+
+
+def view(buf, off, dtype, count):
+    itemsize = np.dtype(dtype).itemsize
+    raw = buf[off:off + count * itemsize].cpu().numpy()
+    return raw.view(dtype)
+
+
+def scratch_views(dgr, res, P, W, H):
+    import gigs_lib
+    lib = gigs_lib.lib()
+    R, geom, binning, img = res[0], res[3], res[4], res[5]
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    g = lambda which, dt, n: view(geom, lib.gigs_geom_offset(P, which), dt, n)  # noqa: E731
+    out = dict(depths=g(0, np.float32, P), pos_view=g(1, np.float32, 3 * P), means2D=g(2, np.float32, 2 * P),
+               cov3D=g(3, np.float32, 6 * P), conic_opacity=g(4, np.float32, 4 * P), rgb=g(5, np.float32, 3 * P),
+               clamped=g(6, np.uint8, 3 * P), tiles_touched=g(7, np.uint32, P), point_offsets=g(8, np.uint32, P))
+    if R > 0:
+        b = lambda which, dt, n: view(binning, lib.gigs_binning_offset(R, which), dt, n)  # noqa: E731
+        out.update(keys_unsorted=b(0, np.uint64, R), vals_unsorted=b(1, np.uint32, R), keys=b(2, np.uint64, R),
+                   point_list=b(3, np.uint32, R))
+    i = lambda which, dt, n: view(img, lib.gigs_image_offset(W, H, which), dt, n)  # noqa: E731
+    out.update(final_T=i(0, np.float32, N), n_contrib=i(1, np.uint32, N), ranges=i(2, np.uint32, 2 * T))
+    return out
+
+
+def compare_planes(hip, ref, names, flip_mask=None, tag=""):
+    for k in names:
+        a, b = hip[k], ref[k]
+        nan_a, nan_b = np.isnan(a), np.isnan(b)
+        assert np.array_equal(nan_a, nan_b), f"{tag}{k}: NaN pattern differs"
+        d = np.abs(np.nan_to_num(a) - np.nan_to_num(b))
+        assert d.mean() <= L1_TOL, f"{tag}{k}: mean L1 {d.mean():.3e}"
+        if flip_mask is not None:
+            d = d[:, ~flip_mask]
+        scale = max(1.0, np.nanmax(np.abs(b)))
+        assert d.max() <= 2e-4 * scale, f"{tag}{k}: max abs {d.max():.3e} (scale {scale:.2f})"
+
+
+PLANES = ["color", "opacity", "depth", "normal", "normal_view", "pos", "albedo", "roughness", "metallic"]
+
+
+def hip_planes(res):
+    keys = ["color", "radii", "geom", "bin", "img", "opacity", "depth", "normal", "normal_view", "pos", "albedo",
+            "roughness", "metallic"]
+    return {k: v.cpu().numpy() for k, v in zip(keys, res[1:]) if k not in ("geom", "bin", "img")}
+
+
+def check_forward(orc, sc, cam, bg=(0.1, 0.3, 0.2), tag="", **kw):
+    dgr = _dgr()
+    okw = {k: v for k, v in kw.items() if k in ("inference", "argmax_depth")}
+    extra = {}
+    if "colors_precomp" in kw:
+        extra.update(shs=None, colors_precomp=kw["colors_precomp"])
+    if "cov3D_precomp" in kw:
+        extra.update(scales=None, rotations=None, cov3D_precomp=kw["cov3D_precomp"])
+    r, ref = oracle_forward(orc, sc, cam, bg=bg, **okw, **extra)
+    res = hip_raw_forward(dgr, sc, cam, bg=bg, **kw)
+    P, W, H = sc["means3D"].shape[0], cam["image_width"], cam["image_height"]
+    assert res[0] == ref["num_rendered"], f"{tag}num_rendered {res[0]} vs {ref['num_rendered']}"
+    hp = hip_planes(res)
+    np.testing.assert_array_equal(hp["radii"], ref["radii"])
+    sv = scratch_views(dgr, res, P, W, H)
+    vis = ref["radii"] > 0
+    # integer / index state: bit-exact
+    for k in ("tiles_touched", "point_offsets", "ranges"):
+        np.testing.assert_array_equal(sv[k], r.state(k), err_msg=tag + k)
+    if res[0] > 0:
+        for k in ("keys_unsorted", "vals_unsorted", "keys", "point_list"):
+            np.testing.assert_array_equal(sv[k], r.state(k), err_msg=tag + k)
+    # per-Gaussian fp32 state: bit-exact too (same IEEE operation sequence, no FMA contraction)
+    for k, w in (("depths", 1), ("means2D", 2), ("conic_opacity", 4), ("pos_view", 3)):
+        np.testing.assert_array_equal(sv[k].reshape(P, w)[vis], r.state(k).reshape(P, w)[vis], err_msg=tag + k)
+    if "cov3D_precomp" not in kw:
+        np.testing.assert_array_equal(sv["cov3D"].reshape(P, 6)[vis], r.state("cov3D").reshape(P, 6)[vis])
+    if "colors_precomp" not in kw:
+        np.testing.assert_array_equal(sv["rgb"].reshape(P, 3)[vis], r.state("rgb").reshape(P, 3)[vis])
+        np.testing.assert_array_equal(sv["clamped"].reshape(P, 3)[vis], r.state("clamped").reshape(P, 3)[vis])
+    flips = (sv["n_contrib"] != r.state("n_contrib")).reshape(H, W)
+    assert flips.mean() <= 1e-4, f"{tag}n_contrib differs on {flips.sum()} pixels"
+    compare_planes(hp, ref, PLANES, flip_mask=flips, tag=tag)
+    np.testing.assert_allclose(sv["final_T"].reshape(H, W)[~flips], r.state("final_T").reshape(H, W)[~flips], atol=1e-6)
+    return r, ref, res, int(flips.sum())
+
+
+# ------------------------------------------------------------------------------------------
+def test_forward_c1_random_cloud(orc):
+    """BASELINE config C1: 10k random Gaussians, 400x400, SH degree 0."""
+    sc = scenes.random_scene(P=10_000, sh_degree=0, seed=0)
+    cam = scenes.orbit_camera(0, 8, 400, 400)
+    _, ref, res, nflip = check_forward(orc, sc, cam, bg=(0, 0, 0), tag="C1 ")
+    assert res[0] > 50_000
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3])
+def test_forward_sh_degrees_and_ragged_image(orc, deg):
+    # image size not a multiple of the 16x16 tile
+    sc = scenes.random_scene(P=4000, sh_degree=deg, seed=deg, scale_mu=0.05)
+    cam = scenes.orbit_camera(deg, 5, 203, 117)
+    check_forward(orc, sc, cam, tag=f"deg{deg} ")
+
+
+def test_forward_active_degree_below_allocated(orc):
+    sc = scenes.random_scene(P=3000, sh_degree=3, seed=4, scale_mu=0.05)
+    sc["sh_degree"] = 1  # M = 16 allocated, D = 1 active (gaussian_renderer/__init__.py:81)
+    cam = scenes.orbit_camera(2, 5, 160, 96)
+    check_forward(orc, sc, cam, tag="D<M ")
+
+
+def test_forward_surface_scene_flags(orc):
+    sc = scenes.surface_scene(P=20_000, sh_degree=2, seed=2, scale_mu=0.02)
+    cam = scenes.orbit_camera(1, 6, 256, 192, radius=3.5)
+    check_forward(orc, sc, cam, tag="surf ")
+    check_forward(orc, sc, cam, inference=True, tag="inference ")
+    check_forward(orc, sc, cam, argmax_depth=True, tag="argmax ")
+
+
+def test_forward_precomputed_colour_and_covariance(orc):
+    sc, cam = small_scene(P=2500, sh_degree=0, W=128, H=96, scale_mu=0.05)
+    rng = np.random.default_rng(0)
+    cols = rng.uniform(0, 1, size=(2500, 3)).astype(np.float32)
+    r, _ = oracle_forward(orc, sc, cam)
+    cov = r.state("cov3D").reshape(2500, 6).copy()
+    check_forward(orc, sc, cam, colors_precomp=cols, tag="colors_precomp ")
+    check_forward(orc, sc, cam, cov3D_precomp=cov, tag="cov3D_precomp ")
+
+
+def test_forward_edge_cases(orc):
+    dgr = _dgr()
+    cam = scenes.orbit_camera(0, 4, 48, 32)
+    # P == 0: outputs stay zero, rendered = 0 (rasterize_points.cu:190-191)
+    sc = scenes.random_scene(P=0, sh_degree=0)
+    res = hip_raw_forward(dgr, sc, cam)
+    assert res[0] == 0 and float(res[1].abs().sum()) == 0
+    # nothing visible: every Gaussian behind the camera -> background only, R = 0
+    sc = scenes.random_scene(P=100, sh_degree=0)
+    sc["means3D"] = (np.asarray(cam["campos"])[None] * 1.5 + 0.01 * sc["means3D"]).astype(np.float32)
+    _, ref, res, _ = check_forward(orc, sc, cam, bg=(1.0, 0.5, 0.25), tag="behind ")
+    assert res[0] == 0
+    # one huge Gaussian covering every tile + a degenerate (zero-scale) one
+    sc = scenes.random_scene(P=3, sh_degree=0, seed=1)
+    sc["means3D"][:] = 0
+    sc["scales"][0] = 5.0
+    sc["scales"][1] = 0.0
+    check_forward(orc, sc, cam, tag="huge ")
+    # bad shape raises like AT_ERROR (rasterize_points.cu:159-161)
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        sc2 = dict(sc)
+        sc2["means3D"] = sc["means3D"][:, :2].copy()
+        hip_raw_forward(dgr, sc2, cam)
+
+
+def test_mark_visible(orc):
+    dgr = _dgr()
+    sc, cam = small_scene(P=5000, sh_degree=0)
+    sc["means3D"] *= 4  # some behind the camera
+    st = settings(dgr, cam, 0)
+    got = dgr.GaussianRasterizer(st).markVisible(tt(sc["means3D"])).cpu().numpy()
+    ref = orc.mark_visible(sc["means3D"], cam["viewmatrix"])
+    np.testing.assert_array_equal(got, ref)
+    assert 0 < got.sum() < 5000
+
+
+# ------------------------------------------------------------------------------------------
+def _backward_pair(orc, sc, cam, bg, seed, zero=()):
+    dgr = _dgr()
+    H, W = cam["image_height"], cam["image_width"]
+    r, ref = oracle_forward(orc, sc, cam, bg=bg)
+    pg = random_pix_grads(np.random.default_rng(seed), H, W)
+    for k in zero:
+        pg[k][:] = 0
+    want = r.backward(grad_color=pg["color"], grad_opacity=pg["opacity"], grad_depth=pg["depth"],
+                      grad_normal=pg["normal"], grad_albedo=pg["albedo"], grad_roughness=pg["roughness"],
+                      grad_metallic=pg["metallic"])
+    st = settings(dgr, cam, sc["sh_degree"], bg=bg)
+    t = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+    m2d = torch.zeros_like(t["means3D"], requires_grad=True)
+    outs = dgr._RasterizeGaussians.apply(t["means3D"], m2d, t["opacities"], t["normal"], t["albedo"], t["roughness"],
+                                         t["metallic"], t["shs"], torch.Tensor([]), t["scales"], t["rotations"],
+                                         torch.Tensor([]), st)
+    color, radii, opacity, depth, normal, albedo, rough, metal, nview, pos = outs
+    loss = ((color * tt(pg["color"])).sum() + (opacity * tt(pg["opacity"])).sum() + (depth * tt(pg["depth"])).sum()
+            + (normal * tt(pg["normal"])).sum() + (albedo * tt(pg["albedo"])).sum()
+            + (rough * tt(pg["roughness"])).sum() + (metal * tt(pg["metallic"])).sum()
+            + 0.0 * nview.nan_to_num().sum() + 0.0 * pos.sum())
+    loss.backward()
+    torch.cuda.synchronize()
+    got = dict(means3D=t["means3D"].grad, means2D=m2d.grad, opacity=t["opacities"].grad, normal=t["normal"].grad,
+               albedo=t["albedo"].grad, roughness=t["roughness"].grad, metallic=t["metallic"].grad, sh=t["shs"].grad,
+               scales=t["scales"].grad, rotations=t["rotations"].grad)
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    return got, want, ref
+
+
+def _check_grads(got, want, tag=""):
+    for k in got:
+        a, b = got[k].astype(np.float64), np.asarray(want[k], np.float64).reshape(got[k].shape)
+        assert np.isfinite(a).all(), f"{tag}{k}: non-finite gradient"
+        peak = max(np.abs(b).max(), 1e-20)
+        # per-Gaussian L1 relative to the mean magnitude, and worst entry relative to the peak
+        rel_l1 = np.abs(a - b).mean() / max(np.abs(b).mean(), 1e-20)
+        rel_max = np.abs(a - b).max() / peak
+        assert rel_l1 <= 2e-4, f"{tag}{k}: mean-relative L1 {rel_l1:.3e}"
+        assert rel_max <= 2e-3, f"{tag}{k}: peak-relative max {rel_max:.3e}"
+
+
+@pytest.mark.parametrize("deg,W,H,P", [(0, 64, 48, 400), (2, 203, 117, 3000), (3, 128, 128, 2000)])
+def test_backward_matches_oracle(orc, deg, W, H, P):
+    sc = scenes.random_scene(P=P, sh_degree=deg, seed=10 + deg, scale_mu=0.06)
+    cam = scenes.orbit_camera(deg, 5, W, H)
+    got, want, _ = _backward_pair(orc, sc, cam, (0.2, 0.1, 0.4), seed=deg)
+    _check_grads(got, want, tag=f"deg{deg} ")
+    assert np.abs(want["means3D"]).max() > 0 and np.abs(want["sh"]).max() > 0
+
+
+def test_backward_stage2_pattern_and_linearity(orc):
+    """Stage-2 training feeds only albedo/roughness/metallic image gradients."""
+    sc = scenes.surface_scene(P=8000, sh_degree=2, seed=5, scale_mu=0.03)
+    cam = scenes.orbit_camera(0, 4, 160, 128, radius=3.5)
+    zero = ("color", "opacity", "depth", "normal")
+    got, want, _ = _backward_pair(orc, sc, cam, (0, 0, 0), seed=1, zero=zero)
+    for k in ("albedo", "roughness", "metallic"):
+        a, b = got[k], np.asarray(want[k]).reshape(got[k].shape)
+        assert np.abs(a - b).mean() <= 2e-4 * max(np.abs(b).mean(), 1e-20)
+    # detached blend weights: no gradient reaches geometry or colour from these planes
+    for k in ("means3D", "scales", "rotations", "opacity", "sh", "means2D"):
+        assert np.abs(got[k]).max() == 0.0, k
+
+
+def test_backward_scratch_gradients_c_abi(orc):
+    """dL_dconic / dL_ddepth are allocated by the reference binding but not returned
+    (rasterize_points.cu:302-303); check them through the raw C-ABI call."""
+    dgr = _dgr()
+    sc, cam = small_scene(P=800, sh_degree=1, W=96, H=64, scale_mu=0.06)
+    H, W = 64, 96
+    r, ref = oracle_forward(orc, sc, cam)
+    pg = random_pix_grads(np.random.default_rng(3), H, W)
+    r.backward(grad_color=pg["color"], grad_opacity=pg["opacity"], grad_depth=pg["depth"], grad_normal=pg["normal"],
+               grad_albedo=pg["albedo"], grad_roughness=pg["roughness"], grad_metallic=pg["metallic"])
+    res = hip_raw_forward(dgr, sc, cam)
+    import gigs_lib
+    lib = gigs_lib.lib()
+    P = 800
+    z = lambda *s: torch.zeros(s, device=DEV)  # noqa: E731
+    outs = dict(m2d=z(P, 3), conic=z(P, 2, 2), ddepth=z(P, 1), dop=z(P, 1), dn=z(P, 3), da=z(P, 3), dr=z(P, 1), dm=z(P, 1),
+                dc=z(P, 3), dm3=z(P, 3), dcov=z(P, 6), dsh=z(P, 4, 3), dsc=z(P, 3), drot=z(P, 4))
+    g = {k: tt(v) for k, v in pg.items()}
+    ins = {k: tt(sc[k]) for k in GAUSS_KEYS}
+    vm, pm, cp, bg = tt(cam["viewmatrix"]), tt(cam["projmatrix"]), tt(cam["campos"]), tt(np.zeros(3, np.float32))
+    rc = lib.gigs_backward(P, 1, 4, res[0], bg.data_ptr(), W, H, ins["means3D"].data_ptr(), ins["shs"].data_ptr(), None,
+                           ins["normal"].data_ptr(), ins["albedo"].data_ptr(), ins["roughness"].data_ptr(),
+                           ins["metallic"].data_ptr(), ins["scales"].data_ptr(), ins["rotations"].data_ptr(), None,
+                           vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), res[2].data_ptr(), 1.0, cam["tanfovx"], cam["tanfovy"],
+                           res[3].data_ptr(), res[4].data_ptr(), res[5].data_ptr(), g["depth"].data_ptr(), g["color"].data_ptr(),
+                           g["opacity"].data_ptr(), g["normal"].data_ptr(), g["albedo"].data_ptr(), g["roughness"].data_ptr(),
+                           g["metallic"].data_ptr(), outs["m2d"].data_ptr(), outs["conic"].data_ptr(), outs["ddepth"].data_ptr(),
+                           outs["dop"].data_ptr(), outs["dn"].data_ptr(), outs["da"].data_ptr(), outs["dr"].data_ptr(),
+                           outs["dm"].data_ptr(), outs["dc"].data_ptr(), outs["dm3"].data_ptr(), outs["dcov"].data_ptr(),
+                           outs["dsh"].data_ptr(), outs["dsc"].data_ptr(), outs["drot"].data_ptr(), 1, None)
+    assert rc == 0, lib.gigs_last_error()
+    torch.cuda.synchronize()
+    for name, got in (("dL_dconic", outs["conic"].cpu().numpy().reshape(-1)), ("dL_ddepth", outs["ddepth"].cpu().numpy().reshape(-1))):
+        want = r.state(name)
+        assert np.abs(got - want).mean() <= 2e-4 * max(np.abs(want).mean(), 1e-20), name
+    # abs-gradient accumulator in means2D.z (backward.cu:618-619)
+    assert np.all(outs["m2d"][:, 2].cpu().numpy() >= 0)
+
+
+# ------------------------------------------------------------------------------------------
+def test_gi_passes_match_oracle(orc):
+    dgr = _dgr()
+    sc = scenes.surface_scene(P=30_000, sh_degree=1, seed=3, scale_mu=0.02)
+    cam = scenes.orbit_camera(0, 4, 208, 160, radius=3.5)
+    W, H = 208, 160
+    fx, fy = focal(cam)
+    r, ref = oracle_forward(orc, sc, cam)
+    depth_f = orc.median3x3(ref["depth"])
+    nd, pos = orc.depth_to_normal(W, H, fx, fy, cam["viewmatrix"], depth_f)
+    # filters and depth->normal on identical inputs
+    got_df = dgr.filters.median_blur(tt(ref["depth"])[None], (3, 3))[0].cpu().numpy()
+    np.testing.assert_array_equal(got_df, depth_f)
+    gn, gp = dgr._C.depth_to_normal(W, H, fx, fy, tt(cam["viewmatrix"]), tt(depth_f))
+    np.testing.assert_array_equal(gp.cpu().numpy(), pos)
+    np.testing.assert_allclose(gn.cpu().numpy(), nd, atol=1e-6)
+    assert (nd != 0).any()
+    got_bl = dgr.filters.bilateral_blur(tt(nd)[None], (3, 3), 1, (3, 3))[0].cpu().numpy()
+    np.testing.assert_allclose(got_bl, orc.bilateral3x3(nd), atol=2e-6)
+    posf = orc.median3x3(pos)
+    np.testing.assert_array_equal(dgr.filters.median_blur(tt(pos)[None], (3, 3))[0].cpu().numpy(), posf)
+
+    F0 = ((1.0 - ref["metallic"]) * 0.04 + ref["albedo"] * ref["metallic"]).astype(np.float32)
+    for gi in (scenes.GI_DEFAULTS, dict(scenes.GI_DEFAULTS, start=64), dict(scenes.GI_DEFAULTS, step=12, start=5, delta=0.125)):
+        a = (gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
+        occ = orc.ssao(W, H, fx, fy, *a, ref["normal_view"], posf)
+        got = dgr._C.SSAO(W, H, fx, fy, *a, tt(ref["normal_view"]), tt(posf)).cpu().numpy()
+        d = np.abs(got - occ)
+        assert d.mean() <= L1_TOL and (d > 1e-5).mean() <= 1e-3, (gi, d.mean(), d.max())
+        col, abd = orc.ssr(W, H, fx, fy, *a, ref["normal_view"], posf, ref["color"], ref["albedo"], ref["roughness"], ref["metallic"], F0)
+        gc, ga = dgr._C.SSR(W, H, fx, fy, *a, tt(ref["normal_view"]), tt(posf), tt(ref["color"]), tt(ref["albedo"]),
+                            tt(ref["roughness"]), tt(ref["metallic"]), tt(F0))
+        for x, y in ((gc.cpu().numpy(), col), (ga.cpu().numpy(), abd)):
+            assert np.array_equal(np.isnan(x), np.isnan(y))
+            d = np.abs(np.nan_to_num(x) - np.nan_to_num(y))
+            assert d.mean() <= L1_TOL and (d > 1e-5).mean() <= 1e-3, (gi, d.mean(), d.max())
+    assert occ.shape == (1, H, W)
+
+
+def test_full_operator_matches_oracle_pipeline(orc):
+    """GaussianRasterizer.forward 12-tuple == oracle pipeline (…/__init__.py:448-537) and
+    Gaussian_SSR backward = grad * abd."""
+    dgr = _dgr()
+    sc = scenes.surface_scene(P=15_000, sh_degree=2, seed=6, scale_mu=0.025)
+    cam = scenes.orbit_camera(2, 6, 176, 144, radius=3.5)
+    W, H = 176, 144
+    fx, fy = focal(cam)
+    gi = scenes.GI_DEFAULTS
+    st = settings(dgr, cam, 2)
+    t = {k: tt(sc[k]) for k in GAUSS_KEYS}
+    out = dgr.GaussianRasterizer(st)(t["means3D"], torch.zeros_like(t["means3D"]), t["opacities"], t["normal"], t["albedo"],
+                                     t["roughness"], t["metallic"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"],
+                                     derive_normal=True)
+    assert len(out) == 12
+    (color, radii, opacity, depth, n_from_d, out_normal, occlusion, albedo, rough, metal, nview, pos_f) = [o.cpu().numpy() for o in out]
+    r, ref = oracle_forward(orc, sc, cam)
+    depth_f = orc.median3x3(ref["depth"])
+    nd, pos = orc.depth_to_normal(W, H, fx, fy, cam["viewmatrix"], depth_f)
+    nd = orc.bilateral3x3(nd)
+    posf = orc.median3x3(pos)
+    occ = orc.ssao(W, H, fx, fy, gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"], ref["normal_view"], posf)
+    np.testing.assert_array_equal(radii, ref["radii"])
+    for a, b, name in ((color, ref["color"], "color"), (depth, ref["depth"], "depth"), (n_from_d, nd, "normal_from_depth"),
+                       (pos_f, posf, "depth_pos_filter"), (occlusion, occ, "occlusion"), (albedo, ref["albedo"], "albedo")):
+        d = np.abs(np.nan_to_num(a) - np.nan_to_num(b))
+        assert d.mean() <= L1_TOL, (name, d.mean())
+    # Gaussian_SSR: width before height in the constructor (…/__init__.py:697)
+    ssr = dgr.Gaussian_SSR(cam["tanfovx"], cam["tanfovy"], W, H, gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
+    alb = out[7].detach().clone().requires_grad_(True)
+    rgh = out[8].detach().clone().requires_grad_(True)
+    F0 = torch.full_like(alb, 0.04)
+    col, abd = ssr(out[10].detach(), out[11].detach(), out[0].detach(), alb, rgh, torch.zeros_like(rgh), F0)
+    g = torch.randn_like(col)
+    col.nan_to_num().mul(g).sum().backward()
+    want = (g * abd).nan_to_num()
+    torch.testing.assert_close(alb.grad.nan_to_num(), want)
+    assert float(rgh.grad.abs().sum()) == 0
+
+
+def test_median_backward_routes_gradient(orc):
+    dgr = _dgr()
+    x = torch.randn(3, 40, 56, device=DEV, requires_grad=True)
+    y = dgr.filters.median_blur(x[None], (3, 3))[0]
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    # reference semantics: unfold 3x3 (zero pad) + torch.median over the 9 taps
+    xr = x.detach().clone().requires_grad_(True)
+    patches = torch.nn.functional.unfold(xr[:, None], 3, padding=1).reshape(3, 9, 40, 56)
+    yr = patches.median(dim=1).values
+    (yr * g).sum().backward()
+    torch.testing.assert_close(y.detach(), yr.detach())
+    torch.testing.assert_close(x.grad, xr.grad)  # continuous random data: no ties
