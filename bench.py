@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py -- train-step renders/sec (fwd+bwd, G-buffer + indirect) at 800x800.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" is one stage-2 training iteration of the reference (train.py:266-422) on one
+camera view per GPU: rasterizer forward (preprocess, scan, duplicate, radix sort, ranges,
+G-buffer blend), the in-operator filters + depth->normal + SSAO, the deferred shade,
+SSR (indirect diffuse), the L1 loss, and the full backward (shade/SSR closed form, blend
+backward, preprocess backward).  No optimizer, no data loading.
+
+Workload = BASELINE.json configs[1] stand-in (the real TensoIR data is not available
+offline): ~300k synthetic Gaussians on surfaces, 800x800, SH degree 2, GI step=16
+delta=0.0625, start=8 (the CLI default of the reference; --start 64 gives the README
+setting where the march loop is empty).  With N GPUs every rank renders a different view of
+the replicated scene and the parameter gradients are summed with one RCCL all-reduce per
+step (weak scaling: one view per GPU per step).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+importlib.import_module("gi-gs_amd")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import gigs_lib  # noqa: E402
+import pipeline  # noqa: E402
+import scenes  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+PARAM_KEYS = ["means3D", "opacities", "normal", "albedo", "roughness", "metallic", "shs", "scales", "rotations"]
+
+
+def algorithmic_bytes(P, V, R, N, M, T):
+    """Compulsory HBM bytes per launch of each stage."""
+    return {
+        "preprocess_fwd": 52 * P + V * (12 * M + 79),
+        "scan": 8 * P,
+        "duplicate": 20 * V + 12 * R,
+        "sort": 24 * R,
+        "tile_ranges": 8 * R + 8 * T,
+        "blend_fwd": 88 * R + 84 * N,
+        "blend_bwd": 40 * R + 60 * N,
+        "preprocess_bwd": V * (259 + 24 * M),
+        "depth_to_normal": 28 * N,
+        "ssao": 28 * N,
+        "ssr": 88 * N,
+        "median3x3": 8 * N,        # per plane-launch of N pixels: read + write (per channel)
+        "bilateral3x3": 24 * N,
+        "median3x3_bwd": 12 * N,
+        "shade_fwd": 80 * N,
+        "shade_bwd": 96 * N,
+    }
+
+
+def make_light(device, shade: str):
+    if shade == "hip":
+        import pbr
+        light = pbr.CubemapLight(base_res=256).to(device)
+        return light, pbr.get_brdf_lut().to(device)
+    return None, None
+
+
+def stub_step(cam, g, sh_degree, gi, gt_image):
+    """Step without the deferred shade (used only until the HIP shade lands; flagged in the
+    JSON line as config.shade = "none")."""
+    dev = g["means3D"].device
+    bg = torch.zeros(3, device=dev)
+    res = pipeline.render(cam, g, sh_degree, bg, gi, derive_normal=True)
+    H, W = cam["image_height"], cam["image_width"]
+    albedo_map, metallic_map = res["albedo_map"], res["metallic_map"]
+    roughness_map = res["roughness_map"] * (1.0 - 0.04) + 0.04
+    occ = res["occlusion_map"].detach()
+    render_direct = torch.where(res["normal_mask"], (albedo_map * occ).clamp(0, 1), bg[:, None, None])
+    ssr = pipeline.Gaussian_SSR(cam["tanfovx"], cam["tanfovy"], W, H, gi["radius"], gi["bias"], gi["thick"],
+                                gi["delta"], gi["step"], gi["start"])
+    F0 = (1.0 - metallic_map) * 0.04 + albedo_map * metallic_map
+    (IRR, _) = ssr(res["out_normal_view"].detach(), res["depth_pos"].detach(),
+                   pipeline.srgb_to_linear(render_direct).detach(), albedo_map, roughness_map, metallic_map, F0)
+    IRR = pipeline.filters.median_blur(pipeline.linear_to_srgb(IRR)[None], (3, 3))[0]
+    loss = torch.abs(render_direct + IRR - gt_image).mean()
+    loss = loss + 0.001 * ((1.0 - roughness_map[res["normal_mask"]]).mean() + metallic_map[res["normal_mask"]].mean())
+    loss.backward()
+    return dict(loss=loss.detach(), radii=res["radii"])
+
+
+def cpu_baseline(sc, cam, gi, sh_degree):
+    """The oracle (a scalar fp32 port, OpenMP over tiles/pixels) timed on the host cores for ONE
+    step of the same workload: rasterizer fwd + filters + depth->normal + SSAO + SSR + bwd."""
+    from oracle import oracle as orc
+    orc.build()
+    cores = orc.max_threads()
+    orc.set_threads(cores)
+    H, W = cam["image_height"], cam["image_width"]
+    fx, fy = W / (2 * cam["tanfovx"]), H / (2 * cam["tanfovy"])
+    t0 = time.perf_counter()
+    r = orc.Rasterizer()
+    out = r.forward(bg=np.zeros(3, np.float32), **{k: sc[k] for k in PARAM_KEYS}, sh_degree=sh_degree,
+                    viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
+                    tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], image_height=H, image_width=W)
+    t_fwd = time.perf_counter()
+    depth_f = orc.median3x3(out["depth"])
+    nd, pos = orc.depth_to_normal(W, H, fx, fy, cam["viewmatrix"], depth_f)
+    nd = orc.bilateral3x3(nd)
+    posf = orc.median3x3(pos)
+    a = (gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
+    occ = orc.ssao(W, H, fx, fy, *a, out["normal_view"], posf)
+    F0 = ((1.0 - out["metallic"]) * 0.04 + out["albedo"] * out["metallic"]).astype(np.float32)
+    col, abd = orc.ssr(W, H, fx, fy, *a, out["normal_view"], posf, out["color"], out["albedo"], out["roughness"],
+                       out["metallic"], F0)
+    t_gi = time.perf_counter()
+    g1 = np.full((1, H, W), 1.0 / (H * W), np.float32)
+    g3 = np.full((3, H, W), 1.0 / (3 * H * W), np.float32)
+    r.backward(grad_color=0 * g3, grad_opacity=0 * g1, grad_depth=0 * g1, grad_normal=0 * g3, grad_albedo=g3,
+               grad_roughness=g1, grad_metallic=g1)
+    t1 = time.perf_counter()
+    return dict(value=1.0 / (t1 - t0), unit="renders/s", cores=cores, kind="port",
+                sample="1 step of the same workload (C2, 1 view): oracle rasterizer fwd %.2fs + filters/SSAO/SSR %.2fs + bwd %.2fs; "
+                       "backward blend is single-threaded (deterministic double sums), the rest OpenMP"
+                       % (t_fwd - t0, t_gi - t_fwd, t1 - t_gi))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=300_000)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--start", type=int, default=8, help="GI march start (8 = reference CLI default, 64 = README)")
+    ap.add_argument("--shade", choices=["auto", "hip", "none"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, (world, args.gpus)
+
+    shade = args.shade
+    if shade == "auto":
+        shade = "hip" if os.path.exists(os.path.join(ROOT, "gi-gs_amd", "pbr", "__init__.py")) else "none"
+
+    gi = dict(scenes.GI_DEFAULTS, start=args.start)
+    sc = scenes.surface_scene(P=args.gaussians, sh_degree=args.sh_degree, seed=0)
+    P, M = sc["means3D"].shape[0], sc["shs"].shape[1]
+    g = {k: torch.from_numpy(sc[k]).to(dev).requires_grad_(True) for k in PARAM_KEYS}
+    n_views = 64
+    cams = [scenes.orbit_camera(i, n_views, args.res, args.res, radius=3.5) for i in range(n_views)]
+    cams_t = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    H = W = args.res
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, W, device=dev), indexing="ij")
+    gt_image = torch.stack([0.5 + 0.3 * torch.sin(6 * xx), 0.5 + 0.3 * torch.cos(5 * yy), 0.4 + 0.2 * xx * yy])
+    light, brdf_lut = make_light(dev, shade)
+    rays = pipeline.canonical_rays(cams[0], dev)
+    if light is not None:
+        params_light = [p for p in light.parameters()]
+    else:
+        params_light = []
+    flat_params = [g[k] for k in PARAM_KEYS] + params_light
+
+    def one_step(i):
+        cam = cams_t[(i * world + rank) % n_views]
+        for p in flat_params:
+            p.grad = None
+        if shade == "hip":
+            out = pipeline.stage2_step(cam, g, args.sh_degree, gi, light, brdf_lut, gt_image, rays)
+        else:
+            out = stub_step(cam, g, args.sh_degree, gi, gt_image)
+        if world > 1:
+            # one flat bucket: xGMI is point-to-point, a single large all-reduce keeps every link busy
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in flat_params]
+            flat = torch.cat([x.reshape(-1) for x in grads])
+            dist.all_reduce(flat)
+            off = 0
+            for p, x in zip(flat_params, grads):
+                n = x.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    with gigs_lib.profile() as prof:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        barrier()
+        t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        # V (visible), R (instances) averaged over the views of the timed region (outside it)
+        import diff_gaussian_rasterization as dgr
+        Vs, Rs = [], []
+        e = torch.Tensor([])
+        with torch.no_grad():
+            for i in range(min(args.steps, 8)):
+                cam = cams_t[((args.warmup + i) * world) % n_views]
+                res = dgr._C.rasterize_gaussians(
+                    torch.zeros(3, device=dev), g["means3D"], e, g["opacities"], g["normal"], g["albedo"], g["roughness"],
+                    g["metallic"], g["scales"], g["rotations"], e, g["shs"], cam["campos"], cam["viewmatrix"],
+                    cam["projmatrix"], 1.0, cam["tanfovx"], cam["tanfovy"], H, W, args.sh_degree, False, False, False, False)
+                Rs.append(int(res[0]))
+                Vs.append(int((res[2] > 0).sum()))
+        V, R = float(np.mean(Vs)), float(np.mean(Rs))
+        N, T = H * W, ((W + 15) // 16) * ((H + 15) // 16)
+        ab = algorithmic_bytes(P, V, R, N, M, T)
+        kernels = {}
+        for name, (ms, n) in prof.stages.items():
+            avg = ms / n
+            rec = {"launches_per_step": n / args.steps, "avg_ms": round(avg, 4), "ms_per_step": round(ms / args.steps, 4)}
+            if name in ab:
+                rec["alg_bytes_per_launch"] = int(ab[name])
+                rec["achieved_GBs"] = round(ab[name] / (avg * 1e-3) / 1e9, 2)
+            kernels[name] = rec
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+        roofline = None
+        if dom is not None and "achieved_GBs" in kernels[dom]:
+            a = kernels[dom]["achieved_GBs"]
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": None,
+                        "note": "dominant kernel by time; it is VALU/gather-bound, not HBM-bound (DESIGN.md)"}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(sc, cams[args.warmup % n_views], gi, args.sh_degree)
+        line = {
+            "metric": "train-step renders/sec (fwd+bwd, G-buffer+indirect) at 800x800",
+            "value": round(args.steps * world / elapsed, 3), "unit": "renders/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 stand-in: %dk surface Gaussians, %dx%d, SH deg %d, GI step=%d start=%d delta=%g"
+                                   % (P // 1000, W, H, args.sh_degree, gi["step"], gi["start"], gi["delta"]),
+                       "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade,
+                       "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "../../include/gigs_hip.h"
 #include "gigs_common.h"
@@ -16,8 +17,6 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local float g_stage_ms[8];
-thread_local int g_stage_n = 0;
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -81,25 +80,56 @@ uint32_t higher_msb(uint32_t n) {
   return msb;
 }
 
-struct StageTimer {
+// ---- in-library per-stage timing --------------------------------------------------------
+// A "profile session" records one hipEvent pair per kernel stage on the stream the stage is
+// launched on, WITHOUT synchronising; gigs_profile_end() synchronises once and sums the
+// elapsed times.  bench.py uses it to measure kernel durations live over its timed region.
+enum Stage {
+  kPreprocess = 0, kScan, kDuplicate, kSort, kRanges, kBlendFwd, kBlendBwd, kPreprocessBwd,
+  kDepthToNormal, kSsao, kSsr, kMedian, kBilateral, kMedianBwd, kShadeFwd, kShadeBwd,
+  kCubemapFwd, kCubemapBwd, kNumStages
+};
+const char* kStageNames[kNumStages] = {
+  "preprocess_fwd", "scan", "duplicate", "sort", "tile_ranges", "blend_fwd", "blend_bwd",
+  "preprocess_bwd", "depth_to_normal", "ssao", "ssr", "median3x3", "bilateral3x3",
+  "median3x3_bwd", "shade_fwd", "shade_bwd", "cubemap_fwd", "cubemap_bwd"};
+
+struct ProfRec { int stage; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+// RAII: records start at construction and stop at destruction when a session is active.
+struct StageScope {
   hipStream_t s;
+  int stage;
   bool on;
-  hipEvent_t ev[9];
-  int n = 0;
-  StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
-    if (on)
-      for (auto& e : ev) hipEventCreate(&e);
+  hipEvent_t a, b;
+  StageScope(int stage_, hipStream_t s_) : s(s_), stage(stage_), on(false) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return;
+    on = true;
+    a = prof_event();
+    b = prof_event();
+    hipEventRecord(a, s);
   }
-  void mark() {
-    if (on && n < 9) hipEventRecord(ev[n++], s);
-  }
-  void finish() {
+  ~StageScope() {
     if (!on) return;
-    hipStreamSynchronize(s);
-    g_stage_n = 0;
-    for (int i = 1; i < n; i++) hipEventElapsedTime(&g_stage_ms[g_stage_n++], ev[i - 1], ev[i]);
-    for (auto& e : ev) hipEventDestroy(e);
-    on = false;
+    hipEventRecord(b, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back({stage, a, b});
   }
 };
 
@@ -152,10 +182,36 @@ long long gigs_image_offset(int width, int height, int which) {
   return (long long)((const char*)ptrs[which] - base);
 }
 
-int gigs_last_stage_ms(float* ms, int n) {
-  const int c = g_stage_n < n ? g_stage_n : n;
-  for (int i = 0; i < c; i++) ms[i] = g_stage_ms[i];
-  return c;
+void gigs_profile_begin(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+  g_prof_recs.clear();
+  g_prof_on = true;
+}
+
+int gigs_profile_end(float* total_ms, int* launches, int n) {
+  std::vector<ProfRec> recs;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    recs.swap(g_prof_recs);
+  }
+  for (int i = 0; i < n; i++) { total_ms[i] = 0.0f; launches[i] = 0; }
+  for (auto& r : recs) {
+    hipEventSynchronize(r.b);
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.stage < n) {
+      total_ms[r.stage] += ms;
+      launches[r.stage] += 1;
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+  return kNumStages;
+}
+
+const char* gigs_profile_stage_name(int stage) {
+  return (stage >= 0 && stage < kNumStages) ? kStageNames[stage] : "";
 }
 
 int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer,
@@ -208,14 +264,16 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
   if (!img_chunk) return fail(GIGS_ERR_ALLOC, "image buffer allocation of %zu bytes failed", img_bytes);
   gigs::ImageState img = gigs::ImageState::fromChunk(img_chunk, N, T);
 
-  StageTimer tm(s, debug == 2);
-  tm.mark();
-  gigs::launch_preprocess_fwd(a, geom, radii, s);
+  {
+    StageScope sc(kPreprocess, s);
+    gigs::launch_preprocess_fwd(a, geom, radii, s);
+  }
   STAGE_CHECK("preprocess");
-  tm.mark();
-  HIP_TRY(gigs::scan_tiles(geom, P, s));
+  {
+    StageScope sc(kScan, s);
+    HIP_TRY(gigs::scan_tiles(geom, P, s));
+  }
   STAGE_CHECK("scan");
-  tm.mark();
 
   // the one blocking read of the forward (rasterizer_impl.cu:589): sizes the binning chunk
   uint32_t num_rendered_u = 0;
@@ -230,22 +288,29 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
   if (!bin_chunk) return fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
   gigs::BinningState bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, sort_sz);
 
-  gigs::launch_duplicate(P, radii, a.gx, a.gy, geom, bin, s);
+  {
+    StageScope sc(kDuplicate, s);
+    gigs::launch_duplicate(P, radii, a.gx, a.gy, geom, bin, s);
+  }
   STAGE_CHECK("duplicateWithKeys");
-  tm.mark();
   const int bit = (int)higher_msb(a.gx * a.gy);
-  if (num_rendered > 0) HIP_TRY(gigs::sort_pairs(bin, num_rendered, 32 + bit, s));
+  if (num_rendered > 0) {
+    StageScope sc(kSort, s);
+    HIP_TRY(gigs::sort_pairs(bin, num_rendered, 32 + bit, s));
+  }
   STAGE_CHECK("sort");
-  tm.mark();
-  HIP_TRY(hipMemsetAsync(img.ranges, 0, T * sizeof(uint2), s));
-  gigs::launch_tile_ranges(num_rendered, bin, img.ranges, s);
+  {
+    StageScope sc(kRanges, s);
+    HIP_TRY(hipMemsetAsync(img.ranges, 0, T * sizeof(uint2), s));
+    gigs::launch_tile_ranges(num_rendered, bin, img.ranges, s);
+  }
   STAGE_CHECK("identifyTileRanges");
-  tm.mark();
-  gigs::launch_blend_fwd(a, geom, bin, img, out_color, out_opacity, out_depth, out_normal,
-                         out_normal_view, out_pos, out_albedo, out_roughness, out_metallic, s);
+  {
+    StageScope sc(kBlendFwd, s);
+    gigs::launch_blend_fwd(a, geom, bin, img, out_color, out_opacity, out_depth, out_normal,
+                           out_normal_view, out_pos, out_albedo, out_roughness, out_metallic, s);
+  }
   STAGE_CHECK("render");
-  tm.mark();
-  tm.finish();
   return num_rendered;
 }
 
@@ -305,16 +370,17 @@ int gigs_backward(int P, int D, int M, int R, const float* background, int width
   gigs::ImageState img = gigs::ImageState::fromChunk(ip, N, T);
   a.radii = radii ? radii : geom.internal_radii;
 
-  StageTimer tm(s, debug == 2);
-  tm.mark();
-  HIP_TRY(hipMemsetAsync(geom.grec, 0, (size_t)P * GIGS_GREC * sizeof(float), s));
-  gigs::launch_blend_bwd(a, geom, bin, img, s);
+  {
+    StageScope sc(kBlendBwd, s);
+    HIP_TRY(hipMemsetAsync(geom.grec, 0, (size_t)P * GIGS_GREC * sizeof(float), s));
+    gigs::launch_blend_bwd(a, geom, bin, img, s);
+  }
   STAGE_CHECK("render backward");
-  tm.mark();
-  gigs::launch_preprocess_bwd(a, geom, s);
+  {
+    StageScope sc(kPreprocessBwd, s);
+    gigs::launch_preprocess_bwd(a, geom, s);
+  }
   STAGE_CHECK("preprocess backward");
-  tm.mark();
-  tm.finish();
   return 0;
 }
 
@@ -333,6 +399,7 @@ int gigs_depth_to_normal(int width, int height, float focal_x, float focal_y,
                          float* depth_pos, void* stream) {
   if (width <= 0 || height <= 0 || !viewmatrix || !depth || !normal || !depth_pos)
     return fail(GIGS_ERR_INVALID, "bad argument");
+  StageScope sc(kDepthToNormal, (hipStream_t)stream);
   gigs::launch_depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depth, normal, depth_pos, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -342,6 +409,7 @@ int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius,
               float thick, float delta, int step, int start, const float* normal_view,
               const float* pos, float* occlusion, void* stream) {
   if (width <= 0 || height <= 0 || !normal_view || !pos || !occlusion) return fail(GIGS_ERR_INVALID, "bad argument");
+  StageScope sc(kSsao, (hipStream_t)stream);
   const int rc = gigs::launch_ssao(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
                                    normal_view, pos, occlusion, (hipStream_t)stream);
   if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
@@ -356,6 +424,7 @@ int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, 
              const float* metallic, const float* F0, float* color, float* abd, void* stream) {
   if (width <= 0 || height <= 0 || !normal_view || !pos || !rgb || !albedo || !metallic || !F0 || !color || !abd)
     return fail(GIGS_ERR_INVALID, "bad argument");
+  StageScope sc(kSsr, (hipStream_t)stream);
   const int rc = gigs::launch_ssr(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
                                   normal_view, pos, rgb, albedo, roughness, metallic, F0, color, abd, (hipStream_t)stream);
   if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
@@ -366,6 +435,7 @@ int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, 
 
 int gigs_median3x3(int channels, int height, int width, const float* in, float* out, void* stream) {
   if (channels <= 0 || width <= 0 || height <= 0 || !in || !out) return fail(GIGS_ERR_INVALID, "bad argument");
+  StageScope sc(kMedian, (hipStream_t)stream);
   gigs::launch_median3x3(channels, height, width, in, out, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -374,6 +444,7 @@ int gigs_median3x3(int channels, int height, int width, const float* in, float* 
 int gigs_median3x3_backward(int channels, int height, int width, const float* in,
                             const float* grad_out, float* grad_in, void* stream) {
   if (channels <= 0 || width <= 0 || height <= 0 || !in || !grad_out || !grad_in) return fail(GIGS_ERR_INVALID, "bad argument");
+  StageScope sc(kMedianBwd, (hipStream_t)stream);
   gigs::launch_median3x3_bwd(channels, height, width, in, grad_out, grad_in, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -383,6 +454,7 @@ int gigs_bilateral3x3(int channels, int height, int width, float sigma_color, fl
                       float sigma_y, const float* in, float* out, void* stream) {
   if ((channels != 1 && channels != 3) || width <= 1 || height <= 1 || !in || !out)
     return fail(GIGS_ERR_INVALID, "bilateral3x3 supports 1 or 3 channels and images larger than 1x1");
+  StageScope sc(kBilateral, (hipStream_t)stream);
   gigs::launch_bilateral3x3(channels, height, width, sigma_color, sigma_x, sigma_y, in, out, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;

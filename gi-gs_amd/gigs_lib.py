@@ -52,7 +52,9 @@ SIGNATURES = {
     "gigs_geom_offset": (C.c_longlong, [_i, _i]),
     "gigs_binning_offset": (C.c_longlong, [_i, _i]),
     "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),
-    "gigs_last_stage_ms": (_i, [C.POINTER(C.c_float), _i]),
+    "gigs_profile_begin": (None, []),
+    "gigs_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
+    "gigs_profile_stage_name": (C.c_char_p, [_i]),
 }
 
 _lib = None
@@ -84,3 +86,22 @@ def check(rc: int, what: str) -> int:
         msg = lib().gigs_last_error().decode("utf-8", "replace")
         raise GigsError(f"{what} failed ({rc}): {msg}")
     return rc
+
+
+class profile:
+    """Context manager around gigs_profile_begin/end; `.stages` = {name: (total_ms, launches)}."""
+
+    def __enter__(self):
+        lib().gigs_profile_begin()
+        self.stages = {}
+        return self
+
+    def __exit__(self, *exc):
+        n = 64
+        ms = (C.c_float * n)()
+        cnt = (C.c_int * n)()
+        k = lib().gigs_profile_end(ms, cnt, n)
+        for i in range(min(k, n)):
+            if cnt[i]:
+                self.stages[lib().gigs_profile_stage_name(i).decode()] = (float(ms[i]), int(cnt[i]))
+        return False

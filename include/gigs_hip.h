@@ -129,10 +129,14 @@ long long gigs_geom_offset(int P, int which);
 long long gigs_binning_offset(int num_rendered, int which);
 long long gigs_image_offset(int width, int height, int which);
 
-/* Wall-clock-free per-stage timing of the last forward/backward issued with debug == 2:
- * fills up to `n` floats with milliseconds (hipEvents on `stream`); returns the count.
- * Order: preprocess, scan, duplicate, sort, ranges, blend_fwd | blend_bwd, preprocess_bwd. */
-int gigs_last_stage_ms(float* ms, int n);
+/* In-library stage timing for bench.py.  Between gigs_profile_begin() and gigs_profile_end()
+ * every kernel stage launched by this library records a hipEvent pair on its own stream (no
+ * synchronisation is added).  gigs_profile_end() waits for the recorded events, writes the
+ * summed milliseconds and launch counts per stage id into the two arrays of length n and
+ * returns the number of stage ids; gigs_profile_stage_name(i) names stage i. */
+void gigs_profile_begin(void);
+int gigs_profile_end(float* total_ms, int* launches, int n);
+const char* gigs_profile_stage_name(int stage);
 
 #ifdef __cplusplus
 }
