@@ -61,6 +61,10 @@ def algorithmic_bytes(P, V, R, N, M, T):
         "median3x3_bwd": 12 * N,
         "shade_fwd": 80 * N,
         "shade_bwd": 96 * N,
+        # light: 10 launches per build_mips (4 mip, 1 diffuse, 5 GGX); per launch on average: textures
+        # read + written (6.3 MB each way over the chain) and the GGX window bounds (96 B per texel)
+        "cubemap_fwd": (2 * 6.3e6 + 96 * 6 * (256 ** 2 + 128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2)) / 10,
+        "cubemap_bwd": (2 * 6.3e6 + 96 * 6 * (256 ** 2 + 128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2)) / 10,
     }
 
 
@@ -245,7 +249,8 @@ def main():
                 rec["alg_bytes_per_launch"] = int(ab[name])
                 rec["achieved_GBs"] = round(ab[name] / (avg * 1e-3) / 1e9, 2)
             kernels[name] = rec
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+        with_bytes = [k for k in kernels if "achieved_GBs" in kernels[k]]
+        dom = max(with_bytes, key=lambda k: kernels[k]["ms_per_step"]) if with_bytes else None
         roofline = None
         if dom is not None and "achieved_GBs" in kernels[dom]:
             a = kernels[dom]["achieved_GBs"]

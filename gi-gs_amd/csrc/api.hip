@@ -135,6 +135,15 @@ struct StageScope {
 
 }  // namespace
 
+// helpers for the other translation units of the library (not part of the ABI)
+extern "C" {
+__attribute__((visibility("hidden"))) int gigs_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
+__attribute__((visibility("hidden"))) void gigs_internal_stage_begin(int stage, void* stream, void** token) {
+  *token = new StageScope(stage, (hipStream_t)stream);
+}
+__attribute__((visibility("hidden"))) void gigs_internal_stage_end(void* token) { delete (StageScope*)token; }
+}
+
 extern "C" {
 
 const char* gigs_last_error(void) { return g_err; }

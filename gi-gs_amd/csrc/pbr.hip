@@ -1,0 +1,813 @@
+// pbr.hip -- deferred split-sum shade of the G-buffer and the cubemap light filters.
+//
+// Reference behaviour restated:
+//   pbr_shading                          pbr/shade.py:108-241
+//   CubemapLight.get_mip / cubemap_mip   pbr/light.py:142-152, 54-79
+//   DiffuseCubemapFwd/BwdKernel          pbr/renderutils/c_src/cubemap.cu:110-169  ("RU/")
+//   SpecularBoundsKernel                 RU/cubemap.cu:181-244
+//   SpecularCubemapFwd/BwdKernel         RU/cubemap.cu:246-350
+// The three texture lookups of the shade are nvdiffrast `dr.texture` calls in the reference
+// (third party, unpinned -> parity unpinned); the sampling rule implemented here is written
+// down in include/gigs_hip.h and oracle/pbr_oracle.cpp.
+//
+// MI355X design
+//   * shade forward/backward are ONE fused kernel each, one lane per pixel: the reference runs
+//     ~40 small torch kernels + 3 texture ops over the same 640k pixels; fused, the pass reads
+//     each G-buffer plane once (~80 B/pixel) and is bound by the gathers into the light
+//     textures, which are small (diffuse 18 KB, specular mips 6.3 MB) and stay in L2;
+//   * gradients of the light textures: the 16x16x6 diffuse map is accumulated per workgroup in
+//     LDS (ds_add_f32, 18 KB) and flushed once, the specular mips take global float atomics;
+//   * the cubemap-filter backward passes are GATHERS, not the reference's atomic scatters: the
+//     GGX window test dot(L, V) >= cutoff is symmetric in (L, V), so the set of outputs that
+//     touch a texel is that texel's own window; same terms, no atomics, reproducible sums;
+//   * pixel-invariant tables (solid angle per texel) are built once on the host with libm and
+//     cached per device.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "gigs_common.h"
+
+namespace gigs {
+
+// ------------------------------------------------------------------------------------------
+// helpers shared by all kernels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ v3 safe_normalize(v3 v) {  // RU/vec3f.h:90-94
+  const float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+  return l > 0.0f ? v3{v.x / l, v.y / l, v.z / l} : v3{0, 0, 0};
+}
+__device__ __forceinline__ v3 cube_dir_raw(float fx, float fy, int side) {
+  switch (side) {
+    case 0: return {1, -fy, -fx};
+    case 1: return {-1, -fy, fx};
+    case 2: return {fx, 1, fy};
+    case 3: return {fx, -1, -fy};
+    case 4: return {fx, -fy, 1};
+    default: return {-fx, -fy, -1};
+  }
+}
+__device__ __forceinline__ v3 cube_to_dir(int x, int y, int side, int N) {  // RU/cubemap.cu:33-47
+  const float fx = 2.0f * (((float)x + 0.5f) / (float)N) - 1.0f;
+  const float fy = 2.0f * (((float)y + 0.5f) / (float)N) - 1.0f;
+  return safe_normalize(cube_dir_raw(fx, fy, side));
+}
+__device__ __forceinline__ float ndf_ggx(float alphaSqr, float cosTheta) {  // RU/cubemap.cu:174-179
+  const float c = fminf(fmaxf(cosTheta, 0.0f), 1.0f);
+  const float d = (c * alphaSqr - c) * c + 1.0f;
+  return (float)((double)alphaSqr / ((double)(d * d) * 3.14159265358979323846));
+}
+
+// ---- per-resolution texel table: float4 (unit direction of the texel centre, solid angle) ----
+// direction = cube_to_dir (RU/cubemap.cu:33-47, computed on the device once per resolution with
+// the same IEEE sequence as the oracle); solid angle = pixel_area (RU/cubemap.cu:17-31) from a
+// 1-D table built on the HOST with libm atanf: area[i] = atan((i+1)/H) - atan(i/H), i = |x - H|.
+// Both are pixel- and iteration-invariant, so the filters read one 16-byte entry per texel
+// instead of redoing 5 divisions, a sqrt and 4 atanf per (output, input) pair.
+__global__ void __launch_bounds__(256)
+texel_table_kernel(int N, const float* __restrict__ area, float4* __restrict__ table) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= 6 * N * N) return;
+  const int pz = o / (N * N), py = (o / N) % N, px = o % N;
+  const v3 d = cube_to_dir(px, py, pz, N);
+  float a = 1.0f;
+  if (N > 1) {
+    const int Hh = N / 2;
+    a = area[abs(px - Hh)] * area[abs(py - Hh)];
+  }
+  table[o] = make_float4(d.x, d.y, d.z, a);
+}
+
+struct TexelTable { float4* dev = nullptr; };
+static std::mutex g_table_mu;
+static std::map<long long, TexelTable> g_table;
+
+static const float4* texel_table(int N, hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_table_mu);
+  const long long key = ((long long)dev << 32) | (unsigned)N;
+  auto it = g_table.find(key);
+  if (it != g_table.end()) return it->second.dev;
+  const int Hh = N / 2;
+  std::vector<float> h(Hh + 2, 1.0f);
+  if (N > 1)
+    for (int i = 0; i <= Hh; i++) h[i] = atanf((float)(i + 1) / (float)Hh) - atanf((float)i / (float)Hh);
+  float* area = nullptr;
+  TexelTable t;
+  // one-time per (device, resolution); kept for the lifetime of the process
+  if (hipMalloc(&area, h.size() * sizeof(float)) != hipSuccess) return nullptr;
+  if (hipMalloc(&t.dev, (size_t)6 * N * N * sizeof(float4)) != hipSuccess) return nullptr;
+  if (hipMemcpyAsync(area, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+  hipLaunchKernelGGL(texel_table_kernel, dim3((6 * N * N + 255) / 256), dim3(256), 0, s, N, area, t.dev);
+  if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+  hipFree(area);
+  g_table[key] = t;
+  return t.dev;
+}
+
+// Sum over the 64 lanes of a wave (DPP, no LDS); total valid in lane 63.
+template <int kCtrl, int kRowMask = 0xf>
+__device__ __forceinline__ float pbr_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum63(float v) {
+  v += pbr_dpp<0xb1>(v);
+  v += pbr_dpp<0x4e>(v);
+  v += pbr_dpp<0x124>(v);
+  v += pbr_dpp<0x128>(v);
+  v += pbr_dpp<0x142, 0xa>(v);
+  v += pbr_dpp<0x143, 0xc>(v);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// cubemap filters: ONE WAVE PER OUTPUT TEXEL (4 per 256-lane workgroup).  The 64 lanes sweep
+// the texel's window as an 8x8 patch, so neighbouring lanes read neighbouring 16-byte table /
+// texture entries, and the four partial sums are combined with DPP.  Even the 16x16 level
+// (1536 outputs) then fills the chip with 1536 waves instead of 24.
+// ------------------------------------------------------------------------------------------
+// forward: out[o] = sum_in tex[in] * w(o, in);  backward (gather): g_in[i] = sum_o g[o] * w(o, i)
+template <bool kBackward>
+__global__ void __launch_bounds__(256)
+diffuse_cubemap_kernel(int N, const float4* __restrict__ table, const float* __restrict__ src,
+                       float* __restrict__ dst) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= 6 * N * N) return;  // wave-uniform
+  const float4 me = table[o];
+  float c0 = 0, c1 = 0, c2 = 0;
+  for (int i = lane; i < 6 * N * N; i += 64) {
+    const float4 ot = table[i];
+    // forward: N = me, L = other, area of L; backward: N = other, L = me, area of me
+    const float d = kBackward ? (ot.x * me.x + ot.y * me.y + ot.z * me.z) : (me.x * ot.x + me.y * ot.y + me.z * ot.z);
+    const float costheta = fminf(fmaxf(d, 0.0f), 0.999f);
+    const float w = costheta * (kBackward ? me.w : ot.w) / 3.141592f;
+    const float* t = src + 3 * (size_t)i;
+    c0 += t[0] * w; c1 += t[1] * w; c2 += t[2] * w;
+  }
+  c0 = wave_sum63(c0); c1 = wave_sum63(c1); c2 = wave_sum63(c2);
+  if (lane == 63) { dst[3 * (size_t)o] = c0; dst[3 * (size_t)o + 1] = c1; dst[3 * (size_t)o + 2] = c2; }
+}
+
+
+__global__ void __launch_bounds__(64)
+specular_bounds_kernel(int N, float cutoff, float* __restrict__ bounds) {
+  const int o = blockIdx.x * 64 + threadIdx.x;
+  if (o >= 6 * N * N) return;
+  const int pz = o / (N * N), py = (o / N) % N, px = o % N;
+  const v3 VNR = cube_to_dir(px, py, pz, N);
+  const int TILE = 16;
+  for (int s = 0; s < 6; ++s) {
+    int minx = N - 1, maxx = 0, miny = N - 1, maxy = 0;
+    for (int tx = 0; tx < (N + TILE - 1) / TILE; tx++)
+      for (int ty = 0; ty < (N + TILE - 1) / TILE; ty++) {
+        const int tsx = tx * TILE, tsy = ty * TILE;
+        const int tex = min((tx + 1) * TILE, N), tey = min((ty + 1) * TILE, N);
+        const v3 L0 = cube_to_dir(tsx, tsy, s, N), L1 = cube_to_dir(tex, tsy, s, N);
+        const v3 L2 = cube_to_dir(tsx, tey, s, N), L3 = cube_to_dir(tex, tey, s, N);
+        const float mnx = fminf(fminf(L0.x, L1.x), fminf(L2.x, L3.x)), mxx = fmaxf(fmaxf(L0.x, L1.x), fmaxf(L2.x, L3.x));
+        const float mny = fminf(fminf(L0.y, L1.y), fminf(L2.y, L3.y)), mxy = fmaxf(fmaxf(L0.y, L1.y), fmaxf(L2.y, L3.y));
+        const float mnz = fminf(fminf(L0.z, L1.z), fminf(L2.z, L3.z)), mxz = fmaxf(fmaxf(L0.z, L1.z), fmaxf(L2.z, L3.z));
+        const float maxdp = fmaxf(mnx * VNR.x, mxx * VNR.x) + fmaxf(mny * VNR.y, mxy * VNR.y) + fmaxf(mnz * VNR.z, mxz * VNR.z);
+        if (maxdp >= cutoff) {
+          for (int y = tsy; y < tey; ++y)
+            for (int x = tsx; x < tex; ++x) {
+              const v3 L = cube_to_dir(x, y, s, N);
+              if (dot3(L, VNR) >= cutoff) {
+                minx = min(minx, x); maxx = max(maxx, x);
+                miny = min(miny, y); maxy = max(maxy, y);
+              }
+            }
+        }
+      }
+    float* b = bounds + 24 * (size_t)o + s * 4;
+    b[0] = (float)minx; b[1] = (float)maxx; b[2] = (float)miny; b[3] = (float)maxy;
+  }
+}
+
+// forward: out[o] = (sum_in tex[in] w, sum w) over in in window(o)
+// backward (gather over the same, symmetric, window): g_in[i] = sum_o g[o].rgb * w(o, i)
+// forward: out[o] = (sum_in tex[in] w, sum w) over in in window(o)
+// backward (gather over the same window, which is symmetric because the test dot(L, V) >= cutoff
+// is): g_in[i] = sum_o g[o].rgb * w(o, i).
+// Per accepted pair the arithmetic is the reference's own sequence (H = safeNormalize(L + V), V.H,
+// the NDF with its fp64 division: RU/cubemap.cu:174-179, 270-277) on the cached unit directions,
+// so every weight is bit-identical to the oracle's and only the summation order differs.  This
+// matters: d = 1 - c^2 (1 - alpha^2) cancels to ~alpha^2 at the lobe centre, so a 1-ulp change of
+// c = V.H (e.g. the algebraic shortcut sqrt((1 + L.V) / 2)) moves a weight by ~1e-7 / alpha^2 --
+// 2e-3 at the roughness-0.08 level.
+template <bool kBackward>
+__global__ void __launch_bounds__(256)
+specular_cubemap_kernel(int N, const float4* __restrict__ table, const float* __restrict__ src,
+                        const float* __restrict__ bounds, float roughness, float cutoff,
+                        float* __restrict__ dst) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= 6 * N * N) return;  // wave-uniform
+  const int lx = lane & 7, ly = lane >> 3;
+  const float4 me = table[o];
+  const float alpha = roughness * roughness, alphaSqr = alpha * alpha;
+  float wsum = 0.0f, c0 = 0, c1 = 0, c2 = 0;
+  const int stride = kBackward ? 4 : 3;
+  const float4* b4 = reinterpret_cast<const float4*>(bounds + 24 * (size_t)o);
+  for (int s = 0; s < 6; ++s) {
+    const float4 b = b4[s];
+    const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
+    if (xmin > xmax) continue;
+    for (int y = ymin + ly; y <= ymax; y += 8)
+      for (int x = xmin + lx; x <= xmax; x += 8) {
+        const int i = (s * N + y) * N + x;
+        const float4 ot = table[i];
+        const float d = kBackward ? (me.x * ot.x + me.y * ot.y + me.z * ot.z) : (ot.x * me.x + ot.y * me.y + ot.z * me.z);
+        if (d >= cutoff) {
+          const float wiDotN = fmaxf(d, 0.0f);
+          // forward: VNR = me, L = other; backward: VNR = other, L = me
+          const v3 Hh = kBackward ? safe_normalize(v3{me.x + ot.x, me.y + ot.y, me.z + ot.z})
+                                  : safe_normalize(v3{ot.x + me.x, ot.y + me.y, ot.z + me.z});
+          const float VNRDotH = fmaxf(kBackward ? (ot.x * Hh.x + ot.y * Hh.y + ot.z * Hh.z)
+                                                : (me.x * Hh.x + me.y * Hh.y + me.z * Hh.z), 0.0f);
+          const float w = wiDotN * ndf_ggx(alphaSqr, VNRDotH) * (kBackward ? me.w : ot.w) / 4.0f;
+          const float* t = src + (size_t)stride * i;
+          c0 += t[0] * w; c1 += t[1] * w; c2 += t[2] * w;
+          wsum += w;
+        }
+      }
+  }
+  c0 = wave_sum63(c0); c1 = wave_sum63(c1); c2 = wave_sum63(c2);
+  if (!kBackward) wsum = wave_sum63(wsum);
+  if (lane == 63) {
+    if (kBackward) {
+      float* q = dst + 3 * (size_t)o;
+      q[0] = c0; q[1] = c1; q[2] = c2;
+    } else {
+      float* q = dst + 4 * (size_t)o;
+      q[0] = c0; q[1] = c1; q[2] = c2; q[3] = wsum;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// cube / 2-D texture sampling
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cube_face_uv(float x, float y, float z, float& u, float& v) {
+  const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+  int idx;
+  float c;
+  if (az > fmaxf(ax, ay)) { idx = 4; c = z; }
+  else if (ay > ax) { idx = 2; c = y; y = z; }
+  else { idx = 0; c = x; x = z; }
+  if (c < 0.f) idx += 1;
+  const float m = (1.0f / fabsf(c)) * 0.5f;
+  const float m0 = (idx == 0 || idx == 5) ? -m : m;
+  const float m1 = (idx != 2) ? -m : m;
+  u = x * m0 + 0.5f;
+  v = y * m1 + 0.5f;
+  if (!isfinite(u) || !isfinite(v)) return -1;
+  u = fminf(fmaxf(u, 0.f), 1.f);
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  return idx;
+}
+
+struct Taps { int idx[4]; float w[4]; };
+
+__device__ __forceinline__ bool cube_taps(int res, float dx, float dy, float dz, Taps& t) {
+  float u, v;
+  const int face = cube_face_uv(dx, dy, dz, u, v);
+  if (face < 0) return false;
+  const float fu = u * (float)res - 0.5f, fv = v * (float)res - 0.5f;
+  const float flu = floorf(fu), flv = floorf(fv);
+  const int iu0 = (int)flu, iv0 = (int)flv;
+  const float tu = fu - flu, tv = fv - flv;
+  float wsum = 0.0f;
+  bool dropped = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int ox = k & 1, oy = k >> 1;
+    const int ix = iu0 + ox, iy = iv0 + oy;
+    const float w = (ox ? tu : 1.0f - tu) * (oy ? tv : 1.0f - tv);
+    const bool out_x = ix < 0 || ix >= res, out_y = iy < 0 || iy >= res;
+    int idx;
+    if (!out_x && !out_y) {
+      idx = (face * res + iy) * res + ix;
+    } else if (out_x && out_y) {
+      idx = -1;
+      dropped = true;
+    } else {
+      const float a = 2.0f * (((float)ix + 0.5f) / (float)res) - 1.0f;
+      const float b = 2.0f * (((float)iy + 0.5f) / (float)res) - 1.0f;
+      const v3 d = cube_dir_raw(a, b, face);
+      float u2, v2;
+      const int f2 = cube_face_uv(d.x, d.y, d.z, u2, v2);
+      const int x2 = min(res - 1, max(0, (int)floorf(u2 * (float)res)));
+      const int y2 = min(res - 1, max(0, (int)floorf(v2 * (float)res)));
+      idx = (f2 * res + y2) * res + x2;
+    }
+    t.idx[k] = idx;
+    t.w[k] = w;
+    if (idx >= 0) wsum += w;
+  }
+  if (dropped) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.w[k] = t.idx[k] >= 0 ? t.w[k] / wsum : 0.0f;
+  }
+  return true;
+}
+
+__device__ __forceinline__ v3 cube_sample(const float* __restrict__ tex, const Taps& t) {
+  v3 r = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (t.idx[k] >= 0) {
+      const float* p = tex + 3 * (size_t)t.idx[k];
+      r.x += p[0] * t.w[k];
+      r.y += p[1] * t.w[k];
+      r.z += p[2] * t.w[k];
+    }
+  return r;
+}
+
+// cubemap_mip: forward 2x2 average, backward = bilinear cube lookup of 0.25 * dout
+__global__ void __launch_bounds__(256)
+cubemap_mip_fwd_kernel(int r, int C, const float* __restrict__ in, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 6 * r * r * C) return;
+  const int c = i % C, x = (i / C) % r, y = (i / (C * r)) % r, f = i / (C * r * r);
+  const int R2 = 2 * r;
+  const float* p = in + ((size_t)(f * R2 + 2 * y) * R2 + 2 * x) * C + c;
+  out[i] = (p[0] + p[C] + p[(size_t)R2 * C] + p[(size_t)R2 * C + C]) * 0.25f;
+}
+
+__global__ void __launch_bounds__(256)
+cubemap_mip_bwd_kernel(int r, const float* __restrict__ dout, float* __restrict__ din) {
+  const int res = 2 * r;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 6 * res * res) return;
+  const int x = i % res, y = (i / res) % res, s = i / (res * res);
+  const float start = -1.0f + 1.0f / (float)res, end = 1.0f - 1.0f / (float)res;
+  const float stepv = (end - start) / (float)(res - 1);
+  const float gx = x < res / 2 ? start + stepv * (float)x : end - stepv * (float)(res - 1 - x);
+  const float gy = y < res / 2 ? start + stepv * (float)y : end - stepv * (float)(res - 1 - y);
+  v3 d = cube_dir_raw(gx, gy, s);
+  const float n = fmaxf(sqrtf(d.x * d.x + d.y * d.y + d.z * d.z), 1e-12f);
+  d = {d.x / n, d.y / n, d.z / n};
+  Taps t;
+  v3 v = {0, 0, 0};
+  if (cube_taps(r, d.x, d.y, d.z, t)) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (t.idx[k] >= 0) {
+        const float* p = dout + 3 * (size_t)t.idx[k];
+        v.x += (p[0] * 0.25f) * t.w[k];
+        v.y += (p[1] * 0.25f) * t.w[k];
+        v.z += (p[2] * 0.25f) * t.w[k];
+      }
+  }
+  din[3 * (size_t)i] = v.x; din[3 * (size_t)i + 1] = v.y; din[3 * (size_t)i + 2] = v.z;
+}
+
+// ------------------------------------------------------------------------------------------
+// shade
+// ------------------------------------------------------------------------------------------
+struct ShadeArgs {
+  int H, W;
+  const float *normals, *view_dirs, *albedo, *roughness;
+  const uint8_t* mask;
+  const float *occlusion, *metallic, *background;
+  const float* diffuse; int diffuse_res;
+  int L; const float* spec[8]; int spec_res[8];
+  const float* lut; int lut_w, lut_h;
+  int tone, gamma;
+  // forward outputs
+  float *render_rgb, *diffuse_rgb, *specular_rgb, *diffuse_light;
+  // backward inputs (may be null) and outputs
+  const float *g_render, *g_diffuse_rgb, *g_specular_rgb, *g_diffuse_light;
+  float *d_albedo, *d_roughness, *d_metallic, *d_diffuse;
+  float* d_spec[8];
+};
+
+__device__ __forceinline__ float get_mip(float r, int L, float& dmip_dr) {  // pbr/light.py:142-152
+  const float MINR = 0.08f, MAXR = 0.5f;
+  if (r < MAXR) {
+    const float c = fminf(fmaxf(r, MINR), MAXR);
+    dmip_dr = (r >= MINR && r <= MAXR) ? (1.0f / (MAXR - MINR)) * (float)(L - 2) : 0.0f;
+    return (c - MINR) / (MAXR - MINR) * (float)(L - 2);
+  }
+  const float c = fminf(fmaxf(r, MAXR), 1.0f);
+  dmip_dr = (r >= MAXR && r <= 1.0f) ? 1.0f / (1.0f - MAXR) : 0.0f;
+  return (c - MAXR) / (1.0f - MAXR) + (float)L - 2.0f;
+}
+__device__ __forceinline__ float lin2srgb(float x, float& d) {  // pbr/shade.py:50-63
+  const float eps = 1.1920929e-07f;
+  if (x <= 0.0031308f) { d = 323.0f / 25.0f; return 323.0f / 25.0f * x; }
+  const float c = fmaxf(x, eps);
+  const float p = powf(c, 5.0f / 12.0f);
+  d = x >= eps ? 211.0f * (5.0f / 12.0f) * p / c / 200.0f : 0.0f;
+  return (211.0f * p - 11.0f) / 200.0f;
+}
+__device__ __forceinline__ float aces(float x, float& d) {  // pbr/shade.py:33-47
+  const float a = 2.51f, b = 0.03f, c = 2.43f, dd = 0.59f, e = 0.14f;
+  const float num = x * (a * x + b), den = x * (c * x + dd) + e;
+  d = ((2 * a * x + b) * den - num * (2 * c * x + dd)) / (den * den);
+  return num / den;
+}
+
+// Everything both passes need, computed identically in forward and backward.
+struct ShadePix {
+  v3 a, dl_raw, dl, drgb, sp, s0, s1, F0, refl, srgb;
+  float r, occ, m, fgx, fgy, dfgx_dv, dfgy_dv, lf, dmdr;
+  int l0, l1;
+  bool lvl_inside;
+  Taps td, t0, t1;
+  bool has_d, has0, has1;
+};
+
+__device__ __forceinline__ void shade_pixel(const ShadeArgs& A, int p, ShadePix& q) {
+  const v3 n = {A.normals[3 * p], A.normals[3 * p + 1], A.normals[3 * p + 2]};
+  const v3 v = {A.view_dirs[3 * p], A.view_dirs[3 * p + 1], A.view_dirs[3 * p + 2]};
+  q.a = {A.albedo[3 * p], A.albedo[3 * p + 1], A.albedo[3 * p + 2]};
+  q.r = A.roughness[p];
+  const float ndv = n.x * v.x + n.y * v.y + n.z * v.z;
+  const float c2 = 2.0f * fmaxf(ndv, 0.0f);
+  const v3 ref = {c2 * n.x - v.x, c2 * n.y - v.y, c2 * n.z - v.z};
+  const v3 nt = {-n.y, n.z, -n.x}, vt = {-v.y, v.z, -v.x}, rt = {-ref.y, ref.z, -ref.x};
+  q.has_d = cube_taps(A.diffuse_res, nt.x, nt.y, nt.z, q.td);
+  q.dl_raw = q.has_d ? cube_sample(A.diffuse, q.td) : v3{0, 0, 0};
+  q.occ = A.occlusion ? A.occlusion[p] : 1.0f;
+  q.dl = A.occlusion ? q.dl_raw * q.occ : q.dl_raw;
+  q.drgb = {q.dl.x * q.a.x, q.dl.y * q.a.y, q.dl.z * q.a.z};
+  const float nov = fminf(fmaxf(nt.x * vt.x + nt.y * vt.y + nt.z * vt.z, 1e-4f), 1.0f);
+  {
+    const float fu = nov * (float)A.lut_w - 0.5f, fv = q.r * (float)A.lut_h - 0.5f;
+    const float flu = floorf(fu), flv = floorf(fv);
+    const float tu = fu - flu, tv = fv - flv;
+    const int x0 = min(A.lut_w - 1, max(0, (int)flu)), x1 = min(A.lut_w - 1, max(0, (int)flu + 1));
+    const int y0 = min(A.lut_h - 1, max(0, (int)flv)), y1 = min(A.lut_h - 1, max(0, (int)flv + 1));
+    const float2 t00 = reinterpret_cast<const float2*>(A.lut)[(size_t)y0 * A.lut_w + x0];
+    const float2 t10 = reinterpret_cast<const float2*>(A.lut)[(size_t)y0 * A.lut_w + x1];
+    const float2 t01 = reinterpret_cast<const float2*>(A.lut)[(size_t)y1 * A.lut_w + x0];
+    const float2 t11 = reinterpret_cast<const float2*>(A.lut)[(size_t)y1 * A.lut_w + x1];
+    const float w00 = (1 - tu) * (1 - tv), w10 = tu * (1 - tv), w01 = (1 - tu) * tv, w11 = tu * tv;
+    q.fgx = t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11;
+    q.fgy = t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11;
+    // d/dv of the bilinear blend (taps fixed), times dv/d(roughness) = lut_h
+    q.dfgx_dv = ((t01.x - t00.x) * (1 - tu) + (t11.x - t10.x) * tu) * (float)A.lut_h;
+    q.dfgy_dv = ((t01.y - t00.y) * (1 - tu) + (t11.y - t10.y) * tu) * (float)A.lut_h;
+  }
+  const float lvl_raw = get_mip(q.r, A.L, q.dmdr);
+  const float lvl = fminf(fmaxf(lvl_raw, 0.0f), (float)(A.L - 1));
+  q.lvl_inside = lvl_raw >= 0.0f && lvl_raw <= (float)(A.L - 1);
+  q.l0 = min((int)floorf(lvl), A.L - 1);
+  q.l1 = min(q.l0 + 1, A.L - 1);
+  q.lf = lvl - (float)q.l0;
+  q.has0 = cube_taps(A.spec_res[q.l0], rt.x, rt.y, rt.z, q.t0);
+  q.s0 = q.has0 ? cube_sample(A.spec[q.l0], q.t0) : v3{0, 0, 0};
+  q.has1 = false;
+  q.s1 = {0, 0, 0};
+  if (q.l1 != q.l0) {
+    q.has1 = cube_taps(A.spec_res[q.l1], rt.x, rt.y, rt.z, q.t1);
+    if (q.has1) q.s1 = cube_sample(A.spec[q.l1], q.t1);
+    q.sp = {q.s0.x * (1 - q.lf) + q.s1.x * q.lf, q.s0.y * (1 - q.lf) + q.s1.y * q.lf, q.s0.z * (1 - q.lf) + q.s1.z * q.lf};
+  } else {
+    q.sp = q.s0;
+  }
+  if (A.metallic) {
+    q.m = A.metallic[p];
+    q.F0 = {(1.0f - q.m) * 0.04f + q.a.x * q.m, (1.0f - q.m) * 0.04f + q.a.y * q.m, (1.0f - q.m) * 0.04f + q.a.z * q.m};
+  } else {
+    q.m = 0.0f;
+    q.F0 = {0.04f, 0.04f, 0.04f};
+  }
+  q.refl = {q.F0.x * q.fgx + q.fgy, q.F0.y * q.fgx + q.fgy, q.F0.z * q.fgx + q.fgy};
+  q.srgb = {q.sp.x * q.refl.x, q.sp.y * q.refl.y, q.sp.z * q.refl.z};
+}
+
+__global__ void __launch_bounds__(256)
+shade_fwd_kernel(ShadeArgs A) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= A.H * A.W) return;
+  ShadePix q;
+  shade_pixel(A, p, q);
+  float rr[3] = {q.drgb.x + q.srgb.x, q.drgb.y + q.srgb.y, q.drgb.z + q.srgb.z};
+  float dd;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float x = rr[c];
+    if (A.tone) x = aces(x, dd);
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    if (A.gamma) x = lin2srgb(x, dd);
+    rr[c] = x;
+  }
+  v3 drgb = q.drgb, srgb = q.srgb;
+  if (A.gamma) {
+    drgb = {lin2srgb(drgb.x, dd), lin2srgb(drgb.y, dd), lin2srgb(drgb.z, dd)};
+    srgb = {lin2srgb(srgb.x, dd), lin2srgb(srgb.y, dd), lin2srgb(srgb.z, dd)};
+  }
+  const bool mk = A.mask[p] != 0;
+#pragma unroll
+  for (int c = 0; c < 3; c++) A.render_rgb[3 * p + c] = mk ? rr[c] : (A.background ? A.background[3 * p + c] : 0.0f);
+  A.diffuse_rgb[3 * p] = drgb.x; A.diffuse_rgb[3 * p + 1] = drgb.y; A.diffuse_rgb[3 * p + 2] = drgb.z;
+  A.specular_rgb[3 * p] = srgb.x; A.specular_rgb[3 * p + 1] = srgb.y; A.specular_rgb[3 * p + 2] = srgb.z;
+  A.diffuse_light[3 * p] = q.dl.x; A.diffuse_light[3 * p + 1] = q.dl.y; A.diffuse_light[3 * p + 2] = q.dl.z;
+}
+
+constexpr int kMaxDiffuseLds = 6 * 16 * 16 * 3;  // diffuse cube gradients staged in LDS up to 16x16
+
+// Scatter-add of one RGB triple per lane into a texture gradient, with neighbouring lanes that
+// hit the SAME texel summed first: neighbouring pixels usually share bilinear taps, and 64
+// same-address float atomics serialise.  Runs of equal keys inside each 16-lane DPP row are
+// reduced with a segmented scan (row_shr 1/2/4/8, in registers); only the last lane of a run
+// issues the three atomics.  Must be called by all 64 lanes (key < 0 = nothing to add).
+template <int kCtrl>
+__device__ __forceinline__ float row_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xf, 0xf, false));
+}
+template <int kCtrl>
+__device__ __forceinline__ int row_i(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, kCtrl, 0xf, 0xf, false);
+}
+template <bool kLds>
+__device__ __forceinline__ void run_add3(float* target, int key, float v0, float v1, float v2) {
+  const int head = (row_i<0x111>(~key, key) != key) ? 1 : 0;  // row_shr:1; lane 0 of a row is a head
+  int f = head;
+#define GIGS_SEG_STEP(CTRL)                                            \
+  {                                                                    \
+    const float u0 = row_f<CTRL>(v0), u1 = row_f<CTRL>(v1), u2 = row_f<CTRL>(v2); \
+    const int fu = row_i<CTRL>(1, f);                                  \
+    if (!f) { v0 += u0; v1 += u1; v2 += u2; }                          \
+    f |= fu;                                                           \
+  }
+  GIGS_SEG_STEP(0x111) GIGS_SEG_STEP(0x112) GIGS_SEG_STEP(0x114) GIGS_SEG_STEP(0x118)
+#undef GIGS_SEG_STEP
+  const int tail = row_i<0x101>(1, head);  // row_shl:1 -> head flag of the next lane; 1 at the row end
+  if (key >= 0 && tail && target) {
+    if (v0 != 0.0f) atomicAdd(target, v0);
+    if (v1 != 0.0f) atomicAdd(target + 1, v1);
+    if (v2 != 0.0f) atomicAdd(target + 2, v2);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+shade_bwd_kernel(ShadeArgs A) {
+  __shared__ float s_dd[kMaxDiffuseLds];
+  const int n_dd = 6 * A.diffuse_res * A.diffuse_res * 3;
+  const bool use_lds = n_dd <= kMaxDiffuseLds;
+  if (use_lds)
+    for (int i = threadIdx.x; i < n_dd; i += 256) s_dd[i] = 0.0f;
+  __syncthreads();
+  const int pg = blockIdx.x * 256 + threadIdx.x;
+  const bool live = pg < A.H * A.W;
+  const int p = live ? pg : 0;  // dead lanes shade pixel 0 and add nothing: the DPP scans need every lane
+  ShadePix q;
+  shade_pixel(A, p, q);
+  float g_dl[3] = {0, 0, 0}, g_sp[3] = {0, 0, 0};
+  if (live) {
+    const bool mk = A.mask[p] != 0;
+    float g_d[3] = {0, 0, 0}, g_s[3] = {0, 0, 0};  // grads w.r.t. linear diffuse_rgb / specular_rgb
+    const float pre_d[3] = {q.drgb.x, q.drgb.y, q.drgb.z}, pre_s[3] = {q.srgb.x, q.srgb.y, q.srgb.z};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      // render = where(mask, gamma(clamp(tone(d + s))), bg)
+      float g = (A.g_render && mk) ? A.g_render[3 * p + c] : 0.0f;
+      if (g != 0.0f) {
+        float x = pre_d[c] + pre_s[c], d_tone = 1.0f, d_gam = 1.0f;
+        if (A.tone) x = aces(x, d_tone);
+        const float xc = fminf(fmaxf(x, 0.0f), 1.0f);
+        const float d_clamp = (x >= 0.0f && x <= 1.0f) ? 1.0f : 0.0f;
+        if (A.gamma) lin2srgb(xc, d_gam);
+        g = g * d_gam * d_clamp * d_tone;
+      }
+      float gd = A.g_diffuse_rgb ? A.g_diffuse_rgb[3 * p + c] : 0.0f;
+      float gs = A.g_specular_rgb ? A.g_specular_rgb[3 * p + c] : 0.0f;
+      if (A.gamma) {
+        float d1, d2;
+        lin2srgb(pre_d[c], d1);
+        lin2srgb(pre_s[c], d2);
+        gd *= d1;
+        gs *= d2;
+      }
+      g_d[c] = g + gd;
+      g_s[c] = g + gs;
+    }
+    const float av[3] = {q.a.x, q.a.y, q.a.z}, dlv[3] = {q.dl.x, q.dl.y, q.dl.z};
+    const float spv[3] = {q.sp.x, q.sp.y, q.sp.z}, F0v[3] = {q.F0.x, q.F0.y, q.F0.z};
+    const float reflv[3] = {q.refl.x, q.refl.y, q.refl.z};
+    const float s0v[3] = {q.s0.x, q.s0.y, q.s0.z}, s1v[3] = {q.s1.x, q.s1.y, q.s1.z};
+    float d_alb[3], d_m = 0.0f, d_fgx = 0.0f, d_fgy = 0.0f, d_lvl = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      d_alb[c] = g_d[c] * dlv[c];
+      g_dl[c] = g_d[c] * av[c] + (A.g_diffuse_light ? A.g_diffuse_light[3 * p + c] : 0.0f);
+      g_sp[c] = g_s[c] * reflv[c];
+      const float g_refl = g_s[c] * spv[c];
+      const float dF0 = g_refl * q.fgx;
+      d_fgx += g_refl * F0v[c];
+      d_fgy += g_refl;
+      if (A.metallic) {
+        d_m += dF0 * (av[c] - 0.04f);
+        d_alb[c] += dF0 * q.m;
+      }
+      if (q.l1 != q.l0) d_lvl += g_sp[c] * (s1v[c] - s0v[c]);
+    }
+    A.d_albedo[3 * p] = d_alb[0]; A.d_albedo[3 * p + 1] = d_alb[1]; A.d_albedo[3 * p + 2] = d_alb[2];
+    if (A.d_metallic) A.d_metallic[p] = d_m;
+    A.d_roughness[p] = d_fgx * q.dfgx_dv + d_fgy * q.dfgy_dv + (q.lvl_inside ? d_lvl * q.dmdr : 0.0f);
+  }
+  // ---- light textures (wave-uniform control flow from here on) ----
+  if (A.d_diffuse) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = (live && q.has_d) ? q.td.idx[k] : -1;
+      const float w = idx >= 0 ? q.td.w[k] * q.occ : 0.0f;
+      if (use_lds) run_add3<true>(s_dd + 3 * max(idx, 0), idx, g_dl[0] * w, g_dl[1] * w, g_dl[2] * w);
+      else run_add3<false>(A.d_diffuse + 3 * (size_t)max(idx, 0), idx, g_dl[0] * w, g_dl[1] * w, g_dl[2] * w);
+    }
+  }
+  {
+    const float wl = (q.l1 != q.l0) ? (1 - q.lf) : 1.0f;
+    float* t0 = A.d_spec[q.l0];
+    float* t1 = A.d_spec[q.l1];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = (live && q.has0 && t0) ? q.t0.idx[k] : -1;
+      const float w = idx >= 0 ? q.t0.w[k] * wl : 0.0f;
+      run_add3<false>(t0 ? t0 + 3 * (size_t)max(idx, 0) : nullptr, idx >= 0 ? (q.l0 << 24) | idx : -1, g_sp[0] * w, g_sp[1] * w, g_sp[2] * w);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = (live && q.l1 != q.l0 && q.has1 && t1) ? q.t1.idx[k] : -1;
+      const float w = idx >= 0 ? q.t1.w[k] * q.lf : 0.0f;
+      run_add3<false>(t1 ? t1 + 3 * (size_t)max(idx, 0) : nullptr, idx >= 0 ? (q.l1 << 24) | idx : -1, g_sp[0] * w, g_sp[1] * w, g_sp[2] * w);
+    }
+  }
+  if (use_lds && A.d_diffuse) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_dd; i += 256) {
+      const float val = s_dd[i];
+      if (val != 0.0f) atomicAdd(A.d_diffuse + i, val);
+    }
+  }
+}
+
+}  // namespace gigs
+
+// ------------------------------------------------------------------------------------------
+// C ABI (declared in include/gigs_hip.h)
+// ------------------------------------------------------------------------------------------
+#include "../../include/gigs_hip.h"
+
+extern "C" {
+
+int gigs_internal_fail(int code, const char* msg);  // api.hip
+void gigs_internal_stage_begin(int stage, void* stream, void** token);
+void gigs_internal_stage_end(void* token);
+
+#define PBR_CHECK_LAUNCH()                                        \
+  do {                                                            \
+    if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "pbr kernel launch failed"); \
+  } while (0)
+
+int gigs_diffuse_cubemap_fwd(int res, const float* cubemap, float* out, void* stream) {
+  if (res <= 0 || !cubemap || !out) return gigs_internal_fail(GIGS_ERR_INVALID, "diffuse_cubemap_fwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float4* table = gigs::texel_table(res, s);
+  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
+  void* tok; gigs_internal_stage_begin(16, stream, &tok);
+  hipLaunchKernelGGL(gigs::diffuse_cubemap_kernel<false>, dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, cubemap, out);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_diffuse_cubemap_bwd(int res, const float* grad_out, float* grad_cubemap, void* stream) {
+  if (res <= 0 || !grad_out || !grad_cubemap) return gigs_internal_fail(GIGS_ERR_INVALID, "diffuse_cubemap_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float4* table = gigs::texel_table(res, s);
+  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
+  void* tok; gigs_internal_stage_begin(17, stream, &tok);
+  hipLaunchKernelGGL(gigs::diffuse_cubemap_kernel<true>, dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, grad_out, grad_cubemap);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_specular_bounds(int res, float costheta_cutoff, float* bounds, void* stream) {
+  if (res <= 0 || !bounds) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_bounds: bad argument");
+  hipLaunchKernelGGL(gigs::specular_bounds_kernel, dim3((6 * res * res + 63) / 64), dim3(64), 0, (hipStream_t)stream, res, costheta_cutoff, bounds);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_specular_cubemap_fwd(int res, const float* cubemap, const float* bounds, float roughness,
+                              float costheta_cutoff, float* out, void* stream) {
+  if (res <= 0 || !cubemap || !bounds || !out) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_fwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float4* table = gigs::texel_table(res, s);
+  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
+  void* tok; gigs_internal_stage_begin(16, stream, &tok);
+  hipLaunchKernelGGL(gigs::specular_cubemap_kernel<false>, dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, cubemap, bounds, roughness, costheta_cutoff, out);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_specular_cubemap_bwd(int res, const float* bounds, const float* grad_out, float roughness,
+                              float costheta_cutoff, float* grad_cubemap, void* stream) {
+  if (res <= 0 || !bounds || !grad_out || !grad_cubemap) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float4* table = gigs::texel_table(res, s);
+  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
+  void* tok; gigs_internal_stage_begin(17, stream, &tok);
+  hipLaunchKernelGGL(gigs::specular_cubemap_kernel<true>, dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, grad_out, bounds, roughness, costheta_cutoff, grad_cubemap);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_cubemap_mip_fwd(int res_out, int channels, const float* in, float* out, void* stream) {
+  if (res_out <= 0 || channels <= 0 || !in || !out) return gigs_internal_fail(GIGS_ERR_INVALID, "cubemap_mip_fwd: bad argument");
+  void* tok; gigs_internal_stage_begin(16, stream, &tok);
+  hipLaunchKernelGGL(gigs::cubemap_mip_fwd_kernel, dim3((6 * res_out * res_out * channels + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, channels, in, out);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_cubemap_mip_bwd(int res_out, const float* dout, float* din, void* stream) {
+  if (res_out <= 0 || !dout || !din) return gigs_internal_fail(GIGS_ERR_INVALID, "cubemap_mip_bwd: bad argument");
+  const int res = 2 * res_out;
+  void* tok; gigs_internal_stage_begin(17, stream, &tok);
+  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+static int fill_shade(gigs::ShadeArgs& A, int H, int W, const float* normals, const float* view_dirs,
+                      const float* albedo, const float* roughness, const uint8_t* mask,
+                      const float* occlusion, const float* metallic, const float* background,
+                      const float* diffuse, int diffuse_res, int n_levels, const float* const* spec,
+                      const int* spec_res, const float* lut, int lut_w, int lut_h, int tone, int gamma) {
+  if (H <= 0 || W <= 0 || !normals || !view_dirs || !albedo || !roughness || !mask || !diffuse || !spec || !spec_res || !lut)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "shade: null required input");
+  if (n_levels < 2 || n_levels > 8 || diffuse_res <= 0 || lut_w <= 0 || lut_h <= 0)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "shade: needs 2..8 specular levels and positive texture sizes");
+  memset(&A, 0, sizeof(A));
+  A.H = H; A.W = W; A.normals = normals; A.view_dirs = view_dirs; A.albedo = albedo; A.roughness = roughness;
+  A.mask = mask; A.occlusion = occlusion; A.metallic = metallic; A.background = background;
+  A.diffuse = diffuse; A.diffuse_res = diffuse_res; A.L = n_levels;
+  for (int i = 0; i < n_levels; i++) {
+    if (!spec[i] || spec_res[i] <= 0) return gigs_internal_fail(GIGS_ERR_INVALID, "shade: bad specular level");
+    A.spec[i] = spec[i];
+    A.spec_res[i] = spec_res[i];
+  }
+  A.lut = lut; A.lut_w = lut_w; A.lut_h = lut_h; A.tone = tone; A.gamma = gamma;
+  return 0;
+}
+
+int gigs_shade_fwd(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+                   const float* roughness, const uint8_t* mask, const float* occlusion,
+                   const float* metallic, const float* background, const float* diffuse, int diffuse_res,
+                   int n_levels, const float* const* spec, const int* spec_res, const float* lut,
+                   int lut_w, int lut_h, int tone, int gamma, float* render_rgb, float* diffuse_rgb,
+                   float* specular_rgb, float* diffuse_light, void* stream) {
+  gigs::ShadeArgs A;
+  const int rc = fill_shade(A, H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, background,
+                            diffuse, diffuse_res, n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma);
+  if (rc) return rc;
+  if (!render_rgb || !diffuse_rgb || !specular_rgb || !diffuse_light) return gigs_internal_fail(GIGS_ERR_INVALID, "shade_fwd: null output");
+  A.render_rgb = render_rgb; A.diffuse_rgb = diffuse_rgb; A.specular_rgb = specular_rgb; A.diffuse_light = diffuse_light;
+  void* tok; gigs_internal_stage_begin(14, stream, &tok);
+  hipLaunchKernelGGL(gigs::shade_fwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, A);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_shade_bwd(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+                   const float* roughness, const uint8_t* mask, const float* occlusion,
+                   const float* metallic, const float* diffuse, int diffuse_res, int n_levels,
+                   const float* const* spec, const int* spec_res, const float* lut, int lut_w, int lut_h,
+                   int tone, int gamma, const float* g_render, const float* g_diffuse_rgb,
+                   const float* g_specular_rgb, const float* g_diffuse_light, float* d_albedo,
+                   float* d_roughness, float* d_metallic, float* d_diffuse, float* const* d_spec,
+                   void* stream) {
+  gigs::ShadeArgs A;
+  const int rc = fill_shade(A, H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, nullptr,
+                            diffuse, diffuse_res, n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma);
+  if (rc) return rc;
+  if (!d_albedo || !d_roughness) return gigs_internal_fail(GIGS_ERR_INVALID, "shade_bwd: null output");
+  A.g_render = g_render; A.g_diffuse_rgb = g_diffuse_rgb; A.g_specular_rgb = g_specular_rgb; A.g_diffuse_light = g_diffuse_light;
+  A.d_albedo = d_albedo; A.d_roughness = d_roughness; A.d_metallic = d_metallic; A.d_diffuse = d_diffuse;
+  for (int i = 0; i < n_levels; i++) A.d_spec[i] = d_spec ? d_spec[i] : nullptr;
+  void* tok; gigs_internal_stage_begin(15, stream, &tok);
+  hipLaunchKernelGGL(gigs::shade_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, A);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

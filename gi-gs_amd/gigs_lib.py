@@ -49,9 +49,22 @@ SIGNATURES = {
     "gigs_median3x3": (_i, [_i, _i, _i, _f, _f, C.c_void_p]),
     "gigs_median3x3_backward": (_i, [_i, _i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_bilateral3x3": (_i, [_i, _i, _i, _fl, _fl, _fl, _f, _f, C.c_void_p]),
+    "gigs_diffuse_cubemap_fwd": (_i, [_i, _f, _f, C.c_void_p]),
+    "gigs_diffuse_cubemap_bwd": (_i, [_i, _f, _f, C.c_void_p]),
+    "gigs_specular_bounds": (_i, [_i, _fl, _f, C.c_void_p]),
+    "gigs_specular_cubemap_fwd": (_i, [_i, _f, _f, _fl, _fl, _f, C.c_void_p]),
+    "gigs_specular_cubemap_bwd": (_i, [_i, _f, _f, _fl, _fl, _f, C.c_void_p]),
+    "gigs_cubemap_mip_fwd": (_i, [_i, _i, _f, _f, C.c_void_p]),
+    "gigs_cubemap_mip_bwd": (_i, [_i, _f, _f, C.c_void_p]),
+    "gigs_shade_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
+                            C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_shade_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
+                            C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
+                            C.POINTER(C.c_void_p), C.c_void_p]),
     "gigs_geom_offset": (C.c_longlong, [_i, _i]),
     "gigs_binning_offset": (C.c_longlong, [_i, _i]),
     "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),
+    "gigs_selftest_div2": (_i, [_i, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_profile_begin": (None, []),
     "gigs_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
     "gigs_profile_stage_name": (C.c_char_p, [_i]),

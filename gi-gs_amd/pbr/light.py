@@ -1,0 +1,96 @@
+"""CubemapLight with the reference's interface (pbr/light.py:84-207); mip chain and GGX
+pre-filter run in libgigs_hip.so.  Image I/O (cv2) parts of the reference class are out of scope."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+import gigs_lib
+
+from .renderutils import diffuse_cubemap, specular_cubemap
+
+_lib = gigs_lib.lib()
+
+
+def cube_to_dir(s: int, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:  # pbr/light.py:38-51
+    if s == 0:
+        rx, ry, rz = torch.ones_like(x), -y, -x
+    elif s == 1:
+        rx, ry, rz = -torch.ones_like(x), -y, x
+    elif s == 2:
+        rx, ry, rz = x, torch.ones_like(x), y
+    elif s == 3:
+        rx, ry, rz = x, -torch.ones_like(x), -y
+    elif s == 4:
+        rx, ry, rz = x, -y, torch.ones_like(x)
+    elif s == 5:
+        rx, ry, rz = -x, -y, -torch.ones_like(x)
+    return torch.stack((rx, ry, rz), dim=-1)
+
+
+class cubemap_mip(torch.autograd.Function):
+    """pbr/light.py:54-79: forward = 2x2 average pool, backward = bilinear cube lookup of 0.25*dout."""
+
+    @staticmethod
+    def forward(ctx, cubemap: torch.Tensor) -> torch.Tensor:
+        if not cubemap.is_cuda:
+            raise RuntimeError("cubemap must be a CUDA/HIP tensor: pbr (gigs-hip) has no CPU path")
+        c = cubemap.contiguous().float()
+        r, C = c.shape[1] // 2, c.shape[3]
+        out = torch.empty((6, r, r, C), dtype=torch.float32, device=c.device)
+        with torch.cuda.device(c.device):
+            gigs_lib.check(_lib.gigs_cubemap_mip_fwd(r, C, c.data_ptr(), out.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), "cubemap_mip_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor) -> torch.Tensor:
+        d = dout.contiguous().float()
+        r = d.shape[1]
+        assert d.shape[3] == 3
+        out = torch.empty((6, 2 * r, 2 * r, 3), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            gigs_lib.check(_lib.gigs_cubemap_mip_bwd(r, d.data_ptr(), out.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), "cubemap_mip_bwd")
+        return out
+
+
+class CubemapLight(nn.Module):
+    LIGHT_MIN_RES = 16
+    MIN_ROUGHNESS = 0.08
+    MAX_ROUGHNESS = 0.5
+
+    def __init__(self, base_res: int = 16, scale: float = 0.5, bias: float = 0.25, path=None, device="cuda") -> None:
+        super().__init__()
+        self.mtx = None
+        self.path = path
+        base = torch.rand(6, base_res, base_res, 3, dtype=torch.float32, device=device) * scale + bias
+        self.base = nn.Parameter(base)
+        self.register_parameter("env_base", self.base)
+
+    def xfm(self, mtx) -> None:
+        self.mtx = mtx
+
+    def clamp_(self, min: Optional[float] = None, max: Optional[float] = None) -> None:
+        self.base.clamp_(min, max)
+
+    def get_mip(self, roughness: torch.Tensor) -> torch.Tensor:
+        return torch.where(
+            roughness < self.MAX_ROUGHNESS,
+            (torch.clamp(roughness, self.MIN_ROUGHNESS, self.MAX_ROUGHNESS) - self.MIN_ROUGHNESS)
+            / (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) * (len(self.specular) - 2),
+            (torch.clamp(roughness, self.MAX_ROUGHNESS, 1.0) - self.MAX_ROUGHNESS) / (1.0 - self.MAX_ROUGHNESS)
+            + len(self.specular) - 2,
+        )
+
+    def build_mips(self, cutoff: float = 0.99) -> None:
+        self.specular = [self.base]
+        while self.specular[-1].shape[1] > self.LIGHT_MIN_RES:
+            self.specular += [cubemap_mip.apply(self.specular[-1])]
+        self.diffuse = diffuse_cubemap(self.specular[-1])
+        for idx in range(len(self.specular) - 1):
+            roughness = (idx / (len(self.specular) - 2)) * (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) + self.MIN_ROUGHNESS
+            self.specular[idx] = specular_cubemap(self.specular[idx], roughness, cutoff)
+        self.specular[-1] = specular_cubemap(self.specular[-1], 1.0, cutoff)

@@ -1,0 +1,119 @@
+"""diffuse_cubemap / specular_cubemap with the reference's signatures (pbr/renderutils/ops.py:404-458),
+backed by the HIP kernels of libgigs_hip.so instead of the JIT-compiled CUDA plugin."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import gigs_lib
+
+_lib = gigs_lib.lib()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gpu(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor: pbr.renderutils (gigs-hip) has no CPU path")
+    return t.contiguous().float()
+
+
+class _diffuse_cubemap_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cubemap):
+        c = _gpu(cubemap, "cubemap")
+        out = torch.empty_like(c)
+        with torch.cuda.device(c.device):
+            gigs_lib.check(_lib.gigs_diffuse_cubemap_fwd(c.shape[1], c.data_ptr(), out.data_ptr(), _stream()),
+                           "diffuse_cubemap_fwd")
+        ctx.res = c.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d = _gpu(dout, "dout")
+        g = torch.empty_like(d)
+        with torch.cuda.device(d.device):
+            gigs_lib.check(_lib.gigs_diffuse_cubemap_bwd(ctx.res, d.data_ptr(), g.data_ptr(), _stream()),
+                           "diffuse_cubemap_bwd")
+        return g
+
+
+def diffuse_cubemap(cubemap, use_python=False):
+    if use_python:
+        assert False
+    assert cubemap.shape[0] == 6 and cubemap.shape[1] == cubemap.shape[2] and cubemap.shape[3] == 3
+    out = _diffuse_cubemap_func.apply(cubemap)
+    if torch.is_anomaly_enabled():
+        assert not torch.isnan(out).any(), "Output of diffuse_cubemap contains inf or NaN"
+    return out
+
+
+class _specular_cubemap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cubemap, roughness, costheta_cutoff, bounds):
+        c = _gpu(cubemap, "cubemap")
+        res = c.shape[1]
+        out = torch.empty((6, res, res, 4), dtype=torch.float32, device=c.device)
+        with torch.cuda.device(c.device):
+            gigs_lib.check(_lib.gigs_specular_cubemap_fwd(res, c.data_ptr(), bounds.data_ptr(), float(roughness),
+                                                          float(costheta_cutoff), out.data_ptr(), _stream()),
+                           "specular_cubemap_fwd")
+        ctx.save_for_backward(bounds)
+        ctx.res, ctx.roughness, ctx.theta_cutoff = res, roughness, costheta_cutoff
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (bounds,) = ctx.saved_tensors
+        d = _gpu(dout, "dout")
+        g = torch.empty((6, ctx.res, ctx.res, 3), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            gigs_lib.check(_lib.gigs_specular_cubemap_bwd(ctx.res, bounds.data_ptr(), d.data_ptr(), float(ctx.roughness),
+                                                          float(ctx.theta_cutoff), g.data_ptr(), _stream()),
+                           "specular_cubemap_bwd")
+        return g, None, None, None
+
+
+def _ndf_cutoff(roughness: float, cutoff: float) -> float:
+    """Cosine of the GGX cone that keeps `cutoff` of the energy (ops.py:428-440, host numpy)."""
+    def ndfGGX(alphaSqr, costheta):
+        costheta = np.clip(costheta, 0.0, 1.0)
+        d = (costheta * alphaSqr - costheta) * costheta + 1.0
+        return alphaSqr / (d * d * np.pi)
+
+    nSamples = 1000000
+    costheta = np.cos(np.linspace(0, np.pi / 2.0, nSamples))
+    D = np.cumsum(ndfGGX(roughness ** 4, costheta))
+    idx = np.argmax(D >= D[..., -1] * cutoff)
+    return float(costheta[idx])
+
+
+_ndfBoundsDict = {}
+
+
+def _ndf_bounds(res, roughness, cutoff, device):
+    key = (res, roughness, cutoff, str(device))
+    if key not in _ndfBoundsDict:
+        cos_cut = _ndf_cutoff(roughness, cutoff)
+        bounds = torch.zeros((6, res, res, 24), dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            gigs_lib.check(_lib.gigs_specular_bounds(res, cos_cut, bounds.data_ptr(), _stream()), "specular_bounds")
+        _ndfBoundsDict[key] = (cos_cut, bounds)
+    return _ndfBoundsDict[key]
+
+
+def specular_cubemap(cubemap, roughness, cutoff=0.99, use_python=False):
+    assert cubemap.shape[0] == 6 and cubemap.shape[1] == cubemap.shape[2], \
+        "Bad shape for cubemap tensor: %s" % str(cubemap.shape)
+    if use_python:
+        assert False
+    if not cubemap.is_cuda:
+        raise RuntimeError("cubemap must be a CUDA/HIP tensor: pbr.renderutils (gigs-hip) has no CPU path")
+    cos_cut, bounds = _ndf_bounds(cubemap.shape[1], roughness, cutoff, cubemap.device)
+    out = _specular_cubemap.apply(cubemap, roughness, cos_cut, bounds)
+    if torch.is_anomaly_enabled():
+        assert not torch.isnan(out).any(), "Output of specular_cubemap contains inf or NaN"
+    return out[..., 0:3] / out[..., 3:]

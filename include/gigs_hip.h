@@ -119,6 +119,56 @@ int gigs_median3x3_backward(int channels, int height, int width, const float* in
 int gigs_bilateral3x3(int channels, int height, int width, float sigma_color, float sigma_x,
                       float sigma_y, const float* in, float* out, void* stream);
 
+/* ---- deferred shade and cubemap light (pbr/shade.py, pbr/light.py, pbr/renderutils) ----------
+ * Cubemaps are [6, res, res, 3] fp32 (NHWC as in the reference); HWC image tensors as passed to
+ * pbr_shading.  Sampling rule of the texture lookups (the reference uses nvdiffrast dr.texture,
+ * third party, parity unpinned): cube face/(u,v) selection by the dominant axis with the face
+ * orientations of pbr/light.py:40-52; bilinear taps at (uv * size - 0.5); a tap that leaves a face
+ * is taken from the neighbouring face, the single missing tap at a cube corner is dropped and the
+ * weights renormalised; 2-D lookups clamp tap indices; the mip blend uses
+ * level = clamp(mip_level_bias, 0, L-1) between floor(level) and floor(level)+1. */
+
+/* diffuse_cubemap_fwd / _bwd (pbr/renderutils/c_src/torch_bindings.cpp:740-795 -> cubemap.cu:110-169).
+ * The backward is a gather over the same weights; grad_cubemap is fully overwritten. */
+int gigs_diffuse_cubemap_fwd(int res, const float* cubemap, float* out, void* stream);
+int gigs_diffuse_cubemap_bwd(int res, const float* grad_out, float* grad_cubemap, void* stream);
+/* specular_bounds (torch_bindings.cpp:797-822 -> cubemap.cu:181-244): bounds = [6,res,res,24]. */
+int gigs_specular_bounds(int res, float costheta_cutoff, float* bounds, void* stream);
+/* specular_cubemap_fwd / _bwd (torch_bindings.cpp:824-890 -> cubemap.cu:246-350).  out and grad_out
+ * are [6,res,res,4] (rgb, weight sum); grad_cubemap [6,res,res,3] is fully overwritten. */
+int gigs_specular_cubemap_fwd(int res, const float* cubemap, const float* bounds, float roughness,
+                              float costheta_cutoff, float* out, void* stream);
+int gigs_specular_cubemap_bwd(int res, const float* bounds, const float* grad_out, float roughness,
+                              float costheta_cutoff, float* grad_cubemap, void* stream);
+/* cubemap_mip (pbr/light.py:54-79): forward 2x2 average pool [6,2r,2r,C] -> [6,r,r,C]; backward =
+ * bilinear cube lookup of 0.25*dout at every fine texel direction, dout [6,r,r,3] -> din [6,2r,2r,3]. */
+int gigs_cubemap_mip_fwd(int res_out, int channels, const float* in, float* out, void* stream);
+int gigs_cubemap_mip_bwd(int res_out, const float* dout, float* din, void* stream);
+
+/* pbr_shading (pbr/shade.py:108-241) fused into one kernel.  normals/view_dirs/albedo [H,W,3],
+ * roughness/occlusion/metallic [H,W,1] (occlusion, metallic, background may be NULL), mask = bool
+ * [H,W,1]; diffuse = light.diffuse [6,dres,dres,3]; spec = HOST array of n_levels device pointers
+ * (light.specular), spec_res their resolutions (host); lut = BRDF LUT [lut_h, lut_w, 2].
+ * Outputs [H,W,3]: render_rgb, diffuse_rgb, specular_rgb, diffuse_light (the result dict). */
+int gigs_shade_fwd(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+                   const float* roughness, const uint8_t* mask, const float* occlusion,
+                   const float* metallic, const float* background, const float* diffuse, int diffuse_res,
+                   int n_levels, const float* const* spec, const int* spec_res, const float* lut,
+                   int lut_w, int lut_h, int tone, int gamma, float* render_rgb, float* diffuse_rgb,
+                   float* specular_rgb, float* diffuse_light, void* stream);
+/* Backward of the above.  g_* are gradients w.r.t. the four outputs (any may be NULL = zero).
+ * d_albedo [H,W,3], d_roughness [H,W,1], d_metallic [H,W,1] (NULL when metallic is NULL) are
+ * overwritten; d_diffuse and d_spec[i] (host array of device pointers, entries may be NULL) are
+ * ACCUMULATED with float atomics and must be zero-initialised by the caller. */
+int gigs_shade_bwd(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+                   const float* roughness, const uint8_t* mask, const float* occlusion,
+                   const float* metallic, const float* diffuse, int diffuse_res, int n_levels,
+                   const float* const* spec, const int* spec_res, const float* lut, int lut_w, int lut_h,
+                   int tone, int gamma, const float* g_render, const float* g_diffuse_rgb,
+                   const float* g_specular_rgb, const float* g_diffuse_light, float* d_albedo,
+                   float* d_roughness, float* d_metallic, float* d_diffuse, float* const* d_spec,
+                   void* stream);
+
 /* Test/diagnostic views into the opaque scratch buffers (byte offsets from the buffer
  * start, or -1).  `which`: geometry 0 depths f32[P], 1 pos_view f32[3P], 2 means2D f32[2P],
  * 3 cov3D f32[6P], 4 conic_opacity f32[4P], 5 rgb f32[3P], 6 clamped u8[3P],
@@ -128,6 +178,12 @@ int gigs_bilateral3x3(int channels, int height, int width, float sigma_color, fl
 long long gigs_geom_offset(int P, int which);
 long long gigs_binning_offset(int num_rendered, int which);
 long long gigs_image_offset(int width, int height, int which);
+
+/* Self-test of two exact rewrites used by the SSAO/SSR march: out_fast[2i..] = the shared-reciprocal
+ * division (nx[i]/d[i], ny[i]/d[i]), out_ref = the same with the compiler's IEEE division;
+ * out_round[2i] = the add-and-truncate rounding of nx[i], out_round[2i+1] = (int)roundf(nx[i]). */
+int gigs_selftest_div2(int n, const float* nx, const float* ny, const float* d, float* out_fast,
+                       float* out_ref, int* out_round, void* stream);
 
 /* In-library stage timing for bench.py.  Between gigs_profile_begin() and gigs_profile_end()
  * every kernel stage launched by this library records a hipEvent pair on its own stream (no

@@ -237,3 +237,77 @@ def bilateral3x3(x, sigma_color=1.0, sigma_space=(3.0, 3.0)):
 
 def higher_msb(n: int) -> int:
     return int(lib().orc_higher_msb(C.c_uint32(n)))
+
+
+# ---- deferred shade / cubemap light (oracle/pbr_oracle.cpp) ------------------------------------
+def diffuse_cubemap_fwd(cubemap):
+    c = _c32(cubemap)
+    out = np.empty_like(c)
+    lib().orc_diffuse_cubemap_fwd(C.c_int(c.shape[1]), _f(c), _f(out))
+    return out
+
+
+def diffuse_cubemap_bwd(grad_out):
+    g = _c32(grad_out)
+    out = np.zeros_like(g)
+    lib().orc_diffuse_cubemap_bwd(C.c_int(g.shape[1]), _f(g), _f(out))
+    return out
+
+
+def specular_bounds(res, cos_cutoff):
+    b = np.zeros((6, res, res, 24), np.float32)
+    lib().orc_specular_bounds(C.c_int(res), C.c_float(cos_cutoff), _f(b))
+    return b
+
+
+def specular_cubemap_fwd(cubemap, bounds, roughness, cos_cutoff):
+    c, b = _c32(cubemap), _c32(bounds)
+    out = np.zeros((6, c.shape[1], c.shape[1], 4), np.float32)
+    lib().orc_specular_cubemap_fwd(C.c_int(c.shape[1]), _f(c), _f(b), C.c_float(roughness), C.c_float(cos_cutoff), _f(out))
+    return out
+
+
+def specular_cubemap_bwd(bounds, grad_out, roughness, cos_cutoff):
+    b, g = _c32(bounds), _c32(grad_out)
+    res = g.shape[1]
+    out = np.zeros((6, res, res, 3), np.float32)
+    lib().orc_specular_cubemap_bwd(C.c_int(res), _f(b), _f(g), C.c_float(roughness), C.c_float(cos_cutoff), _f(out))
+    return out
+
+
+def cubemap_mip_fwd(cubemap):
+    c = _c32(cubemap)
+    r, ch = c.shape[1] // 2, c.shape[3]
+    out = np.zeros((6, r, r, ch), np.float32)
+    lib().orc_cubemap_mip_fwd(C.c_int(r), C.c_int(ch), _f(c), _f(out))
+    return out
+
+
+def cubemap_mip_bwd(dout):
+    d = _c32(dout)
+    r = d.shape[1]
+    out = np.zeros((6, 2 * r, 2 * r, 3), np.float32)
+    lib().orc_cubemap_mip_bwd(C.c_int(r), _f(d), _f(out))
+    return out
+
+
+def shade_fwd(normals, view_dirs, albedo, roughness, mask, occlusion, metallic, background, diffuse, specular, lut,
+              tone=False, gamma=False):
+    """pbr_shading forward on HWC numpy arrays -> dict(render_rgb, diffuse_rgb, specular_rgb, diffuse_light)."""
+    H, W, _ = normals.shape
+    arrs = dict(normals=_c32(normals), view_dirs=_c32(view_dirs), albedo=_c32(albedo), roughness=_c32(roughness),
+                occlusion=None if occlusion is None else _c32(occlusion),
+                metallic=None if metallic is None else _c32(metallic),
+                background=None if background is None else _c32(background), diffuse=_c32(diffuse), lut=_c32(lut))
+    m8 = np.ascontiguousarray(mask, dtype=np.uint8)
+    spec = [_c32(s) for s in specular]
+    sp = (c_float_p * len(spec))(*[_f(s) for s in spec])
+    sr = (C.c_int * len(spec))(*[s.shape[1] for s in spec])
+    outs = [np.zeros((H, W, 3), np.float32) for _ in range(4)]
+    lut2 = arrs["lut"].reshape(-1, arrs["lut"].shape[-2], 2)
+    lib().orc_shade_fwd(C.c_int(H), C.c_int(W), _f(arrs["normals"]), _f(arrs["view_dirs"]), _f(arrs["albedo"]),
+                        _f(arrs["roughness"]), m8.ctypes.data_as(C.c_void_p), _f(arrs["occlusion"]), _f(arrs["metallic"]),
+                        _f(arrs["background"]), _f(arrs["diffuse"]), C.c_int(arrs["diffuse"].shape[1]), C.c_int(len(spec)),
+                        sp, sr, _f(arrs["lut"]), C.c_int(lut2.shape[1]), C.c_int(lut2.shape[0]), C.c_int(int(tone)),
+                        C.c_int(int(gamma)), *[_f(o) for o in outs])
+    return dict(render_rgb=outs[0], diffuse_rgb=outs[1], specular_rgb=outs[2], diffuse_light=outs[3])

@@ -415,3 +415,34 @@ def test_median_backward_routes_gradient(orc):
     (yr * g).sum().backward()
     torch.testing.assert_close(y.detach(), yr.detach())
     torch.testing.assert_close(x.grad, xr.grad)  # continuous random data: no ties
+
+
+def test_fast_div2_and_rounding_are_bit_exact():
+    """The SSAO/SSR march replaces two IEEE divisions by a shared-reciprocal FMA chain and roundf by
+    add-and-truncate; both must be bit-identical to the plain forms (gi.hip: div2_exact, round_to_int)."""
+    import gigs_lib
+    lib = gigs_lib.lib()
+    rng = np.random.default_rng(0)
+    n = 1 << 22
+    # projected coordinates / depths as the march sees them, plus wide-exponent and special values
+    nx = np.concatenate([rng.normal(0, 3, n // 2), np.ldexp(rng.normal(size=n // 4), rng.integers(-100, 100, n // 4)),
+                         rng.uniform(-2000, 2000, n // 4)]).astype(np.float32)
+    ny = np.roll(nx, 7) * np.float32(0.73)
+    d = np.concatenate([rng.uniform(0.2, 8, n // 2), np.ldexp(rng.normal(size=n // 4), rng.integers(-100, 100, n // 4)),
+                        rng.normal(0, 1e-3, n // 4)]).astype(np.float32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, 0.5, -0.5, 1.5, 2.5, 8388607.5, -8388607.5,
+                        2147483520.0, -2147483648.0, 4e9], np.float32)
+    nx[:special.size] = special
+    d[special.size:2 * special.size] = special
+    tnx, tny, td = tt(nx), tt(ny), tt(d)
+    of = torch.zeros(2 * n, device=DEV)
+    orf = torch.zeros(2 * n, device=DEV)
+    ornd = torch.zeros(2 * n, dtype=torch.int32, device=DEV)
+    assert lib.gigs_selftest_div2(n, tnx.data_ptr(), tny.data_ptr(), td.data_ptr(), of.data_ptr(), orf.data_ptr(),
+                                  ornd.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    a, b = of.cpu().numpy().view(np.uint32), orf.cpu().numpy().view(np.uint32)
+    both_nan = np.isnan(of.cpu().numpy()) & np.isnan(orf.cpu().numpy())
+    assert np.all((a == b) | both_nan), f"{int(((a != b) & ~both_nan).sum())} quotients differ"
+    r = ornd.cpu().numpy().reshape(-1, 2)
+    np.testing.assert_array_equal(r[:, 0], r[:, 1])
