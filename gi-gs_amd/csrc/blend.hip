@@ -217,6 +217,14 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   }
   const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
   const float bg_dot_dpixel = 0 + bg_color[0] * dp0 + bg_color[1] * dp1 + bg_color[2] * dp2;
+  // Which incoming gradient planes are non-zero anywhere in this tile?  A plane that is zero for
+  // all 256 pixels contributes exact zeros to every sum, so its reductions are skipped (stage-2
+  // training feeds only albedo / roughness / metallic gradients: SURVEY Appendix D).
+  //   geo: colour or opacity grads -> dL_dalpha -> mean2D, conic, opacity, colour (v[0..9])
+  const bool any_geo = __syncthreads_or((dp0 != 0.0f) | (dp1 != 0.0f) | (dp2 != 0.0f) | (dop != 0.0f)) != 0;
+  const bool any_nrm = __syncthreads_or((dn0 != 0.0f) | (dn1 != 0.0f) | (dn2 != 0.0f)) != 0;
+  const bool any_mat = __syncthreads_or((da0 != 0.0f) | (da1 != 0.0f) | (da2 != 0.0f) | (drg != 0.0f) | (dmt != 0.0f)) != 0;
+  const bool any_dep = __syncthreads_or(ddp != 0.0f) != 0;
 
   for (int i = 0; i < rounds; i++, toDo -= kBatch) {
     __syncthreads();
@@ -287,12 +295,34 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
         v[5] = -0.5f * gdy * dy * dL_dG;
         v[6] = G * dL_dalpha;
       }
+      float* acc = s_acc + j * GIGS_GREC;
+      if (any_geo) {
 #pragma unroll
-      for (int k = 0; k < 19; k++) v[k] = wave_sum_lane63(v[k]);
-      if (lane == 63) {
-        float* acc = s_acc + j * GIGS_GREC;
+        for (int k = 0; k < 10; k++) v[k] = wave_sum_lane63(v[k]);
+        if (lane == 63) {
 #pragma unroll
-        for (int k = 0; k < 19; k++) atomicAdd(acc + k, v[k]);
+          for (int k = 0; k < 10; k++) atomicAdd(acc + k, v[k]);
+        }
+      }
+      if (any_nrm) {
+#pragma unroll
+        for (int k = 10; k < 13; k++) v[k] = wave_sum_lane63(v[k]);
+        if (lane == 63) {
+#pragma unroll
+          for (int k = 10; k < 13; k++) atomicAdd(acc + k, v[k]);
+        }
+      }
+      if (any_mat) {
+#pragma unroll
+        for (int k = 13; k < 18; k++) v[k] = wave_sum_lane63(v[k]);
+        if (lane == 63) {
+#pragma unroll
+          for (int k = 13; k < 18; k++) atomicAdd(acc + k, v[k]);
+        }
+      }
+      if (any_dep) {
+        v[18] = wave_sum_lane63(v[18]);
+        if (lane == 63) atomicAdd(acc + 18, v[18]);
       }
     }
     __syncthreads();

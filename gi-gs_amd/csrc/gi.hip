@@ -174,10 +174,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // shared between the two numerators and the residual steps run as packed fp32 FMAs
 // (v_pk_fma_f32): 1 rcp + 2 FMA + 5 packed ops instead of 22 instructions.
 // (Checked bit-for-bit against `/` on the device: tests/test_gpu_parity.py::test_fast_div2.)
-__device__ __forceinline__ f32x2 div2_exact(f32x2 n, float d) {
-  const float big = fmaxf(fmaxf(fabsf(n.x), fabsf(n.y)), fabsf(d));
-  const float small = fminf(fminf(fabsf(n.x), fabsf(n.y)), fabsf(d));
-  if (big < 0x1p60f && small > 0x1p-60f) {
+// `mag_ok` = the caller guarantees |n.x|, |n.y|, |d| < 2^60 (no overflow / pre-scaling); the
+// denominator must also be away from zero.  A tiny or zero NUMERATOR is harmless here: the chain
+// then returns the correctly signed tiny quotient or a zero of either sign, and the caller adds
+// cx/cy (>= 0.5) to q * fx, which absorbs both.
+__device__ __forceinline__ f32x2 div2_exact(f32x2 n, float d, bool mag_ok) {
+  if (mag_ok && fabsf(d) > 0x1p-60f) {
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e0 = __builtin_fmaf(-d, r0, 1.0f);
     const float r1 = __builtin_fmaf(e0, r0, r0);
@@ -191,45 +193,96 @@ __device__ __forceinline__ f32x2 div2_exact(f32x2 n, float d) {
   return f32x2{n.x / d, n.y / d};
 }
 
+// The FMA chain alone (valid under the conditions stated above; garbage otherwise).
+__device__ __forceinline__ f32x2 div2_fast(f32x2 n, float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e0, r0, r0);
+  const f32x2 nd = {-d, -d}, rr = {r1, r1};
+  const f32x2 q0 = n * rr;
+  const f32x2 e1 = __builtin_elementwise_fma(nd, q0, n);
+  const f32x2 q1 = __builtin_elementwise_fma(e1, rr, q0);
+  const f32x2 e2 = __builtin_elementwise_fma(nd, q1, n);
+  return __builtin_elementwise_fma(e2, rr, q1);
+}
+
 // (int)roundf(t) for the GPU's saturating conversion: exhaustively verified over all 2^32 floats
 // that trunc(t + copysign(0.5 - 2^-25, t)) rounds half away from zero like roundf.
 __device__ __forceinline__ int round_to_int(float t) { return f2i(t + copysignf(0.49999997f, t)); }
 
-// Marches one ray; returns true on a hit and the pixel index of the hit in `q`.
-template <bool kPow2>
-__device__ __forceinline__ bool march(const GiParams& p, v3 pos, float a, v3 sv, float cx, float cy,
-                                      const float* __restrict__ pos_z, int& q) {
-  const f32x2 svxy = {sv.x, sv.y}, posxy = {pos.x, pos.y}, fxy = {p.fx, p.fy}, cxy = {cx, cy};
-  for (int j = p.start; j < p.step; ++j) {
-    const float fj = (float)j;
-    // pos + sampleVec * j * (1 + z/100) * (1 + z/100) * radius / step, left to right (forward.cu:693)
-    f32x2 m = svxy * fj;
-    float mz = sv.z * fj;
-    m = m * a; mz = mz * a;
-    m = m * a; mz = mz * a;
-    m = m * p.radius; mz = mz * p.radius;
-    if (kPow2) {
-      m = m * p.inv_step; mz = mz * p.inv_step;
-    } else {
-      const float fs = (float)p.step;
-      m = f32x2{m.x / fs, m.y / fs}; mz = mz / fs;
+// Marches kRays rays of one pixel together; hit[k] = pixel index of ray k's hit or -1.
+// The reference walks j = start..step-1 per ray and stops at the first sample that leaves the image
+// or hits (forward.cu:691-714).  ~98 % of the rays of a real frame run all their steps, so:
+//   * steps are evaluated in groups of kGroup: the coordinates of the whole group (times kRays) are
+//     computed and their z-plane gathers issued together -- memory-level parallelism instead of one
+//     dependent L2 round trip per step;
+//   * the group is then resolved IN ORDER with per-lane selects, not branches (`open` = ray still
+//     marching), which is exactly the sequential outcome; the only branches left are wave-uniform
+//     (all rays of the wave resolved; rare IEEE-division slow path), so the scalar unit is not
+//     spent on exec-mask bookkeeping.
+template <bool kPow2, int kGroup, int kRays>
+__device__ __forceinline__ void march(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
+                                      const float* __restrict__ pos_z, bool mag_ok, int* hit) {
+  const f32x2 posxy = {pos.x, pos.y}, fxy = {p.fx, p.fy}, cxy = {cx, cy};
+  bool open[kRays];
+#pragma unroll
+  for (int k = 0; k < kRays; k++) { open[k] = true; hit[k] = -1; }
+  for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
+    int idx[kRays][kGroup];
+    float spzv[kRays][kGroup], zv[kRays][kGroup];
+    bool inb[kRays][kGroup];
+#pragma unroll
+    for (int g = 0; g < kGroup; g++) {
+      const float fj = (float)(j0 + g);
+      const bool in_range = (j0 + g) < p.step;
+#pragma unroll
+      for (int k = 0; k < kRays; k++) {
+        // pos + sampleVec * j * (1 + z/100) * (1 + z/100) * radius / step, left to right (forward.cu:693)
+        f32x2 m = f32x2{sv[k].x, sv[k].y} * fj;
+        float mz = sv[k].z * fj;
+        m = m * a; mz = mz * a;
+        m = m * a; mz = mz * a;
+        m = m * p.radius; mz = mz * p.radius;
+        if (kPow2) {
+          m = m * p.inv_step; mz = mz * p.inv_step;
+        } else {
+          const float fs = (float)p.step;
+          m = f32x2{m.x / fs, m.y / fs}; mz = mz / fs;
+        }
+        const f32x2 sp = posxy + m;
+        const float spz = pos.z + mz;
+        // get_coord (ssr.h:120-135)
+        const float den = spz + 0.0000001f;
+        f32x2 qv = div2_fast(sp, den);
+        const bool need_ieee = !(mag_ok && fabsf(den) > 0x1p-60f);
+        if (__builtin_expect(__any(need_ieee && open[k]), 0)) {
+          if (need_ieee) qv = f32x2{sp.x / den, sp.y / den};
+        }
+        const f32x2 t = qv * fxy + cxy;
+        const int ix = round_to_int(t.x);
+        const int iy = round_to_int(t.y);
+        inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+        idx[k][g] = inb[k][g] ? p.W * iy + ix : 0;
+        spzv[k][g] = spz;
+      }
     }
-    const f32x2 sp = posxy + m;
-    const float spz = pos.z + mz;
-    // get_coord (ssr.h:120-135)
-    const float den = spz + 0.0000001f;
-    const f32x2 t = div2_exact(sp, den) * fxy + cxy;
-    const int ix = round_to_int(t.x);
-    const int iy = round_to_int(t.y);
-    if ((unsigned)ix >= (unsigned)p.W || (unsigned)iy >= (unsigned)p.H) return false;
-    const int idx = p.W * iy + ix;
-    const float sampleDepth = pos_z[idx];
-    if (sampleDepth <= spz + p.bias && sampleDepth >= spz - p.thick) {
-      q = idx;
-      return true;
+#pragma unroll
+    for (int g = 0; g < kGroup; g++)
+#pragma unroll
+      for (int k = 0; k < kRays; k++) zv[k][g] = pos_z[idx[k][g]];
+    bool any_open = false;
+#pragma unroll
+    for (int k = 0; k < kRays; k++) {
+#pragma unroll
+      for (int g = 0; g < kGroup; g++) {
+        const bool h = inb[k][g] && (zv[k][g] <= spzv[k][g] + p.bias) && (zv[k][g] >= spzv[k][g] - p.thick);
+        hit[k] = (open[k] && h) ? idx[k][g] : hit[k];
+        open[k] = open[k] && inb[k][g] && !h;
+      }
+      any_open = any_open || open[k];
     }
+    if (!__any(any_open)) break;
   }
-  return false;
 }
 
 struct Tbn { v3 t, b, n; };
@@ -248,11 +301,34 @@ __device__ __forceinline__ v3 tbn_apply(const Tbn& m, float x, float y, float z)
   return {m.t.x * x + m.b.x * y + m.n.x * z, m.t.y * x + m.b.y * y + m.n.y * z,
           m.t.z * x + m.b.z * y + m.n.z * z};
 }
+// |sample position| <= |pos| + |sv| * (j/step) * a^2 * radius with |sv| <= sqrt(3): when this bound
+// is far below 2^60 for the pixel, no step of any ray needs the operand pre-scaling of IEEE division.
+__device__ __forceinline__ bool gi_mag_ok(v3 pos, float a, float radius) {
+  const float bound = fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fabsf(pos.z)) + 2.0f * fabsf(a * a * radius) + 1.0f;
+  return bound < 0x1p59f;  // false for NaN / inf
+}
 
-__device__ __forceinline__ bool gi_pixel(int W, int H, int& x, int& y) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-  y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+// Every sample direction contains t * ts.x, so a tangent that is NaN in all three components
+// (empty pixel: N = 0 -> NaN normal; or N parallel to `up`) makes every sample position NaN:
+// the projected pixel is (0, 0), the depth test against NaN is false, no ray ever hits.  Such
+// pixels -- the whole background of an object-centric frame -- skip the march with the same result.
+__device__ __forceinline__ bool tbn_never_hits(const Tbn& m) {
+  return (m.t.x != m.t.x) && (m.t.y != m.t.y) && (m.t.z != m.t.z);
+}
+
+constexpr int kGiGroup = 4;
+constexpr int kGiRays = 2;  // rays marched together per lane (independent instruction streams)
+constexpr int kGiWaves = 4;
+
+// One 256-lane workgroup per 8x8 pixel tile: the four waves cover the SAME 64 pixels and split the
+// ray set into four contiguous chunks (25 000 x 4 waves at 800x800 instead of 10 000 long-running
+// ones: the tail of the launch is short and empty tiles retire immediately).  Partial sums are
+// combined through LDS in the fixed order ((w0 + w1) + w2) + w3.
+__device__ __forceinline__ bool gi_pixel(int W, int H, int& x, int& y, int& wave) {
+  const int lane = threadIdx.x & 63;
+  wave = threadIdx.x >> 6;
+  x = blockIdx.x * 8 + (lane & 7);
+  y = blockIdx.y * 8 + (lane >> 3);
   return x < W && y < H;
 }
 
@@ -261,29 +337,56 @@ __global__ void __launch_bounds__(256)
 ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             const float* __restrict__ nrm, const float* __restrict__ pos_map,
             float* __restrict__ occlusion) {
-  int x, y;
-  if (!gi_pixel(p.W, p.H, x, y)) return;
+  __shared__ float s_part[kGiWaves][64];
+  int x, y, wave;
+  const bool inside = gi_pixel(p.W, p.H, x, y, wave);
+  const int lane = threadIdx.x & 63;
   const size_t HW = (size_t)p.H * p.W;
-  const size_t pix_id = (size_t)p.W * y + x;
-  const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
-  const v3 pos = {pos_map[pix_id], pos_map[HW + pix_id], pos_map[2 * HW + pix_id]};
-  const float* pos_z = pos_map + 2 * HW;
-  const float a = 1 + pos.z / 100;
-  const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
+  const size_t pix_id = inside ? (size_t)p.W * y + x : 0;
   float occ = 0.0f;
-  if (p.start < p.step) {
-    for (int r = 0; r < p.nrays; r++) {
-      const float4 r0 = rays[2 * r];      // wave-uniform -> scalar loads
-      const float4 r1 = rays[2 * r + 1];
-      const v3 sv = tbn_apply(tbn, r0.x, r0.y, r0.z);
-      int q;
-      if (march<kPow2>(p, pos, a, sv, cx, cy, pos_z, q)) occ += r1.y;
+  if (inside && p.start < p.step) {
+    const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
+    if (!tbn_never_hits(tbn)) {
+      const v3 pos = {pos_map[pix_id], pos_map[HW + pix_id], pos_map[2 * HW + pix_id]};
+      const float* pos_z = pos_map + 2 * HW;
+      const float a = 1 + pos.z / 100;
+      const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
+      const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
+      const int r0 = wave * chunk, r1 = min(p.nrays, r0 + chunk);
+      const bool mag_ok = gi_mag_ok(pos, a, p.radius);
+      int r = r0;
+      for (; r + kGiRays <= r1; r += kGiRays) {
+        v3 sv[kGiRays];
+        float w[kGiRays];
+        int hit[kGiRays];
+#pragma unroll
+        for (int k = 0; k < kGiRays; k++) {
+          const float4 ra = rays[2 * (r + k)];  // wave-uniform -> scalar loads
+          w[k] = rays[2 * (r + k) + 1].y;
+          sv[k] = tbn_apply(tbn, ra.x, ra.y, ra.z);
+        }
+        march<kPow2, kGiGroup, kGiRays>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
+#pragma unroll
+        for (int k = 0; k < kGiRays; k++) occ += hit[k] >= 0 ? w[k] : 0.0f;  // x + 0 is exact: ray order kept
+      }
+      for (; r < r1; r++) {
+        const float4 ra = rays[2 * r];
+        const v3 sv = tbn_apply(tbn, ra.x, ra.y, ra.z);
+        int hit;
+        march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, &hit);
+        occ += hit >= 0 ? rays[2 * r + 1].y : 0.0f;
+      }
     }
   }
-  if (sum_w > 0.0f)
-    occlusion[pix_id] = fmaxf(0.0f, fminf(1.0f, (float)(1.0 - (double)(occ / sum_w))));
-  else
-    occlusion[pix_id] = 1.0f;
+  s_part[wave][lane] = occ;
+  __syncthreads();
+  if (wave == 0 && inside) {
+    const float tot = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
+    if (sum_w > 0.0f)
+      occlusion[pix_id] = fmaxf(0.0f, fminf(1.0f, (float)(1.0 - (double)(tot / sum_w))));
+    else
+      occlusion[pix_id] = 1.0f;
+  }
 }
 
 template <bool kPow2>
@@ -292,12 +395,68 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
            const float* __restrict__ pos_map, const float* __restrict__ rgb,
            const float* __restrict__ albedo_map, const float* __restrict__ metallic_map,
            const float* __restrict__ F0_map, float* __restrict__ color, float* __restrict__ abd) {
-  int x, y;
-  if (!gi_pixel(p.W, p.H, x, y)) return;
+  __shared__ float s_part[kGiWaves][3][64];
+  int x, y, wave;
+  const bool inside = gi_pixel(p.W, p.H, x, y, wave);
+  const int lane = threadIdx.x & 63;
   const size_t HW = (size_t)p.H * p.W;
-  const size_t pix_id = (size_t)p.W * y + x;
+  const size_t pix_id = inside ? (size_t)p.W * y + x : 0;
   const v3 pos = {pos_map[pix_id], pos_map[HW + pix_id], pos_map[2 * HW + pix_id]};
   const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
+  v3 diffuse = {0, 0, 0};
+  if (inside && p.start < p.step && !tbn_never_hits(tbn)) {
+    const float* pos_z = pos_map + 2 * HW;
+    const float a = 1 + pos.z / 100;
+    const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
+    const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
+    const int r0 = wave * chunk, r1 = min(p.nrays, r0 + chunk);
+    const bool mag_ok = gi_mag_ok(pos, a, p.radius);
+    auto add_hit = [&](int q, float cos_t, float sin_t) {
+      if (q >= 0) {
+        // rgb * cosf(theta) * sinf(theta), left to right (forward.cu:824-826)
+        diffuse.x += rgb[q] * cos_t * sin_t;
+        diffuse.y += rgb[HW + q] * cos_t * sin_t;
+        diffuse.z += rgb[2 * HW + q] * cos_t * sin_t;
+      }
+    };
+    int r = r0;
+    for (; r + kGiRays <= r1; r += kGiRays) {
+      v3 sv[kGiRays];
+      float ct[kGiRays], st[kGiRays];
+      int hit[kGiRays];
+#pragma unroll
+      for (int k = 0; k < kGiRays; k++) {
+        const float4 ra = rays[2 * (r + k)];
+        ct[k] = ra.w;
+        st[k] = rays[2 * (r + k) + 1].x;
+        sv[k] = tbn_apply(tbn, ra.x, ra.y, ra.z);
+      }
+      march<kPow2, kGiGroup, kGiRays>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
+      bool any_hit = false;
+#pragma unroll
+      for (int k = 0; k < kGiRays; k++) any_hit = any_hit || hit[k] >= 0;
+      if (__any(any_hit)) {  // hits are rare: one wave-uniform test per ray pair
+#pragma unroll
+        for (int k = 0; k < kGiRays; k++) add_hit(hit[k], ct[k], st[k]);
+      }
+    }
+    for (; r < r1; r++) {
+      const float4 ra = rays[2 * r];
+      const v3 sv = tbn_apply(tbn, ra.x, ra.y, ra.z);
+      int hit;
+      march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, &hit);
+      add_hit(hit, ra.w, rays[2 * r + 1].x);
+    }
+  }
+  s_part[wave][0][lane] = diffuse.x;
+  s_part[wave][1][lane] = diffuse.y;
+  s_part[wave][2][lane] = diffuse.z;
+  __syncthreads();
+  if (wave != 0 || !inside) return;
+  diffuse.x = ((s_part[0][0][lane] + s_part[1][0][lane]) + s_part[2][0][lane]) + s_part[3][0][lane];
+  diffuse.y = ((s_part[0][1][lane] + s_part[1][1][lane]) + s_part[2][1][lane]) + s_part[3][1][lane];
+  diffuse.z = ((s_part[0][2][lane] + s_part[1][2][lane]) + s_part[2][2][lane]) + s_part[3][2][lane];
+
   const v3 N = tbn.n;
   const v3 alb = {albedo_map[pix_id], albedo_map[HW + pix_id], albedo_map[2 * HW + pix_id]};
   const v3 F0 = {F0_map[pix_id], F0_map[HW + pix_id], F0_map[2 * HW + pix_id]};
@@ -311,25 +470,6 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
   kD.x = (float)((double)kD.x * (1.0 - (double)metallic));
   kD.y = (float)((double)kD.y * (1.0 - (double)metallic));
   kD.z = (float)((double)kD.z * (1.0 - (double)metallic));
-
-  const float* pos_z = pos_map + 2 * HW;
-  const float a = 1 + pos.z / 100;
-  const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
-  v3 diffuse = {0, 0, 0};
-  if (p.start < p.step) {
-    for (int r = 0; r < p.nrays; r++) {
-      const float4 r0 = rays[2 * r];
-      const float4 r1 = rays[2 * r + 1];
-      const v3 sv = tbn_apply(tbn, r0.x, r0.y, r0.z);
-      int q;
-      if (march<kPow2>(p, pos, a, sv, cx, cy, pos_z, q)) {
-        // rgb * cosf(theta) * sinf(theta), left to right (forward.cu:824-826)
-        diffuse.x += rgb[q] * r0.w * r1.x;
-        diffuse.y += rgb[HW + q] * r0.w * r1.x;
-        diffuse.z += rgb[2 * HW + q] * r0.w * r1.x;
-      }
-    }
-  }
   const float nrSamples = (float)p.nrays;  // += 1 per ray in fp32 is exact below 2^24
   v3 gd;
   if (nrSamples > 0.0f) {
@@ -367,7 +507,7 @@ int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, floa
   if (rc) return rc;
   bool pow2;
   const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
-  dim3 grid((W + 15) / 16, (H + 15) / 16);
+  dim3 grid((W + 7) / 8, (H + 7) / 8);
   if (pow2)
     hipLaunchKernelGGL(ssao_kernel<true>, grid, dim3(256), 0, s, p, t.dev, t.sum_w, normal, pos, occlusion);
   else
@@ -384,7 +524,7 @@ int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float
   if (rc) return rc;
   bool pow2;
   const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
-  dim3 grid((W + 15) / 16, (H + 15) / 16);
+  dim3 grid((W + 7) / 8, (H + 7) / 8);
   if (pow2)
     hipLaunchKernelGGL(ssr_kernel<true>, grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd);
   else
@@ -544,7 +684,10 @@ selftest_div2_kernel(int n, const float* __restrict__ nx, const float* __restric
                      int* __restrict__ out_round) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const f32x2 q = div2_exact(f32x2{nx[i], ny[i]}, d[i]);
+  const float big = fmaxf(fmaxf(fabsf(nx[i]), fabsf(ny[i])), fabsf(d[i]));
+  const float small = fminf(fabsf(nx[i]), fabsf(ny[i]));
+  // numerators below 2^-60 are exercised only through the march (absorbed by + cx), not here
+  const f32x2 q = div2_exact(f32x2{nx[i], ny[i]}, d[i], big < 0x1p60f && small > 0x1p-60f);
   out_fast[2 * i] = q.x;
   out_fast[2 * i + 1] = q.y;
   out_ref[2 * i] = nx[i] / d[i];

@@ -188,15 +188,37 @@ specular_bounds_kernel(int N, float cutoff, float* __restrict__ bounds) {
   }
 }
 
+// safeNormalize (RU/vec3f.h:90-94) for |v| in (2^-60, 2^60): the three IEEE quotients v / l share one
+// reciprocal refinement (same FMA chain as the compiler's division expansion, bit-identical results).
+__device__ __forceinline__ v3 normalize_exact(v3 v) {
+  const float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+  if (!(l > 0x1p-60f && l < 0x1p60f)) return safe_normalize(v);
+  const float r0 = __builtin_amdgcn_rcpf(l);
+  const float e0 = __builtin_fmaf(-l, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e0, r0, r0);
+  v3 q;
+  {
+    const float q0 = v.x * r1, e1 = __builtin_fmaf(-l, q0, v.x), q1 = __builtin_fmaf(e1, r1, q0);
+    q.x = __builtin_fmaf(__builtin_fmaf(-l, q1, v.x), r1, q1);
+  }
+  {
+    const float q0 = v.y * r1, e1 = __builtin_fmaf(-l, q0, v.y), q1 = __builtin_fmaf(e1, r1, q0);
+    q.y = __builtin_fmaf(__builtin_fmaf(-l, q1, v.y), r1, q1);
+  }
+  {
+    const float q0 = v.z * r1, e1 = __builtin_fmaf(-l, q0, v.z), q1 = __builtin_fmaf(e1, r1, q0);
+    q.z = __builtin_fmaf(__builtin_fmaf(-l, q1, v.z), r1, q1);
+  }
+  return q;
+}
+
 // forward: out[o] = (sum_in tex[in] w, sum w) over in in window(o)
 // backward (gather over the same, symmetric, window): g_in[i] = sum_o g[o].rgb * w(o, i)
 // forward: out[o] = (sum_in tex[in] w, sum w) over in in window(o)
 // backward (gather over the same window, which is symmetric because the test dot(L, V) >= cutoff
 // is): g_in[i] = sum_o g[o].rgb * w(o, i).
-// Per accepted pair the arithmetic is the reference's own sequence (H = safeNormalize(L + V), V.H,
-// the NDF with its fp64 division: RU/cubemap.cu:174-179, 270-277) on the cached unit directions,
-// so every weight is bit-identical to the oracle's and only the summation order differs.  This
-// matters: d = 1 - c^2 (1 - alpha^2) cancels to ~alpha^2 at the lobe centre, so a 1-ulp change of
+// Per accepted pair H = safeNormalize(L + V), c = V.H and d = (c a^2 - c) c + 1 are the reference's
+// own IEEE sequence (RU/cubemap.cu:174-179, 270-277) on the cached unit directions.  This matters: d = 1 - c^2 (1 - alpha^2) cancels to ~alpha^2 at the lobe centre, so a 1-ulp change of
 // c = V.H (e.g. the algebraic shortcut sqrt((1 + L.V) / 2)) moves a weight by ~1e-7 / alpha^2 --
 // 2e-3 at the roughness-0.08 level.
 template <bool kBackward>
@@ -225,11 +247,16 @@ specular_cubemap_kernel(int N, const float4* __restrict__ table, const float* __
         if (d >= cutoff) {
           const float wiDotN = fmaxf(d, 0.0f);
           // forward: VNR = me, L = other; backward: VNR = other, L = me
-          const v3 Hh = kBackward ? safe_normalize(v3{me.x + ot.x, me.y + ot.y, me.z + ot.z})
-                                  : safe_normalize(v3{ot.x + me.x, ot.y + me.y, ot.z + me.z});
+          const v3 Hh = kBackward ? normalize_exact(v3{me.x + ot.x, me.y + ot.y, me.z + ot.z})
+                                  : normalize_exact(v3{ot.x + me.x, ot.y + me.y, ot.z + me.z});
           const float VNRDotH = fmaxf(kBackward ? (ot.x * Hh.x + ot.y * Hh.y + ot.z * Hh.z)
                                                 : (me.x * Hh.x + me.y * Hh.y + me.z * Hh.z), 0.0f);
-          const float w = wiDotN * ndf_ggx(alphaSqr, VNRDotH) * (kBackward ? me.w : ot.w) / 4.0f;
+          // c and dd exactly as the reference; only the last, well-conditioned division
+          // alphaSqr / (dd^2 * pi) is done in fp32 instead of fp64 (<= 2e-7 relative)
+          const float c = fminf(fmaxf(VNRDotH, 0.0f), 1.0f);
+          const float dd = (c * alphaSqr - c) * c + 1.0f;
+          const float ndf = alphaSqr / ((dd * dd) * 3.14159265358979323846f);
+          const float w = wiDotN * ndf * (kBackward ? me.w : ot.w) / 4.0f;
           const float* t = src + (size_t)stride * i;
           c0 += t[0] * w; c1 += t[1] * w; c2 += t[2] * w;
           wsum += w;

@@ -308,7 +308,18 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g) {
   a.dL_dmetallic[idx] = g4.y;
   a.dL_ddepth[idx] = g4.z;
 
-  if (!(a.radii[idx] > 0)) return;
+  if (!(a.radii[idx] > 0)) {
+    // culled Gaussian: the reference leaves the caller's zero-initialised outputs untouched; writing
+    // the zeros here lets the caller hand in uninitialised memory (no memset launches per tensor)
+    a.dL_dmean3D[3 * (size_t)idx + 0] = 0.0f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.0f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.0f;
+    if (a.shs)
+      for (int i = 0; i < 3 * M; i++) a.dL_dsh[(size_t)idx * M * 3 + i] = 0.0f;
+    a.dL_dscale[3 * (size_t)idx + 0] = 0.0f; a.dL_dscale[3 * (size_t)idx + 1] = 0.0f; a.dL_dscale[3 * (size_t)idx + 2] = 0.0f;
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
+    return;
+  }
 
   // ---- computeCov2DCUDA (backward.cu:145-279)
   const float* vm = a.viewmatrix;
@@ -406,6 +417,7 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g) {
     const float x = dir.x, y = dir.y, z = dir.z;
     float* dsh = a.dL_dsh + (size_t)idx * M * 3;
 #define W3(k, v) { const v3 _v = (v); dsh[3 * (k)] = _v.x; dsh[3 * (k) + 1] = _v.y; dsh[3 * (k) + 2] = _v.z; }
+    for (int i = 3 * (D + 1) * (D + 1); i < 3 * M; i++) dsh[i] = 0.0f;  // coefficients above the active degree
     W3(0, dRGB * SHC0);
     if (D > 0) {
       const float d1 = -SHC1 * y, d2 = SHC1 * z, d3 = -SHC1 * x;
@@ -455,6 +467,10 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g) {
   a.dL_dmean3D[3 * (size_t)idx + 2] = dmeans.z;
 
   // ---- computeCov3D backward (backward.cu:283-346)
+  if (!a.scales) {
+    a.dL_dscale[3 * (size_t)idx + 0] = 0.0f; a.dL_dscale[3 * (size_t)idx + 1] = 0.0f; a.dL_dscale[3 * (size_t)idx + 2] = 0.0f;
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
+  }
   if (a.scales) {
     const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
     const float r = q.x, x = q.y, y = q.z, z = q.w;

@@ -121,16 +121,17 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
     dev = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     fopts = dict(dtype=torch.float32, device=dev)
-    out_color = torch.zeros((NUM_CHANNELS, H, W), **fopts)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-    out_opacity = torch.zeros((1, H, W), **fopts)
-    out_depth = torch.zeros((1, H, W), **fopts)
-    out_normal = torch.zeros((NUM_CHANNELS, H, W), **fopts)
-    out_normal_view = torch.zeros((NUM_CHANNELS, H, W), **fopts)
-    out_pos = torch.zeros((NUM_CHANNELS, H, W), **fopts)
-    out_albedo = torch.zeros((NUM_CHANNELS, H, W), **fopts)
-    out_roughness = torch.zeros((1, H, W), **fopts)
-    out_metallic = torch.zeros((1, H, W), **fopts)
+    # the reference zero-fills every output (rasterize_points.cu:170-179); the kernels overwrite every
+    # pixel / every Gaussian when P > 0, so one uninitialised slab is carved instead of 10 fill launches
+    if P != 0:
+        slab = torch.empty((20, H, W), **fopts)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    else:
+        slab = torch.zeros((20, H, W), **fopts)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    out_color, out_normal, out_normal_view = slab[0:3], slab[3:6], slab[6:9]
+    out_pos, out_albedo = slab[9:12], slab[12:15]
+    out_opacity, out_depth, out_roughness, out_metallic = slab[15:16], slab[16:17], slab[17:18], slab[18:19]
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     rendered = 0
     if P != 0:
@@ -171,7 +172,10 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
     P = int(means3D.size(0))
     H, W = int(grad_color.size(1)), int(grad_color.size(2))
     M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
-    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    # every element of every gradient tensor is written by the backward kernels when P > 0
+    # (the reference zero-fills 14 tensors first, rasterize_points.cu:299-312)
+    _mk = torch.empty if P != 0 else torch.zeros
+    z = lambda *shape: _mk(shape, dtype=torch.float32, device=dev)  # noqa: E731
     dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, NUM_CHANNELS)
     dL_dconic, dL_ddepth, dL_dopacity = z(P, 2, 2), z(P, 1), z(P, 1)
     dL_dnormal, dL_dalbedo, dL_droughness, dL_dmetallic = z(P, 3), z(P, 3), z(P, 1), z(P, 1)
@@ -235,7 +239,7 @@ def _depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depthMap):
 def _SSAO(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, out_normal, out_pos):
     _need_gpu(out_normal, "out_normal")
     dev = out_normal.device
-    occlusion = torch.ones((1, height, width), dtype=torch.float32, device=dev)
+    occlusion = torch.empty((1, height, width), dtype=torch.float32, device=dev)  # every pixel is written
     n, k0 = _fptr(out_normal, "out_normal")
     ps, k1 = _fptr(out_pos, "out_pos")
     with torch.cuda.device(dev):
@@ -249,8 +253,8 @@ def _SSR(width, height, focal_x, focal_y, radius, bias, thick, delta, step, star
          out_rgb, out_albedo, out_roughness, out_metallic, out_F0):
     _need_gpu(out_roughness, "out_roughness")
     dev = out_roughness.device
-    color = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
-    abd = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
+    color = torch.empty((3, height, width), dtype=torch.float32, device=dev)  # every pixel is written
+    abd = torch.empty((3, height, width), dtype=torch.float32, device=dev)
     ptrs, keep = [], []
     for t, name in ((out_normal, "out_normal"), (out_pos, "out_pos"), (out_rgb, "out_rgb"),
                     (out_albedo, "out_albedo"), (out_roughness, "out_roughness"),

@@ -54,7 +54,8 @@ size_t gigs_required_binning(int num_rendered);
 /* Rasterizer::forward (R/cuda_rasterizer/rasterizer.h:24-63, rasterizer_impl.cu:486-672).
  * Runs preprocess -> scan -> (one 4-byte D2H read of num_rendered) -> duplicate -> radix sort
  * -> tile ranges -> G-buffer blend.  `background` is 3 floats.  `radii` may be NULL.
- * Output planes must be zero-initialised by the caller when P == 0 (nothing is launched). */
+ * Every pixel of every output plane and every radii[i] is written when P > 0; when P == 0 nothing
+ * is launched and the caller's (zero) initialisation stays. */
 int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer,
                  void* binning_user, gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M,
                  const float* background, int width, int height, const float* means3D,
@@ -68,9 +69,10 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
                  float* out_pos, float* out_albedo, float* out_roughness, float* out_metallic,
                  int* radii, int debug, void* stream);
 
-/* Rasterizer::backward (rasterizer.h:103-150, rasterizer_impl.cu:676-803).  All dL_d* outputs
- * must be zero-initialised by the caller (R/rasterize_points.cu:299-312); dL_dconic [P,2,2]
- * and dL_ddepth [P] are the two scratch gradients the reference allocates but does not return. */
+/* Rasterizer::backward (rasterizer.h:103-150, rasterizer_impl.cu:676-803).  Every element of every
+ * dL_d* output is written (culled Gaussians get zeros), so the caller need not zero-initialise them
+ * as the reference binding does (R/rasterize_points.cu:299-312); dL_dconic [P,2,2] and dL_ddepth [P]
+ * are the two scratch gradients the reference allocates but does not return. */
 int gigs_backward(int P, int D, int M, int R, const float* background, int width, int height,
                   const float* means3D, const float* shs, const float* colors_precomp,
                   const float* normal, const float* albedo, const float* roughness,
@@ -96,7 +98,7 @@ int gigs_depth_to_normal(int width, int height, float focal_x, float focal_y,
                          const float* viewmatrix, const float* depth, float* normal,
                          float* depth_pos, void* stream);
 
-/* Rasterizer::SSAO (rasterizer_impl.cu:222-253 -> forward.cu:635-724). occlusion = [1,H,W]. */
+/* Rasterizer::SSAO (rasterizer_impl.cu:222-253 -> forward.cu:635-724). occlusion = [1,H,W], fully written. */
 int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius, float bias,
               float thick, float delta, int step, int start, const float* normal_view,
               const float* pos, float* occlusion, void* stream);
