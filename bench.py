@@ -34,6 +34,7 @@ importlib.import_module("gi-gs_amd")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+import dp  # noqa: E402
 import gigs_lib  # noqa: E402
 import pipeline  # noqa: E402
 import scenes  # noqa: E402
@@ -66,6 +67,25 @@ def algorithmic_bytes(P, V, R, N, M, T):
         "cubemap_fwd": (2 * 6.3e6 + 96 * 6 * (256 ** 2 + 128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2)) / 10,
         "cubemap_bwd": (2 * 6.3e6 + 96 * 6 * (256 ** 2 + 128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2)) / 10,
     }
+
+
+def pmc_traffic(stage: str):
+    """HBM bytes per launch of `stage` from the newest committed rocprofv3 --pmc summary under
+    profiles/ (separate FETCH_SIZE / WRITE_SIZE passes; (2*FETCH_SIZE + WRITE_SIZE) * 1024 per
+    MI355X_MICROARCH.md -- the x2 is calibrated for wide streaming reads only, so for the
+    gather-dominated GI kernels this is an upper estimate).  None if no summary is committed."""
+    import glob
+    names = {"ssao": "ssao_kernel<true>", "ssr": "ssr_kernel<true>", "blend_fwd": "blend_fwd_kernel",
+             "blend_bwd": "blend_bwd_kernel", "shade_bwd": "shade_bwd_kernel", "shade_fwd": "shade_fwd_kernel",
+             "preprocess_fwd": "preprocess_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel", "sort": "rocprim_sort"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")))
+    if not files or stage not in names:
+        return None
+    try:
+        k = json.load(open(files[-1])).get(names[stage], {})
+        return int((2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def make_light(device, shade: str):
@@ -185,7 +205,7 @@ def main():
     flat_params = [g[k] for k in PARAM_KEYS] + params_light
 
     def one_step(i):
-        cam = cams_t[(i * world + rank) % n_views]
+        cam = cams_t[dp.view_for(i, rank, world, n_views)]
         for p in flat_params:
             p.grad = None
         if shade == "hip":
@@ -194,14 +214,7 @@ def main():
             out = stub_step(cam, g, args.sh_degree, gi, gt_image)
         if world > 1:
             # one flat bucket: xGMI is point-to-point, a single large all-reduce keeps every link busy
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in flat_params]
-            flat = torch.cat([x.reshape(-1) for x in grads])
-            dist.all_reduce(flat)
-            off = 0
-            for p, x in zip(flat_params, grads):
-                n = x.numel()
-                p.grad = flat[off:off + n].view_as(p)
-                off += n
+            dp.allreduce_gradients(flat_params)
         return out
 
     def barrier():
@@ -255,7 +268,7 @@ def main():
         if dom is not None and "achieved_GBs" in kernels[dom]:
             a = kernels[dom]["achieved_GBs"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
                         "note": "dominant kernel by time; it is VALU/gather-bound, not HBM-bound (DESIGN.md)"}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
