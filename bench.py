@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=2)
     ap.add_argument("--start", type=int, default=8, help="GI march start (8 = reference CLI default, 64 = README)")
     ap.add_argument("--shade", choices=["auto", "hip", "none"], default="auto")
+    ap.add_argument("--graphs", choices=["on", "off"], default="on",
+                    help="capture the launch-bound glue segments of the step into hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -198,18 +200,23 @@ def main():
     gt_image = torch.stack([0.5 + 0.3 * torch.sin(6 * xx), 0.5 + 0.3 * torch.cos(5 * yy), 0.4 + 0.2 * xx * yy])
     light, brdf_lut = make_light(dev, shade)
     rays = pipeline.canonical_rays(cams[0], dev)
+    view_dirs = [pipeline.view_dirs_for(c, rays, dev) for c in cams_t]  # per-camera constants, like gt_image
     if light is not None:
         params_light = [p for p in light.parameters()]
     else:
         params_light = []
     flat_params = [g[k] for k in PARAM_KEYS] + params_light
+    stepper = None
+    if shade == "hip":
+        stepper = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=(args.graphs == "on"))
 
     def one_step(i):
-        cam = cams_t[dp.view_for(i, rank, world, n_views)]
+        vi = dp.view_for(i, rank, world, n_views)
+        cam = cams_t[vi]
         for p in flat_params:
             p.grad = None
         if shade == "hip":
-            out = pipeline.stage2_step(cam, g, args.sh_degree, gi, light, brdf_lut, gt_image, rays)
+            out = stepper(cam, g, gt_image, view_dirs[vi])
         else:
             out = stub_step(cam, g, args.sh_degree, gi, gt_image)
         if world > 1:
@@ -280,7 +287,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2 stand-in: %dk surface Gaussians, %dx%d, SH deg %d, GI step=%d start=%d delta=%g"
                                    % (P // 1000, W, H, args.sh_degree, gi["step"], gi["start"], gi["delta"]),
-                       "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade,
+                       "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade, "hip_graphs": args.graphs,
                        "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

@@ -49,9 +49,16 @@ depth_to_normal_kernel(int W, int H, float fx, float fy, const float* __restrict
                        float* __restrict__ depth_pos) {
   const int x = blockIdx.x * 16 + (threadIdx.x & 15);
   const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (x <= 0 || x >= W - 1 || y <= 0 || y >= H - 1) return;
+  if (x >= W || y >= H) return;
   const size_t HW = (size_t)H * W;
   const size_t pix_id = (size_t)W * y + x;
+  // The reference returns early in three places and relies on the caller's zero fill
+  // (rasterize_points.cu:394-395); the zeros are written here so the caller can pass raw memory.
+  normal_out[pix_id] = 0.0f; normal_out[HW + pix_id] = 0.0f; normal_out[2 * HW + pix_id] = 0.0f;
+  if (x <= 0 || x >= W - 1 || y <= 0 || y >= H - 1) {
+    depth_pos[pix_id] = 0.0f; depth_pos[HW + pix_id] = 0.0f; depth_pos[2 * HW + pix_id] = 0.0f;
+    return;
+  }
   const float depth_thresh = 0.01f;
   const float depth = depth_map[pix_id];
   const float cx = float(W) / 2.0f, cy = float(H) / 2.0f;

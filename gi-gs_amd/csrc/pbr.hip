@@ -278,6 +278,109 @@ specular_cubemap_kernel(int N, const float4* __restrict__ table, const float* __
 
 
 // ------------------------------------------------------------------------------------------
+// GGX pre-filter through a cached weight table.
+// The weight of a (texel, texel) pair, f = max(L.V, 0) * D_ggx(V.H), depends only on the resolution,
+// the roughness and the cutoff -- not on the cubemap values that change every training step.  With
+// 288 GB of HBM it is cheaper to keep f for every candidate of every window (186 M floats = 0.74 GB
+// for the 256..16 chain, twice that with the role-swapped table the backward needs) than to redo the
+// normalisation, the NDF and its divisions each step: the filter becomes one streaming pass
+// (4 B of weight + an L2-resident texel per candidate) instead of a VALU-bound one.
+// Table layout: for (texel o, face s) the entries [offsets[6o+s], +w*h) hold f row-major over the
+// face's AABB, or -1 for candidates outside the cone.  kSwap = false: roles (VNR = o, L = in) as the
+// forward uses them; kSwap = true: (VNR = other, L = o) as the gather-form backward needs them, so
+// that every product is bit-identical to the table-free kernels above.
+// ------------------------------------------------------------------------------------------
+template <bool kSwap>
+__global__ void __launch_bounds__(256)
+specular_weights_kernel(int N, const float4* __restrict__ table, const float* __restrict__ bounds,
+                        const uint32_t* __restrict__ offsets, float roughness, float cutoff,
+                        float* __restrict__ W) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= 6 * N * N) return;
+  const float4 me = table[o];
+  const float alpha = roughness * roughness, alphaSqr = alpha * alpha;
+  const float4* b4 = reinterpret_cast<const float4*>(bounds + 24 * (size_t)o);
+  for (int s = 0; s < 6; ++s) {
+    const float4 b = b4[s];
+    const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
+    if (xmin > xmax || ymin > ymax) continue;
+    const int wd = xmax - xmin + 1, n = wd * (ymax - ymin + 1);
+    const float inv = 1.0f / (float)wd;
+    const uint32_t base = offsets[6 * (size_t)o + s];
+    for (int i = lane; i < n; i += 64) {
+      const int yy = (int)(((float)i + 0.5f) * inv), xx = i - yy * wd;
+      const float4 ot = table[(s * N + ymin + yy) * N + xmin + xx];
+      const float d = kSwap ? (me.x * ot.x + me.y * ot.y + me.z * ot.z) : (ot.x * me.x + ot.y * me.y + ot.z * me.z);
+      float f = -1.0f;
+      if (d >= cutoff) {
+        const float wiDotN = fmaxf(d, 0.0f);
+        const v3 Hh = kSwap ? normalize_exact(v3{me.x + ot.x, me.y + ot.y, me.z + ot.z})
+                            : normalize_exact(v3{ot.x + me.x, ot.y + me.y, ot.z + me.z});
+        const float VNRDotH = fmaxf(kSwap ? (ot.x * Hh.x + ot.y * Hh.y + ot.z * Hh.z)
+                                          : (me.x * Hh.x + me.y * Hh.y + me.z * Hh.z), 0.0f);
+        const float c = fminf(fmaxf(VNRDotH, 0.0f), 1.0f);
+        const float dd = (c * alphaSqr - c) * c + 1.0f;
+        f = wiDotN * (alphaSqr / ((dd * dd) * 3.14159265358979323846f));
+      }
+      W[(size_t)base + i] = f;
+    }
+  }
+}
+
+// forward: out[o] = (sum tex[in] * f * area(in) / 4, sum of weights); backward: g_in[o] = sum g[other].rgb * f * area(o) / 4
+// kNorm: the forward writes rgb / wsum to dst [.,3] and wsum to `wsum_out` (the division
+// ops.py:458 does in torch); the backward then reads a 3-channel gradient that the caller has
+// already divided by wsum.
+template <bool kBackward, bool kNorm>
+__global__ void __launch_bounds__(256)
+specular_apply_kernel(int N, const float4* __restrict__ table, const float* __restrict__ src,
+                      const float* __restrict__ bounds, const uint32_t* __restrict__ offsets,
+                      const float* __restrict__ W, float* __restrict__ dst, float* __restrict__ wsum_out) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= 6 * N * N) return;
+  const float my_area = table[o].w;
+  float wsum = 0.0f, c0 = 0, c1 = 0, c2 = 0;
+  const int stride = (kBackward && !kNorm) ? 4 : 3;
+  const float4* b4 = reinterpret_cast<const float4*>(bounds + 24 * (size_t)o);
+  for (int s = 0; s < 6; ++s) {
+    const float4 b = b4[s];
+    const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
+    if (xmin > xmax || ymin > ymax) continue;
+    const int wd = xmax - xmin + 1, n = wd * (ymax - ymin + 1);
+    const float inv = 1.0f / (float)wd;
+    const float* wrow = W + offsets[6 * (size_t)o + s];
+    for (int i = lane; i < n; i += 64) {
+      const float f = wrow[i];
+      if (f >= 0.0f) {
+        const int yy = (int)(((float)i + 0.5f) * inv), xx = i - yy * wd;
+        const int idx = (s * N + ymin + yy) * N + xmin + xx;
+        const float w = f * (kBackward ? my_area : table[idx].w) / 4.0f;
+        const float* t = src + (size_t)stride * idx;
+        c0 += t[0] * w; c1 += t[1] * w; c2 += t[2] * w;
+        wsum += w;
+      }
+    }
+  }
+  c0 = wave_sum63(c0); c1 = wave_sum63(c1); c2 = wave_sum63(c2);
+  if (!kBackward) wsum = wave_sum63(wsum);
+  if (lane == 63) {
+    if (kBackward) {
+      float* q = dst + 3 * (size_t)o;
+      q[0] = c0; q[1] = c1; q[2] = c2;
+    } else if (kNorm) {
+      float* q = dst + 3 * (size_t)o;
+      q[0] = c0 / wsum; q[1] = c1 / wsum; q[2] = c2 / wsum;
+      wsum_out[o] = wsum;
+    } else {
+      float* q = dst + 4 * (size_t)o;
+      q[0] = c0; q[1] = c1; q[2] = c2; q[3] = wsum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // cube / 2-D texture sampling
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int cube_face_uv(float x, float y, float z, float& u, float& v) {
@@ -749,6 +852,53 @@ int gigs_specular_cubemap_bwd(int res, const float* bounds, const float* grad_ou
   if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
   void* tok; gigs_internal_stage_begin(17, stream, &tok);
   hipLaunchKernelGGL(gigs::specular_cubemap_kernel<true>, dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, grad_out, bounds, roughness, costheta_cutoff, grad_cubemap);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_specular_weights(int res, const float* bounds, const uint32_t* offsets, float roughness,
+                          float costheta_cutoff, int swap_roles, float* weights, void* stream) {
+  if (res <= 0 || !bounds || !offsets || !weights) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_weights: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float4* table = gigs::texel_table(res, s);
+  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
+  const dim3 grid((6 * res * res + 3) / 4);
+  if (swap_roles)
+    hipLaunchKernelGGL(gigs::specular_weights_kernel<true>, grid, dim3(256), 0, s, res, table, bounds, offsets, roughness, costheta_cutoff, weights);
+  else
+    hipLaunchKernelGGL(gigs::specular_weights_kernel<false>, grid, dim3(256), 0, s, res, table, bounds, offsets, roughness, costheta_cutoff, weights);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_specular_cubemap_fwd_w(int res, const float* cubemap, const float* bounds, const uint32_t* offsets,
+                                const float* weights, float* out, float* wsum_out, void* stream) {
+  if (res <= 0 || !cubemap || !bounds || !offsets || !weights || !out) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_fwd_w: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float4* table = gigs::texel_table(res, s);
+  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
+  void* tok; gigs_internal_stage_begin(16, stream, &tok);
+  if (wsum_out)
+    hipLaunchKernelGGL((gigs::specular_apply_kernel<false, true>), dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, cubemap, bounds, offsets, weights, out, wsum_out);
+  else
+    hipLaunchKernelGGL((gigs::specular_apply_kernel<false, false>), dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, cubemap, bounds, offsets, weights, out, (float*)nullptr);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* offsets, const float* weights_swapped,
+                                const float* grad_out, int grad_is_rgb, float* grad_cubemap, void* stream) {
+  if (res <= 0 || !bounds || !offsets || !weights_swapped || !grad_out || !grad_cubemap) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_bwd_w: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float4* table = gigs::texel_table(res, s);
+  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
+  void* tok; gigs_internal_stage_begin(17, stream, &tok);
+  if (grad_is_rgb)
+    hipLaunchKernelGGL((gigs::specular_apply_kernel<true, true>), dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, grad_out, bounds, offsets, weights_swapped, grad_cubemap, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((gigs::specular_apply_kernel<true, false>), dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, grad_out, bounds, offsets, weights_swapped, grad_cubemap, (float*)nullptr);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;

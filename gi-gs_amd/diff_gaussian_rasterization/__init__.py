@@ -225,8 +225,8 @@ def _mark_visible(means3D, viewmatrix, projmatrix):
 def _depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depthMap):
     _need_gpu(depthMap, "depthMap")
     dev = depthMap.device
-    normalMap = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
-    depth_pos = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
+    normalMap = torch.empty((3, height, width), dtype=torch.float32, device=dev)  # every pixel is written
+    depth_pos = torch.empty((3, height, width), dtype=torch.float32, device=dev)
     v, k0 = _fptr(viewmatrix, "viewmatrix")
     d, k1 = _fptr(depthMap, "depthMap")
     with torch.cuda.device(dev):

@@ -2,6 +2,8 @@
 backed by the HIP kernels of libgigs_hip.so instead of the JIT-compiled CUDA plugin."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -52,16 +54,25 @@ def diffuse_cubemap(cubemap, use_python=False):
 
 
 class _specular_cubemap(torch.autograd.Function):
+    """`tables` = None (recompute the pair weights every call, like the reference) or the cached
+    (offsets, weights_fwd, weights_bwd) of `_weight_tables`."""
+
     @staticmethod
-    def forward(ctx, cubemap, roughness, costheta_cutoff, bounds):
+    def forward(ctx, cubemap, roughness, costheta_cutoff, bounds, tables=None):
         c = _gpu(cubemap, "cubemap")
         res = c.shape[1]
         out = torch.empty((6, res, res, 4), dtype=torch.float32, device=c.device)
         with torch.cuda.device(c.device):
-            gigs_lib.check(_lib.gigs_specular_cubemap_fwd(res, c.data_ptr(), bounds.data_ptr(), float(roughness),
-                                                          float(costheta_cutoff), out.data_ptr(), _stream()),
-                           "specular_cubemap_fwd")
+            if tables is None:
+                gigs_lib.check(_lib.gigs_specular_cubemap_fwd(res, c.data_ptr(), bounds.data_ptr(), float(roughness),
+                                                              float(costheta_cutoff), out.data_ptr(), _stream()),
+                               "specular_cubemap_fwd")
+            else:
+                gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(res, c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
+                                                                tables[1].data_ptr(), out.data_ptr(), None, _stream()),
+                               "specular_cubemap_fwd_w")
         ctx.save_for_backward(bounds)
+        ctx.tables = tables
         ctx.res, ctx.roughness, ctx.theta_cutoff = res, roughness, costheta_cutoff
         return out
 
@@ -71,10 +82,15 @@ class _specular_cubemap(torch.autograd.Function):
         d = _gpu(dout, "dout")
         g = torch.empty((6, ctx.res, ctx.res, 3), dtype=torch.float32, device=d.device)
         with torch.cuda.device(d.device):
-            gigs_lib.check(_lib.gigs_specular_cubemap_bwd(ctx.res, bounds.data_ptr(), d.data_ptr(), float(ctx.roughness),
-                                                          float(ctx.theta_cutoff), g.data_ptr(), _stream()),
-                           "specular_cubemap_bwd")
-        return g, None, None, None
+            if ctx.tables is None:
+                gigs_lib.check(_lib.gigs_specular_cubemap_bwd(ctx.res, bounds.data_ptr(), d.data_ptr(), float(ctx.roughness),
+                                                              float(ctx.theta_cutoff), g.data_ptr(), _stream()),
+                               "specular_cubemap_bwd")
+            else:
+                gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
+                                                                ctx.tables[2].data_ptr(), d.data_ptr(), 0, g.data_ptr(),
+                                                                _stream()), "specular_cubemap_bwd_w")
+        return g, None, None, None, None
 
 
 def _ndf_cutoff(roughness: float, cutoff: float) -> float:
@@ -105,6 +121,68 @@ def _ndf_bounds(res, roughness, cutoff, device):
     return _ndfBoundsDict[key]
 
 
+class _specular_cubemap_normalized(torch.autograd.Function):
+    """rgb / wsum in ONE launch (table path): forward = streaming filter + division, backward =
+    (g / wsum) then the gather; replaces kernel + slice + div and their ~10 autograd launches."""
+
+    @staticmethod
+    def forward(ctx, cubemap, bounds, tables):
+        c = _gpu(cubemap, "cubemap")
+        res = c.shape[1]
+        out = torch.empty((6, res, res, 3), dtype=torch.float32, device=c.device)
+        wsum = torch.empty((6, res, res, 1), dtype=torch.float32, device=c.device)
+        with torch.cuda.device(c.device):
+            gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(res, c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
+                                                            tables[1].data_ptr(), out.data_ptr(), wsum.data_ptr(), _stream()),
+                           "specular_cubemap_fwd_w")
+        ctx.save_for_backward(bounds, wsum)
+        ctx.tables, ctx.res = tables, res
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        bounds, wsum = ctx.saved_tensors
+        d = (_gpu(dout, "dout") / wsum).contiguous()  # d(rgb / w) / d(rgb); w does not depend on the cubemap
+        g = torch.empty((6, ctx.res, ctx.res, 3), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
+                                                            ctx.tables[2].data_ptr(), d.data_ptr(), 1, g.data_ptr(), _stream()),
+                           "specular_cubemap_bwd_w")
+        return g, None, None
+
+
+# Cached pair-weight tables (see csrc/pbr.hip): 0.74 GB for the 256..16 chain, x2 for the backward.
+# HBM is 288 GB on MI355X; set GIGS_SPEC_TABLE_MAX_GB=0 to recompute the weights every call instead.
+_TABLE_MAX_BYTES = float(os.environ.get("GIGS_SPEC_TABLE_MAX_GB", "8")) * 1e9
+_weightTables = {}
+
+
+def _weight_tables(res, roughness, cutoff, device):
+    key = (res, roughness, cutoff, str(device))
+    if key not in _weightTables:
+        cos_cut, bounds = _ndf_bounds(res, roughness, cutoff, device)
+        b = bounds.view(-1, 6, 4)
+        w = torch.where(b[..., 0] <= b[..., 1], b[..., 1] - b[..., 0] + 1, torch.zeros_like(b[..., 0]))
+        h = torch.where(b[..., 2] <= b[..., 3], b[..., 3] - b[..., 2] + 1, torch.zeros_like(b[..., 0]))
+        cnt = (w * h).to(torch.int64).reshape(-1)
+        total = int(cnt.sum().item())
+        used = sum(t[1].numel() * 8 for t in _weightTables.values() if t is not None)
+        if total == 0 or total >= 2 ** 31 or used + total * 8 > _TABLE_MAX_BYTES:
+            _weightTables[key] = None
+        else:
+            offsets = (torch.cumsum(cnt, 0) - cnt).to(torch.int32).contiguous()
+            tabs = []
+            with torch.cuda.device(device):
+                for swap in (0, 1):
+                    wt = torch.empty(total, dtype=torch.float32, device=device)
+                    gigs_lib.check(_lib.gigs_specular_weights(res, bounds.data_ptr(), offsets.data_ptr(), float(roughness),
+                                                              float(cos_cut), swap, wt.data_ptr(), _stream()),
+                                   "specular_weights")
+                    tabs.append(wt)
+            _weightTables[key] = (offsets, tabs[0], tabs[1])
+    return _weightTables[key]
+
+
 def specular_cubemap(cubemap, roughness, cutoff=0.99, use_python=False):
     assert cubemap.shape[0] == 6 and cubemap.shape[1] == cubemap.shape[2], \
         "Bad shape for cubemap tensor: %s" % str(cubemap.shape)
@@ -113,7 +191,10 @@ def specular_cubemap(cubemap, roughness, cutoff=0.99, use_python=False):
     if not cubemap.is_cuda:
         raise RuntimeError("cubemap must be a CUDA/HIP tensor: pbr.renderutils (gigs-hip) has no CPU path")
     cos_cut, bounds = _ndf_bounds(cubemap.shape[1], roughness, cutoff, cubemap.device)
-    out = _specular_cubemap.apply(cubemap, roughness, cos_cut, bounds)
+    tables = _weight_tables(cubemap.shape[1], roughness, cutoff, cubemap.device)
+    if tables is not None and not torch.is_anomaly_enabled():
+        return _specular_cubemap_normalized.apply(cubemap, bounds, tables)
+    out = _specular_cubemap.apply(cubemap, roughness, cos_cut, bounds, tables)
     if torch.is_anomaly_enabled():
         assert not torch.isnan(out).any(), "Output of specular_cubemap contains inf or NaN"
     return out[..., 0:3] / out[..., 3:]

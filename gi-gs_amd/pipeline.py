@@ -57,17 +57,10 @@ def make_settings(cam: Dict, sh_degree: int, bg: torch.Tensor, gi: Dict, device,
         debug=debug, inference=inference, argmax_depth=False)
 
 
-def render(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tensor, gi: Dict,
-           inference: bool = False, derive_normal: bool = True, debug=False) -> Dict[str, torch.Tensor]:
-    """gaussian_renderer.render with pad_normal=False."""
-    means3D = g["means3D"]
-    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
-    st = make_settings(cam, sh_degree, bg, gi, means3D.device, inference=inference, debug=debug)
-    (rendered_image, radii, opacity_map, depth_map, normal_map_from_depth, normal_map, occlusion_map, albedo_map,
-     roughness_map, metallic_map, out_normal_view, depth_pos) = GaussianRasterizer(st)(
-        means3D=means3D, means2D=screenspace_points, opacities=g["opacities"], normal=g["normal"], shs=g["shs"],
-        albedo=g["albedo"], roughness=g["roughness"], metallic=g["metallic"], scales=g["scales"],
-        rotations=g["rotations"], derive_normal=derive_normal)
+def gbuffer_post(normal_map_from_depth: torch.Tensor, normal_map: torch.Tensor, out_normal_view: torch.Tensor,
+                 viewmatrix: torch.Tensor):
+    """The tensor post-processing of gaussian_renderer.render (:157-199, pad_normal=False): masks,
+    normalisation, 3x3 medians and the rotation of the shading normal into view space."""
     normal_from_depth_mask = (normal_map_from_depth != 0).all(0)
     normal_mask = (normal_map != 0).all(0, keepdim=True)
     normal_map_from_depth = torch.where(torch.norm(normal_map_from_depth, dim=0, keepdim=True) > 0,
@@ -75,11 +68,35 @@ def render(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tens
     normal_map = torch.where(torch.norm(normal_map, dim=0, keepdim=True) > 0, F.normalize(normal_map, dim=0, p=2),
                              normal_map)
     normal_map = filters.median_blur(normal_map[None, ...], (3, 3))[0]
-    R = st.viewmatrix[:3, :3]
+    R = viewmatrix[:3, :3]
     normals_view = -(normal_map.permute(1, 2, 0) @ R).permute(2, 0, 1)
     out_normal_view = torch.where(torch.norm(out_normal_view, dim=0, keepdim=True) > 0,
                                   F.normalize(out_normal_view, dim=0, p=2), out_normal_view)
     out_normal_view = filters.median_blur(out_normal_view[None, ...], (3, 3))[0]
+    return normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view
+
+
+def rasterize(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tensor, gi: Dict,
+              inference: bool = False, derive_normal: bool = True, debug=False):
+    """The operator call of gaussian_renderer.render (:53-155): returns the raw 12-tuple + means2D."""
+    means3D = g["means3D"]
+    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
+    st = make_settings(cam, sh_degree, bg, gi, means3D.device, inference=inference, debug=debug)
+    out = GaussianRasterizer(st)(
+        means3D=means3D, means2D=screenspace_points, opacities=g["opacities"], normal=g["normal"], shs=g["shs"],
+        albedo=g["albedo"], roughness=g["roughness"], metallic=g["metallic"], scales=g["scales"],
+        rotations=g["rotations"], derive_normal=derive_normal)
+    return out, screenspace_points, st
+
+
+def render(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tensor, gi: Dict,
+           inference: bool = False, derive_normal: bool = True, debug=False) -> Dict[str, torch.Tensor]:
+    """gaussian_renderer.render with pad_normal=False."""
+    ((rendered_image, radii, opacity_map, depth_map, normal_map_from_depth, normal_map, occlusion_map, albedo_map,
+      roughness_map, metallic_map, out_normal_view, depth_pos), screenspace_points, st) = rasterize(
+        cam, g, sh_degree, bg, gi, inference=inference, derive_normal=derive_normal, debug=debug)
+    (normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view) = gbuffer_post(
+        normal_map_from_depth, normal_map, out_normal_view, st.viewmatrix)
     return {
         "render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
         "radii": radii, "opacity_map": opacity_map, "depth_map": depth_map,
@@ -98,46 +115,111 @@ def view_dirs_for(cam: Dict, rays: torch.Tensor, device) -> torch.Tensor:
     return -((F.normalize(rays[:, None, :], p=2, dim=-1) * c2w[None, :3, :3]).sum(dim=-1).reshape(H, W, 3))
 
 
-def stage2_step(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, gi: Dict, light, brdf_lut: torch.Tensor,
-                gt_image: torch.Tensor, rays: torch.Tensor, metallic: bool = True, indirect: bool = True,
-                gamma: bool = False, tone: bool = False) -> Dict[str, torch.Tensor]:
-    """One stage-2 iteration of train.py (:266-422) up to and including loss.backward()."""
-    from pbr import pbr_shading  # HIP-backed drop-in of the reference's pbr package
+class Stage2Front(torch.nn.Module):
+    """train.py:293-379 between the rasterizer and Gaussian_SSR as ONE tensor function: G-buffer
+    post-processing, roughness remap, build_mips, pbr_shading, F0 and the linearised direct light.
+    All shapes are fixed by the resolution, so the module can be captured into a hipGraph."""
 
-    dev = g["means3D"].device
-    background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
-    res = render(cam, g, sh_degree, background, gi, derive_normal=True)
-    H, W = cam["image_height"], cam["image_width"]
-    normal_map, albedo_map = res["normal_map"], res["albedo_map"]
-    roughness_map = res["roughness_map"] * (1.0 - 0.04) + 0.04  # train.py:293-295
-    metallic_map = res["metallic_map"]
-    view_dirs = view_dirs_for(cam, rays, dev)
-    occlusion = (res["occlusion_map"] if indirect else torch.ones_like(roughness_map)).permute(1, 2, 0)
-    normal_mask = res["normal_mask"]
-    light.build_mips()
-    pbr_result = pbr_shading(light=light, normals=normal_map.permute(1, 2, 0).detach(), view_dirs=view_dirs,
-                             mask=normal_mask.permute(1, 2, 0), albedo=albedo_map.permute(1, 2, 0),
-                             roughness=roughness_map.permute(1, 2, 0),
-                             metallic=metallic_map.permute(1, 2, 0) if metallic else None, tone=tone, gamma=gamma,
-                             occlusion=occlusion.detach(), brdf_lut=brdf_lut)
-    render_direct = pbr_result["render_rgb"].permute(2, 0, 1)
-    render_direct = torch.where(normal_mask, render_direct, background[:, None, None])
-    ssr = Gaussian_SSR(cam["tanfovx"], cam["tanfovy"], W, H, gi["radius"], gi["bias"], gi["thick"], gi["delta"],
-                       gi["step"], gi["start"])
-    if metallic:
-        F0 = (1.0 - metallic_map) * 0.04 + albedo_map * metallic_map
-    else:
-        F0 = torch.ones_like(albedo_map) * 0.04
-        metallic_map = torch.zeros_like(roughness_map)
-    linear_rgb = srgb_to_linear(render_direct)
-    (IRR, _) = ssr(res["out_normal_view"].detach(), res["depth_pos"].detach(), linear_rgb.detach(), albedo_map,
-                   roughness_map, metallic_map, F0)
-    IRR = linear_to_srgb(IRR)
+    def __init__(self, light, brdf_lut: torch.Tensor, metallic: bool = True, indirect: bool = True,
+                 tone: bool = False, gamma: bool = False):
+        super().__init__()
+        self.light = light
+        self.register_buffer("brdf_lut", brdf_lut, persistent=False)
+        self.metallic, self.indirect, self.tone, self.gamma = metallic, indirect, tone, gamma
+
+    def forward(self, normal_map_from_depth, normal_map_raw, out_normal_view_raw, albedo_map, roughness_raw,
+                metallic_map, occlusion_map, viewmatrix, view_dirs):
+        from pbr import pbr_shading  # HIP-backed drop-in of the reference's pbr package
+        (_, _, normals_view, normal_mask, out_normal_view) = gbuffer_post(
+            normal_map_from_depth, normal_map_raw, out_normal_view_raw, viewmatrix)
+        roughness_map = roughness_raw * (1.0 - 0.04) + 0.04  # train.py:293-295
+        occlusion = (occlusion_map if self.indirect else torch.ones_like(roughness_map)).permute(1, 2, 0)
+        self.light.build_mips()
+        pbr_result = pbr_shading(light=self.light, normals=normals_view.permute(1, 2, 0).detach(), view_dirs=view_dirs,
+                                 mask=normal_mask.permute(1, 2, 0), albedo=albedo_map.permute(1, 2, 0),
+                                 roughness=roughness_map.permute(1, 2, 0),
+                                 metallic=metallic_map.permute(1, 2, 0) if self.metallic else None, tone=self.tone,
+                                 gamma=self.gamma, occlusion=occlusion.detach(), brdf_lut=self.brdf_lut)
+        render_direct = pbr_result["render_rgb"].permute(2, 0, 1)
+        render_direct = torch.where(normal_mask, render_direct, torch.zeros_like(render_direct))  # black background
+        if self.metallic:
+            F0 = (1.0 - metallic_map) * 0.04 + albedo_map * metallic_map
+            metallic_out = metallic_map
+        else:
+            F0 = torch.ones_like(albedo_map) * 0.04
+            metallic_out = torch.zeros_like(roughness_map)
+        linear_rgb = srgb_to_linear(render_direct).detach()
+        return (render_direct, roughness_map, metallic_out, F0, linear_rgb, out_normal_view.detach(),
+                normal_mask.to(roughness_map.dtype))
+
+
+def stage2_loss(render_direct, IRR_linear, gt_image, normal_mask_f, roughness_map, metallic_map):
+    """train.py:382-402: IRR to sRGB, 3x3 median, L1 against the ground truth, 'lamb' regulariser."""
+    IRR = linear_to_srgb(IRR_linear)
     IRR = filters.median_blur(IRR[None, ...], (3, 3))[0]
     render_rgb = render_direct + IRR
     loss = torch.abs(render_rgb - gt_image).mean()  # utils/loss_utils.l1_loss
-    lamb_loss = (1.0 - roughness_map[normal_mask]).mean() + metallic_map[normal_mask].mean()
-    loss = loss + lamb_loss * 0.001
-    loss.backward()
-    return dict(loss=loss.detach(), render_rgb=render_rgb.detach(), render_direct=render_direct.detach(),
-                IRR=IRR.detach(), viewspace_points=res["viewspace_points"], radii=res["radii"])
+    # train.py:401-402 writes (1 - roughness_map[normal_mask]).mean() + metallic_map[normal_mask].mean();
+    # boolean indexing synchronises with the host (it needs the element count), the masked sums do not
+    cnt = normal_mask_f.sum()
+    lamb_loss = ((1.0 - roughness_map) * normal_mask_f).sum() / cnt + (metallic_map * normal_mask_f).sum() / cnt
+    return loss + lamb_loss * 0.001, render_rgb.detach()
+
+
+class Stage2Step:
+    """One stage-2 iteration of train.py (:266-422) up to and including loss.backward().
+
+    graphs=True captures the two launch-bound glue segments (front: ~120 small kernels + build_mips
+    + shade, and the loss) forward AND backward into hipGraphs with torch.cuda.make_graphed_callables;
+    the rasterizer (data-dependent sizes, one host read) and SSR stay eager so their kernels are timed
+    individually.  Results are identical to graphs=False (same kernels, same order)."""
+
+    def __init__(self, light, brdf_lut, gi: Dict, sh_degree: int, metallic: bool = True, indirect: bool = True,
+                 gamma: bool = False, tone: bool = False, graphs: bool = False):
+        self.gi, self.sh_degree, self.metallic = gi, sh_degree, metallic
+        self.front = Stage2Front(light, brdf_lut, metallic=metallic, indirect=indirect, tone=tone, gamma=gamma)
+        self.loss_fn = stage2_loss
+        self.graphs = graphs
+        self._captured = False
+
+    def _capture(self, front_args, loss_args):
+        def clone(args):
+            return tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
+        self.front = torch.cuda.make_graphed_callables(self.front, clone(front_args), allow_unused_input=True)
+        self.loss_fn = torch.cuda.make_graphed_callables(self.loss_fn, clone(loss_args), allow_unused_input=True)
+        self._captured = True
+
+    def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], gt_image: torch.Tensor, view_dirs: torch.Tensor):
+        dev = g["means3D"].device
+        background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
+        ((_, radii, _, _, normal_map_from_depth, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map,
+          out_normal_view, depth_pos), screenspace_points, st) = rasterize(cam, g, self.sh_degree, background, self.gi)
+        H, W = cam["image_height"], cam["image_width"]
+        gi = self.gi
+        front_args = (normal_map_from_depth, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
+                      occlusion_map.detach(), st.viewmatrix, view_dirs)
+        if self.graphs and not self._captured:
+            # capture needs representative loss inputs: run the front eagerly once
+            with torch.no_grad():
+                o = self.front(*front_args)
+            la = (o[0].clone().requires_grad_(True), torch.zeros_like(o[0]).requires_grad_(True), gt_image,
+                  o[6], o[1].clone().requires_grad_(True), o[2].clone().requires_grad_(True))
+            self._capture(front_args, la)
+        (render_direct, roughness_f, metallic_f, F0, linear_rgb, onv, normal_mask_f) = self.front(*front_args)
+        ssr = Gaussian_SSR(cam["tanfovx"], cam["tanfovy"], W, H, gi["radius"], gi["bias"], gi["thick"], gi["delta"],
+                           gi["step"], gi["start"])
+        (IRR, _) = ssr(onv, depth_pos.detach(), linear_rgb, albedo_map, roughness_f, metallic_f, F0)
+        loss, render_rgb = self.loss_fn(render_direct, IRR, gt_image, normal_mask_f, roughness_f, metallic_f)
+        loss.backward()
+        return dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct.detach(),
+                    IRR=IRR.detach(), viewspace_points=screenspace_points, radii=radii)
+
+
+def stage2_step(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, gi: Dict, light, brdf_lut: torch.Tensor,
+                gt_image: torch.Tensor, rays: torch.Tensor, metallic: bool = True, indirect: bool = True,
+                gamma: bool = False, tone: bool = False, view_dirs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Eager convenience wrapper around Stage2Step (one-off use; bench.py keeps a Stage2Step)."""
+    if view_dirs is None:  # a per-camera constant (train.py:299-308); callers may cache it with the camera
+        view_dirs = view_dirs_for(cam, rays, g["means3D"].device)
+    step = Stage2Step(light, brdf_lut, gi, sh_degree, metallic=metallic, indirect=indirect, gamma=gamma, tone=tone)
+    return step(cam, g, gt_image, view_dirs)

@@ -92,8 +92,8 @@ int gigs_backward(int P, int D, int M, int R, const float* background, int width
 int gigs_mark_visible(int P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present, void* stream);
 
-/* Rasterizer::depthToNormal (rasterizer_impl.cu:201-220 -> forward.cu:914-1032).
- * `normal` and `depth_pos` ([3,H,W]) must be zero-initialised by the caller. */
+/* Rasterizer::depthToNormal (rasterizer_impl.cu:201-220 -> forward.cu:914-1032).  Every pixel of
+ * `normal` and `depth_pos` ([3,H,W]) is written (zeros where the reference leaves its zero fill). */
 int gigs_depth_to_normal(int width, int height, float focal_x, float focal_y,
                          const float* viewmatrix, const float* depth, float* normal,
                          float* depth_pos, void* stream);
@@ -142,6 +142,24 @@ int gigs_specular_cubemap_fwd(int res, const float* cubemap, const float* bounds
                               float costheta_cutoff, float* out, void* stream);
 int gigs_specular_cubemap_bwd(int res, const float* bounds, const float* grad_out, float roughness,
                               float costheta_cutoff, float* grad_cubemap, void* stream);
+/* The same filter through a cached weight table (an MI355X-specific addition, no reference
+ * counterpart): the pair weights depend only on (res, roughness, cutoff), so they are computed once
+ * into `weights` and the per-step filter becomes a streaming pass.  offsets = uint32 [6*res*res*6]
+ * exclusive prefix sums of the per-(texel, face) AABB areas of `bounds`; weights holds that many floats
+ * (+ the last area).  swap_roles = 0 builds the table the forward reads, 1 the one the backward reads
+ * (the NDF argument V.H is evaluated with the reference's operand roles in both, so results are
+ * bit-identical to the table-free entry points up to summation order). */
+int gigs_specular_weights(int res, const float* bounds, const uint32_t* offsets, float roughness,
+                          float costheta_cutoff, int swap_roles, float* weights, void* stream);
+/* wsum_out == NULL: out = [6,res,res,4] (rgb, weight sum) like the table-free entry point;
+ * wsum_out != NULL: out = [6,res,res,3] = rgb / wsum (the division of ops.py:458 folded in) and the
+ * weight sums go to wsum_out [6,res,res].  grad_is_rgb: grad_out is [6,res,res,3] (already divided
+ * by wsum by the caller) instead of [6,res,res,4]. */
+int gigs_specular_cubemap_fwd_w(int res, const float* cubemap, const float* bounds, const uint32_t* offsets,
+                                const float* weights, float* out, float* wsum_out, void* stream);
+int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* offsets,
+                                const float* weights_swapped, const float* grad_out, int grad_is_rgb,
+                                float* grad_cubemap, void* stream);
 /* cubemap_mip (pbr/light.py:54-79): forward 2x2 average pool [6,2r,2r,C] -> [6,r,r,C]; backward =
  * bilinear cube lookup of 0.25*dout at every fine texel direction, dout [6,r,r,3] -> din [6,2r,2r,3]. */
 int gigs_cubemap_mip_fwd(int res_out, int channels, const float* in, float* out, void* stream);
