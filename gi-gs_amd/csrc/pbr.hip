@@ -23,6 +23,7 @@
 //   * pixel-invariant tables (solid angle per texel) are built once on the host with libm and
 //     cached per device.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -321,7 +322,9 @@ specular_weights_kernel(int N, const float4* __restrict__ table, const float* __
                                           : (me.x * Hh.x + me.y * Hh.y + me.z * Hh.z), 0.0f);
         const float c = fminf(fmaxf(VNRDotH, 0.0f), 1.0f);
         const float dd = (c * alphaSqr - c) * c + 1.0f;
-        f = wiDotN * (alphaSqr / ((dd * dd) * 3.14159265358979323846f));
+        // the full pair weight, ((wiDotN * ndf) * area) / 4 as in RU/cubemap.cu:276: area of the input
+        // texel in the forward table, of the gathering texel in the role-swapped (backward) table
+        f = wiDotN * (alphaSqr / ((dd * dd) * 3.14159265358979323846f)) * (kSwap ? me.w : ot.w) / 4.0f;
       }
       W[(size_t)base + i] = f;
     }
@@ -337,13 +340,14 @@ __global__ void __launch_bounds__(256)
 specular_apply_kernel(int N, const float4* __restrict__ table, const float* __restrict__ src,
                       const float* __restrict__ bounds, const uint32_t* __restrict__ offsets,
                       const float* __restrict__ W, float* __restrict__ dst, float* __restrict__ wsum_out) {
+  (void)table;
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (o >= 6 * N * N) return;
-  const float my_area = table[o].w;
   float wsum = 0.0f, c0 = 0, c1 = 0, c2 = 0;
   const int stride = (kBackward && !kNorm) ? 4 : 3;
   const float4* b4 = reinterpret_cast<const float4*>(bounds + 24 * (size_t)o);
+  constexpr int kU = 4;  // candidates per lane in flight: the pass is latency-bound, not bandwidth-bound
   for (int s = 0; s < 6; ++s) {
     const float4 b = b4[s];
     const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
@@ -351,15 +355,30 @@ specular_apply_kernel(int N, const float4* __restrict__ table, const float* __re
     const int wd = xmax - xmin + 1, n = wd * (ymax - ymin + 1);
     const float inv = 1.0f / (float)wd;
     const float* wrow = W + offsets[6 * (size_t)o + s];
-    for (int i = lane; i < n; i += 64) {
-      const float f = wrow[i];
-      if (f >= 0.0f) {
+    const int face_base = (s * N + ymin) * N + xmin;
+    for (int i0 = lane; i0 < n; i0 += 64 * kU) {
+      float w[kU];
+      int idx[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        const int i = i0 + 64 * u;
+        w[u] = i < n ? wrow[i] : -1.0f;
         const int yy = (int)(((float)i + 0.5f) * inv), xx = i - yy * wd;
-        const int idx = (s * N + ymin + yy) * N + xmin + xx;
-        const float w = f * (kBackward ? my_area : table[idx].w) / 4.0f;
-        const float* t = src + (size_t)stride * idx;
-        c0 += t[0] * w; c1 += t[1] * w; c2 += t[2] * w;
-        wsum += w;
+        idx[u] = face_base + yy * N + xx;
+      }
+      float t0[kU], t1[kU], t2[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        const bool ok = w[u] >= 0.0f;  // -1 marks candidates outside the cone (never read, as in the reference)
+        const float* t = src + (size_t)stride * (ok ? idx[u] : face_base);
+        t0[u] = t[0]; t1[u] = t[1]; t2[u] = t[2];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        if (w[u] >= 0.0f) {
+          c0 += t0[u] * w[u]; c1 += t1[u] * w[u]; c2 += t2[u] * w[u];
+          wsum += w[u];
+        }
       }
     }
   }
@@ -511,6 +530,11 @@ struct ShadeArgs {
   int L; const float* spec[8]; int spec_res[8];
   const float* lut; int lut_w, lut_h;
   int tone, gamma;
+  int ablate;  // diagnostic only (env GIGS_ABLATE): bit 0 skips the diffuse-map atomics, bit 1 the specular ones
+  // backward: gradient textures small enough to be accumulated per workgroup in LDS
+  int lds_total;        // floats of dynamic LDS
+  int lds_diffuse_off;  // offset (floats) of the diffuse-map accumulator, or -1
+  int lds_spec_off[8];  // per specular level, or -1
   // forward outputs
   float *render_rgb, *diffuse_rgb, *specular_rgb, *diffuse_light;
   // backward inputs (may be null) and outputs
@@ -644,7 +668,8 @@ shade_fwd_kernel(ShadeArgs A) {
   A.diffuse_light[3 * p] = q.dl.x; A.diffuse_light[3 * p + 1] = q.dl.y; A.diffuse_light[3 * p + 2] = q.dl.z;
 }
 
-constexpr int kMaxDiffuseLds = 6 * 16 * 16 * 3;  // diffuse cube gradients staged in LDS up to 16x16
+constexpr int kShadeBwdBlock = 1024;     // 16 waves share one set of LDS accumulators
+constexpr int kShadeLdsBudget = 30 * 1024;  // floats (120 KB of the CU's 160 KB)
 
 // Scatter-add of one RGB triple per lane into a texture gradient, with neighbouring lanes that
 // hit the SAME texel summed first: neighbouring pixels usually share bilinear taps, and 64
@@ -680,15 +705,17 @@ __device__ __forceinline__ void run_add3(float* target, int key, float v0, float
   }
 }
 
-__global__ void __launch_bounds__(256)
+// Gradients of the light textures: hundreds of thousands of pixels add into a few thousand texels of
+// the coarse levels (16^2 diffuse, 16^2 / 32^2 specular), which serialises memory-side float atomics on
+// the same addresses (measured: 0.72 of 0.77 ms).  Every level that fits is therefore accumulated per
+// 1024-lane workgroup in LDS (up to 120 KB) and flushed once, non-zero entries only; larger levels take
+// global atomics.  In both cases neighbouring lanes hitting the same texel are pre-summed (run_add3).
+__global__ void __launch_bounds__(kShadeBwdBlock)
 shade_bwd_kernel(ShadeArgs A) {
-  __shared__ float s_dd[kMaxDiffuseLds];
-  const int n_dd = 6 * A.diffuse_res * A.diffuse_res * 3;
-  const bool use_lds = n_dd <= kMaxDiffuseLds;
-  if (use_lds)
-    for (int i = threadIdx.x; i < n_dd; i += 256) s_dd[i] = 0.0f;
+  extern __shared__ __align__(16) float s_lds[];
+  for (int i = threadIdx.x; i < A.lds_total; i += kShadeBwdBlock) s_lds[i] = 0.0f;
   __syncthreads();
-  const int pg = blockIdx.x * 256 + threadIdx.x;
+  const int pg = blockIdx.x * kShadeBwdBlock + threadIdx.x;
   const bool live = pg < A.H * A.W;
   const int p = live ? pg : 0;  // dead lanes shade pixel 0 and add nothing: the DPP scans need every lane
   ShadePix q;
@@ -747,19 +774,21 @@ shade_bwd_kernel(ShadeArgs A) {
     A.d_roughness[p] = d_fgx * q.dfgx_dv + d_fgy * q.dfgy_dv + (q.lvl_inside ? d_lvl * q.dmdr : 0.0f);
   }
   // ---- light textures (wave-uniform control flow from here on) ----
-  if (A.d_diffuse) {
+  if (A.d_diffuse && !(A.ablate & 1)) {
+    float* base = A.lds_diffuse_off >= 0 ? s_lds + A.lds_diffuse_off : A.d_diffuse;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int idx = (live && q.has_d) ? q.td.idx[k] : -1;
       const float w = idx >= 0 ? q.td.w[k] * q.occ : 0.0f;
-      if (use_lds) run_add3<true>(s_dd + 3 * max(idx, 0), idx, g_dl[0] * w, g_dl[1] * w, g_dl[2] * w);
-      else run_add3<false>(A.d_diffuse + 3 * (size_t)max(idx, 0), idx, g_dl[0] * w, g_dl[1] * w, g_dl[2] * w);
+      run_add3<false>(base + 3 * (size_t)max(idx, 0), idx, g_dl[0] * w, g_dl[1] * w, g_dl[2] * w);
     }
   }
-  {
+  if (!(A.ablate & 2)) {
     const float wl = (q.l1 != q.l0) ? (1 - q.lf) : 1.0f;
-    float* t0 = A.d_spec[q.l0];
-    float* t1 = A.d_spec[q.l1];
+    float* t0 = A.lds_spec_off[q.l0] >= 0 ? s_lds + A.lds_spec_off[q.l0] : A.d_spec[q.l0];
+    float* t1 = A.lds_spec_off[q.l1] >= 0 ? s_lds + A.lds_spec_off[q.l1] : A.d_spec[q.l1];
+    if (!A.d_spec[q.l0]) t0 = nullptr;
+    if (!A.d_spec[q.l1]) t1 = nullptr;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int idx = (live && q.has0 && t0) ? q.t0.idx[k] : -1;
@@ -773,11 +802,22 @@ shade_bwd_kernel(ShadeArgs A) {
       run_add3<false>(t1 ? t1 + 3 * (size_t)max(idx, 0) : nullptr, idx >= 0 ? (q.l1 << 24) | idx : -1, g_sp[0] * w, g_sp[1] * w, g_sp[2] * w);
     }
   }
-  if (use_lds && A.d_diffuse) {
+  if (A.lds_total > 0) {
     __syncthreads();
-    for (int i = threadIdx.x; i < n_dd; i += 256) {
-      const float val = s_dd[i];
-      if (val != 0.0f) atomicAdd(A.d_diffuse + i, val);
+    if (A.lds_diffuse_off >= 0 && A.d_diffuse) {
+      const int n = 6 * A.diffuse_res * A.diffuse_res * 3;
+      for (int i = threadIdx.x; i < n; i += kShadeBwdBlock) {
+        const float val = s_lds[A.lds_diffuse_off + i];
+        if (val != 0.0f) atomicAdd(A.d_diffuse + i, val);
+      }
+    }
+    for (int l = 0; l < A.L; l++) {
+      if (A.lds_spec_off[l] < 0 || !A.d_spec[l]) continue;
+      const int n = 6 * A.spec_res[l] * A.spec_res[l] * 3;
+      for (int i = threadIdx.x; i < n; i += kShadeBwdBlock) {
+        const float val = s_lds[A.lds_spec_off[l] + i];
+        if (val != 0.0f) atomicAdd(A.d_spec[l] + i, val);
+      }
     }
   }
 }
@@ -942,6 +982,8 @@ static int fill_shade(gigs::ShadeArgs& A, int H, int W, const float* normals, co
     A.spec_res[i] = spec_res[i];
   }
   A.lut = lut; A.lut_w = lut_w; A.lut_h = lut_h; A.tone = tone; A.gamma = gamma;
+  const char* ab = getenv("GIGS_ABLATE");
+  A.ablate = ab ? atoi(ab) : 0;
   return 0;
 }
 
@@ -980,8 +1022,27 @@ int gigs_shade_bwd(int H, int W, const float* normals, const float* view_dirs, c
   A.g_render = g_render; A.g_diffuse_rgb = g_diffuse_rgb; A.g_specular_rgb = g_specular_rgb; A.g_diffuse_light = g_diffuse_light;
   A.d_albedo = d_albedo; A.d_roughness = d_roughness; A.d_metallic = d_metallic; A.d_diffuse = d_diffuse;
   for (int i = 0; i < n_levels; i++) A.d_spec[i] = d_spec ? d_spec[i] : nullptr;
+  // LDS plan: the diffuse map first, then specular levels from the coarsest up while they fit
+  int used = 0;
+  A.lds_diffuse_off = -1;
+  for (int i = 0; i < 8; i++) A.lds_spec_off[i] = -1;
+  const int n_dd = 6 * diffuse_res * diffuse_res * 3;
+  if (d_diffuse && n_dd <= gigs::kShadeLdsBudget) { A.lds_diffuse_off = 0; used = n_dd; }
+  for (int i = n_levels - 1; i >= 0; i--) {
+    const int n = 6 * spec_res[i] * spec_res[i] * 3;
+    if (A.d_spec[i] && used + n <= gigs::kShadeLdsBudget) { A.lds_spec_off[i] = used; used += n; }
+  }
+  A.lds_total = used;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gigs::shade_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            gigs::kShadeLdsBudget * (int)sizeof(float)) != hipSuccess)
+      return gigs_internal_fail(GIGS_ERR_HIP, "shade_bwd: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
   void* tok; gigs_internal_stage_begin(15, stream, &tok);
-  hipLaunchKernelGGL(gigs::shade_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, A);
+  hipLaunchKernelGGL(gigs::shade_bwd_kernel, dim3((H * W + gigs::kShadeBwdBlock - 1) / gigs::kShadeBwdBlock),
+                     dim3(gigs::kShadeBwdBlock), (size_t)used * sizeof(float), (hipStream_t)stream, A);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;
