@@ -23,6 +23,7 @@
 //     chip handles at full rate), skipping zero entries.  This replaces the reference's 21
 //     same-address atomics per (pixel, Gaussian) pair.
 //   No MFMA: the per-pair work is a scalar recurrence over depth-ordered Gaussians.
+#include <cstdlib>
 #include "gigs_common.h"
 
 namespace gigs {
@@ -46,6 +47,31 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// Conservative test "no pixel centre of the 8x8 quadrant can pass `alpha >= 1/255`" for one Gaussian.
+// (u0, v0) = mean2D - first pixel centre of the quadrant, so d = mean - pix ranges over
+// [u0-7, u0] x [v0-7, v0]; the exponent -power = Q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy is convex when the
+// conic is positive definite, and its minimum over the box is 0 (centre inside) or lies on one of the four
+// edges.  alpha >= 1/255 needs Q <= log(255 * opacity); the comparison carries a slack far above the fp32
+// error of both this bound and the kernel's own evaluation of `power`, so a culled Gaussian is one that
+// the reference's per-pixel tests (forward.cu:533-541) would have skipped for every pixel of the quadrant.
+__device__ __forceinline__ bool quadrant_never_blends(float u0, float v0, float A, float B, float C, float op) {
+  if (op < 1.0f / 255.0f) return true;  // alpha <= opacity * exp(power <= 0)
+  if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f)) return false;
+  const float ua = u0 - 7.0f, ub = u0, va = v0 - 7.0f, vb = v0;
+  if (ua <= 0.0f && ub >= 0.0f && va <= 0.0f && vb >= 0.0f) return false;
+  const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
+  auto f = [&](float u, float v) { return 0.5f * (A * u * u + C * v * v) + B * u * v; };
+  const float q1 = f(ua, fminf(fmaxf(-B * ua * iC, va), vb));
+  const float q2 = f(ub, fminf(fmaxf(-B * ub * iC, va), vb));
+  const float q3 = f(fminf(fmaxf(-B * va * iA, ua), ub), va);
+  const float q4 = f(fminf(fmaxf(-B * vb * iA, ua), ub), vb);
+  const float qmin = fminf(fminf(q1, q2), fminf(q3, q4));
+  const float um = fmaxf(fabsf(ua), fabsf(ub)), vm = fmaxf(fabsf(va), fabsf(vb));
+  const float smax = 0.5f * (A * um * um + C * vm * vm) + fabsf(B) * um * vm;
+  const float tau = __logf(255.0f * op);
+  return qmin > tau + 1e-5f * smax + 1e-2f;  // false for NaN
+}
+
 struct BlendOut {
   float *color, *opacity, *depth, *normal, *normal_view, *pos, *albedo, *roughness, *metallic;
 };
@@ -55,8 +81,9 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ brec,
                  const float* __restrict__ viewmatrix, const float* __restrict__ bg_color,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, BlendOut o,
-                 int argmax_depth, int inference) {
+                 int argmax_depth, int inference, uint8_t* __restrict__ hit_mask, int cull) {
   __shared__ float4 s_rec[GIGS_BREC_F4 * kBatch];  // [k][j], 20 KB
+  __shared__ unsigned long long s_hit[4 * (kBatch / 64)];  // [wave][chunk] contribution bits of the batch
 
   const unsigned tile = blockIdx.x;
   const unsigned ty = tile / gx, tx = tile - ty * gx;
@@ -73,11 +100,15 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   int toDo = range.y - range.x;
 
   float T = 1.0f;
-  uint32_t contributor = 0, last_contributor = 0;
+  uint32_t last_contributor = 0;
   float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, A0 = 0, A1 = 0, A2 = 0;
   float Rr = 0, Mm = 0, O = 0, P0 = 0, P1 = 0, P2 = 0;  // P2 doubles as D (depth == pos_view.z)
   float max_weight = 0.0f, e0 = 0, e1 = 0, e2 = 0;
 
+  // Instances of batches that are never fetched (every pixel done) contribute nowhere: their mask is 0.
+  for (uint32_t k = range.x + tid; k < range.y; k += GIGS_TILE) hit_mask[k] = 0;
+  // pixel-centre box of this wave's quadrant
+  const float qx0 = (float)(tx * GIGS_BLOCK_X + (wave & 1) * 8), qy0 = (float)(ty * GIGS_BLOCK_Y + (wave >> 1) * 8);
   for (int i = 0; i < rounds; i++, toDo -= kBatch) {
     const int num_done = __syncthreads_count(done);
     if (num_done == GIGS_TILE) break;
@@ -91,37 +122,68 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
     __syncthreads();
 
     const int n = min(kBatch, toDo);
-    for (int j = 0; !done && j < n; j++) {
-      contributor++;
-      const float4 r0 = s_rec[j];           // mean2D.xy, roughness, metallic
-      const float4 r1 = s_rec[kBatch + j];  // conic xyz, opacity
-      const float dx = r0.x - pixfx, dy = r0.y - pixfy;
-      const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-      if (power > 0.0f) continue;
-      const float alpha = fminf(0.99f, r1.w * expf(power));
-      if (alpha < 1.0f / 255.0f) continue;
-      const float test_T = T * (1 - alpha);
-      if (test_T < 0.0001f) {
-        done = true;
-        continue;
+    unsigned long long hits[kBatch / 64] = {0ull, 0ull, 0ull, 0ull};
+    bool wave_done = __ballot(!done) == 0ull;
+#pragma unroll
+    for (int c = 0; c < kBatch / 64; c++) {
+      if (wave_done || c * 64 >= n) continue;
+      // instance-parallel cull: lane l tests instance c*64+l against the quadrant, the wave then walks
+      // only the surviving bits (in list order, so the blend order is unchanged)
+      unsigned long long m;
+      {
+        const int jj = c * 64 + lane;
+        const float4 q0 = s_rec[jj], q1 = s_rec[kBatch + jj];
+        m = __ballot(jj < n && !(cull && quadrant_never_blends(q0.x - qx0, q0.y - qy0, q1.x, q1.y, q1.z, q1.w)));
       }
-      const float weight = alpha * T;
-      const float4 r2 = s_rec[2 * kBatch + j];  // rgb, pos.x
-      const float4 r3 = s_rec[3 * kBatch + j];  // normal, pos.y
-      const float4 r4 = s_rec[4 * kBatch + j];  // albedo, pos.z
-      C0 += r2.x * weight; C1 += r2.y * weight; C2 += r2.z * weight;
-      A0 += r4.x * weight; A1 += r4.y * weight; A2 += r4.z * weight;
-      N0 += r3.x * weight; N1 += r3.y * weight; N2 += r3.z * weight;
-      Rr += r0.z * weight;
-      Mm += r0.w * weight;
-      P0 += r2.w * weight; P1 += r3.w * weight; P2 += r4.w * weight;
-      O += weight;
-      if (weight > max_weight) {
-        e0 = r2.w; e1 = r3.w; e2 = r4.w;
-        max_weight = weight;
+      while (m != 0ull) {
+        const int bit = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const int j = c * 64 + bit;
+        const float4 r0 = s_rec[j];           // mean2D.xy, roughness, metallic
+        const float4 r1 = s_rec[kBatch + j];  // conic xyz, opacity
+        const float dx = r0.x - pixfx, dy = r0.y - pixfy;
+        const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+        // same decisions as the reference's `continue` chain (forward.cu:533-547), kept as predicates so
+        // that the wave can record whether ANY of its pixels blends this Gaussian
+        const float alpha = fminf(0.99f, r1.w * expf(power));
+        const float test_T = T * (1 - alpha);
+        const bool cand = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        const bool stop = cand && test_T < 0.0001f;
+        const bool contrib = cand && !stop;
+        if (stop) done = true;
+        if (__ballot(contrib) != 0ull) hits[c] |= 1ull << bit;
+        if (contrib) {
+          const float weight = alpha * T;
+          const float4 r2 = s_rec[2 * kBatch + j];  // rgb, pos.x
+          const float4 r3 = s_rec[3 * kBatch + j];  // normal, pos.y
+          const float4 r4 = s_rec[4 * kBatch + j];  // albedo, pos.z
+          C0 += r2.x * weight; C1 += r2.y * weight; C2 += r2.z * weight;
+          A0 += r4.x * weight; A1 += r4.y * weight; A2 += r4.z * weight;
+          N0 += r3.x * weight; N1 += r3.y * weight; N2 += r3.z * weight;
+          Rr += r0.z * weight;
+          Mm += r0.w * weight;
+          P0 += r2.w * weight; P1 += r3.w * weight; P2 += r4.w * weight;
+          O += weight;
+          if (weight > max_weight) {
+            e0 = r2.w; e1 = r3.w; e2 = r4.w;
+            max_weight = weight;
+          }
+          T = test_T;
+          last_contributor = (uint32_t)(i * kBatch + j + 1);
+        }
+        if (__ballot(stop) != 0ull && __ballot(!done) == 0ull) { wave_done = true; break; }
       }
-      T = test_T;
-      last_contributor = contributor;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < kBatch / 64; c++) s_hit[wave * (kBatch / 64) + c] = hits[c];
+    }
+    __syncthreads();
+    if (range.x + progress < range.y) {
+      uint32_t byte = 0;
+#pragma unroll
+      for (int w = 0; w < 4; w++) byte |= (uint32_t)((s_hit[w * (kBatch / 64) + wave] >> lane) & 1ull) << w;
+      hit_mask[range.x + progress] = (uint8_t)byte;
     }
   }
 
@@ -161,9 +223,12 @@ void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& 
                       float* out_albedo, float* out_roughness, float* out_metallic, hipStream_t s) {
   BlendOut o{out_color, out_opacity, out_depth, out_normal, out_normal_view,
              out_pos, out_albedo, out_roughness, out_metallic};
+  // GIGS_BLEND_CULL=0 disables the quadrant cull (diagnostic: the outputs must not change by a bit)
+  const char* e = getenv("GIGS_BLEND_CULL");
+  const int cull = !(e && e[0] == '0');
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(a.gx * a.gy), dim3(GIGS_TILE), 0, s, a.W, a.H, a.gx,
                      im.ranges, b.point_list, g.brec, a.viewmatrix, a.background, im.n_contrib,
-                     im.final_T, o, a.argmax_depth, a.inference);
+                     im.final_T, o, a.argmax_depth, a.inference, b.hit_mask, cull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -175,9 +240,11 @@ __global__ void __launch_bounds__(GIGS_TILE)
 blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ brec,
                  const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
-                 const uint32_t* __restrict__ n_contrib, BlendGradIn gi, float* __restrict__ grec) {
+                 const uint32_t* __restrict__ n_contrib, BlendGradIn gi, float* __restrict__ grec,
+                 const uint8_t* __restrict__ hit_mask) {
   __shared__ float4 s_rec[3 * kBatch];       // [k][j] k = 0..2 (mean2D, conic/opacity, rgb)
   __shared__ uint32_t s_id[kBatch];
+  __shared__ uint32_t s_hit[kBatch];
   __shared__ float s_acc[kBatch * GIGS_GREC];  // 20 KB, [j][20]
 
   const unsigned tile = blockIdx.x;
@@ -196,7 +263,6 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
 
   const float T_final = inside ? final_Ts[pix_id] : 0;
   float T = T_final;
-  uint32_t contributor = toDo;  // wave-uniform
   const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
 
   float last_alpha = 0.0f, accum_opacity = 0.0f;
@@ -232,6 +298,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
     if (range.x + progress < range.y) {
       const uint32_t coll_id = point_list[range.y - progress - 1];
       s_id[tid] = coll_id;
+      s_hit[tid] = hit_mask[range.y - progress - 1];
       const float4* src = brec + (size_t)coll_id * GIGS_BREC_F4;
 #pragma unroll
       for (int k = 0; k < 3; k++) s_rec[k * kBatch + tid] = src[k];
@@ -244,19 +311,22 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
     __syncthreads();
 
     const int n = min(kBatch, toDo);
-    for (int j = 0; j < n; j++) {
-      contributor--;
-      bool act = inside && ((int)contributor < last_contributor);
-      if (!__any(act)) continue;
+    // the forward recorded which quadrants blended each instance (same tests, same expf): the wave walks only
+    // the instances whose bit is set for its quadrant, newest first
+#pragma unroll 1
+    for (int c = 0; c < kBatch / 64; c++) {
+      unsigned long long m = __ballot(c * 64 + lane < n && ((s_hit[c * 64 + lane] >> wave) & 1u) != 0u);
+      while (m != 0ull) {
+      const int j = c * 64 + __builtin_ctzll(m);
+      m &= m - 1ull;
+      const int contributor = toDo - 1 - j;  // index of the instance in the tile list
       const float4 r0 = s_rec[j];
       const float4 r1 = s_rec[kBatch + j];
       const float dx = r0.x - pixfx, dy = r0.y - pixfy;
       const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-      act = act && !(power > 0.0f);
       const float G = expf(power);
       const float alpha = fminf(0.99f, r1.w * G);
-      act = act && !(alpha < 1.0f / 255.0f);
-      if (!__any(act)) continue;
+      const bool act = inside && (contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 
       float v[19];
 #pragma unroll
@@ -324,6 +394,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
         v[18] = wave_sum_lane63(v[18]);
         if (lane == 63) atomicAdd(acc + 18, v[18]);
       }
+      }
     }
     __syncthreads();
     // flush: consecutive lanes -> consecutive floats of consecutive 80-byte rows
@@ -344,7 +415,7 @@ void launch_blend_bwd(const BwdArgs& a, const GeomState& g, const BinningState& 
                  a.dL_dpix_albedo, a.dL_dpix_roughness, a.dL_dpix_metallic};
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.gx * a.gy), dim3(GIGS_TILE), 0, s, a.W, a.H, a.gx,
                      im.ranges, b.point_list, g.brec, a.background, im.final_T,
-                     im.n_contrib, gi, g.grec);
+                     im.n_contrib, gi, g.grec, b.hit_mask);
 }
 
 }  // namespace gigs

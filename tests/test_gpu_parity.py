@@ -207,6 +207,33 @@ def test_forward_edge_cases(orc):
         hip_raw_forward(dgr, sc2, cam)
 
 
+def test_forward_quadrant_cull_is_exact(orc, monkeypatch):
+    """The blend kernel skips (Gaussian, 8x8 quadrant) pairs a conservative ellipse/box bound proves empty.
+    Needle-shaped, mostly faint Gaussians (opacity around the 1/255 threshold) are the adversarial case:
+    parity with the oracle as usual, and switching the cull off must not change a single bit of the
+    per-pixel state or of any output plane (same kernel, same expf)."""
+    rng = np.random.default_rng(7)
+    sc = scenes.random_scene(P=6000, sh_degree=0, seed=7, scale_mu=0.06)
+    sc["scales"] = np.ascontiguousarray(
+        sc["scales"] * np.exp(rng.uniform(-3.0, 1.5, size=sc["scales"].shape)), dtype=np.float32)
+    sc["opacities"] = np.ascontiguousarray(
+        np.where(rng.uniform(size=(6000, 1)) < 0.5, rng.uniform(0.002, 0.02, size=(6000, 1)),
+                 rng.uniform(0.02, 1.0, size=(6000, 1))), dtype=np.float32)
+    cam = scenes.orbit_camera(3, 7, 240, 176)
+    dgr = _dgr()
+    _, _, res, _ = check_forward(orc, sc, cam, tag="needles ")
+    sv = scratch_views(dgr, res, 6000, 240, 176)
+    hp = hip_planes(res)
+    monkeypatch.setenv("GIGS_BLEND_CULL", "0")
+    res0 = hip_raw_forward(dgr, sc, cam, bg=(0.1, 0.3, 0.2))
+    sv0 = scratch_views(dgr, res0, 6000, 240, 176)
+    hp0 = hip_planes(res0)
+    for k in ("n_contrib", "final_T"):
+        np.testing.assert_array_equal(sv[k].view(np.uint32), sv0[k].view(np.uint32), err_msg=k)
+    for k in PLANES:
+        np.testing.assert_array_equal(hp[k].view(np.uint32), hp0[k].view(np.uint32), err_msg=k)
+
+
 def test_mark_visible(orc):
     dgr = _dgr()
     sc, cam = small_scene(P=5000, sh_degree=0)
