@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
     "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-DNDEBUG",
-]
+] + os.environ.get("GIGS_EXTRA_FLAGS", "").split()
 
 
 def _deps(src: str):

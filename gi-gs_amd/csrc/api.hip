@@ -418,6 +418,7 @@ int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius,
               float thick, float delta, int step, int start, const float* normal_view,
               const float* pos, float* occlusion, void* stream) {
   if (width <= 0 || height <= 0 || !normal_view || !pos || !occlusion) return fail(GIGS_ERR_INVALID, "bad argument");
+  if (width >= (1 << 15) || height >= (1 << 15)) return fail(GIGS_ERR_INVALID, "image side above 32767 pixels");
   StageScope sc(kSsao, (hipStream_t)stream);
   const int rc = gigs::launch_ssao(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
                                    normal_view, pos, occlusion, (hipStream_t)stream);
@@ -433,6 +434,7 @@ int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, 
              const float* metallic, const float* F0, float* color, float* abd, void* stream) {
   if (width <= 0 || height <= 0 || !normal_view || !pos || !rgb || !albedo || !metallic || !F0 || !color || !abd)
     return fail(GIGS_ERR_INVALID, "bad argument");
+  if (width >= (1 << 15) || height >= (1 << 15)) return fail(GIGS_ERR_INVALID, "image side above 32767 pixels");
   StageScope sc(kSsr, (hipStream_t)stream);
   const int rc = gigs::launch_ssr(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
                                   normal_view, pos, rgb, albedo, roughness, metallic, F0, color, abd, (hipStream_t)stream);

@@ -25,6 +25,7 @@
 //   * SSR reads the rgb planes only on a hit (the reference reads them every step but uses
 //     them only on a hit: forward.cu:820-826).
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -169,6 +170,7 @@ struct GiParams {
   int step, start;
   float inv_step;  // exact 1/step when step is a power of two
   int nrays;
+  int tile_log2w;  // the 64 pixels of a workgroup form a (1 << tile_log2w) x (64 >> tile_log2w) rectangle
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -217,6 +219,59 @@ __device__ __forceinline__ f32x2 div2_fast(f32x2 n, float d) {
 // that trunc(t + copysign(0.5 - 2^-25, t)) rounds half away from zero like roundf.
 __device__ __forceinline__ int round_to_int(float t) { return f2i(t + copysignf(0.49999997f, t)); }
 
+// Sample coordinates of one group of steps for kRays rays: byte offset into the z plane (0 when the sample
+// is outside the image), the in-image flag and the sample's z.  kExact = false uses the shared-reciprocal
+// FMA chain for every lane and returns the smallest |den| seen, so that the caller can decide ONCE per
+// group whether any lane needed the IEEE slow path; kExact = true re-evaluates with per-lane selection.
+template <bool kPow2, int kGroup, int kRays, bool kExact>
+__device__ __forceinline__ float group_coords(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
+                                              bool mag_ok, int j0, unsigned (*off)[kGroup], bool (*inb)[kGroup],
+                                              float (*spzv)[kGroup]) {
+  const f32x2 posxy = {pos.x, pos.y}, fxy = {p.fx, p.fy}, cxy = {cx, cy};
+  float min_den = __builtin_inff();
+#pragma unroll
+  for (int g = 0; g < kGroup; g++) {
+    const float fj = (float)(j0 + g);
+    const bool in_range = (j0 + g) < p.step;
+#pragma unroll
+    for (int k = 0; k < kRays; k++) {
+      // pos + sampleVec * j * (1 + z/100) * (1 + z/100) * radius / step, left to right (forward.cu:693)
+      f32x2 m = f32x2{sv[k].x, sv[k].y} * fj;
+      float mz = sv[k].z * fj;
+      m = m * a; mz = mz * a;
+      m = m * a; mz = mz * a;
+      m = m * p.radius; mz = mz * p.radius;
+      if (kPow2) {
+        m = m * p.inv_step; mz = mz * p.inv_step;
+      } else {
+        const float fs = (float)p.step;
+        m = f32x2{m.x / fs, m.y / fs}; mz = mz / fs;
+      }
+      const f32x2 sp = posxy + m;
+      const float spz = pos.z + mz;
+      // get_coord (ssr.h:120-135)
+      const float den = spz + 0.0000001f;
+      f32x2 qv = div2_fast(sp, den);
+      if (kExact) {
+        if (!(mag_ok && fabsf(den) > 0x1p-60f)) qv = f32x2{sp.x / den, sp.y / den};
+      } else {
+        min_den = fminf(min_den, fabsf(den));  // a NaN den is not recorded: both paths then give NaN -> pixel (0, 0)
+      }
+      const f32x2 t = qv * fxy + cxy;
+      const int ix = round_to_int(t.x);
+      const int iy = round_to_int(t.y);
+      inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+      // The gather address is clamped into the image instead of predicated (an out-of-image sample is
+      // never used: inb is false).  W, H < 2^15 (checked by the C-ABI wrapper): 24-bit multiply, and the
+      // byte offset fits 32 bits so the load takes the scalar-base + 32-bit-offset form.
+      const unsigned cxi = min((unsigned)ix, (unsigned)(p.W - 1)), cyi = min((unsigned)iy, (unsigned)(p.H - 1));
+      off[k][g] = (__umul24(cyi, (unsigned)p.W) + cxi) << 2;
+      spzv[k][g] = spz;
+    }
+  }
+  return min_den;
+}
+
 // Marches kRays rays of one pixel together; hit[k] = pixel index of ray k's hit or -1.
 // The reference walks j = start..step-1 per ray and stops at the first sample that leaves the image
 // or hits (forward.cu:691-714).  ~98 % of the rays of a real frame run all their steps, so:
@@ -225,71 +280,50 @@ __device__ __forceinline__ int round_to_int(float t) { return f2i(t + copysignf(
 //     dependent L2 round trip per step;
 //   * the group is then resolved IN ORDER with per-lane selects, not branches (`open` = ray still
 //     marching), which is exactly the sequential outcome; the only branches left are wave-uniform
-//     (all rays of the wave resolved; rare IEEE-division slow path), so the scalar unit is not
-//     spent on exec-mask bookkeeping.
-template <bool kPow2, int kGroup, int kRays>
-__device__ __forceinline__ void march(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
-                                      const float* __restrict__ pos_z, bool mag_ok, int* hit) {
-  const f32x2 posxy = {pos.x, pos.y}, fxy = {p.fx, p.fy}, cxy = {cx, cy};
+//     (all rays of the wave resolved; the rare IEEE-division re-march, decided once per ray pair), so the
+//     scalar unit is not spent on exec-mask bookkeeping.
+template <bool kPow2, int kGroup, int kRays, bool kExact>
+__device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
+                                           const float* __restrict__ pos_z, bool mag_ok, int* hit) {
   bool open[kRays];
 #pragma unroll
   for (int k = 0; k < kRays; k++) { open[k] = true; hit[k] = -1; }
+  const char* zbase = reinterpret_cast<const char*>(pos_z);
+  float min_den = __builtin_inff();
   for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
-    int idx[kRays][kGroup];
+    unsigned off[kRays][kGroup];
     float spzv[kRays][kGroup], zv[kRays][kGroup];
     bool inb[kRays][kGroup];
-#pragma unroll
-    for (int g = 0; g < kGroup; g++) {
-      const float fj = (float)(j0 + g);
-      const bool in_range = (j0 + g) < p.step;
-#pragma unroll
-      for (int k = 0; k < kRays; k++) {
-        // pos + sampleVec * j * (1 + z/100) * (1 + z/100) * radius / step, left to right (forward.cu:693)
-        f32x2 m = f32x2{sv[k].x, sv[k].y} * fj;
-        float mz = sv[k].z * fj;
-        m = m * a; mz = mz * a;
-        m = m * a; mz = mz * a;
-        m = m * p.radius; mz = mz * p.radius;
-        if (kPow2) {
-          m = m * p.inv_step; mz = mz * p.inv_step;
-        } else {
-          const float fs = (float)p.step;
-          m = f32x2{m.x / fs, m.y / fs}; mz = mz / fs;
-        }
-        const f32x2 sp = posxy + m;
-        const float spz = pos.z + mz;
-        // get_coord (ssr.h:120-135)
-        const float den = spz + 0.0000001f;
-        f32x2 qv = div2_fast(sp, den);
-        const bool need_ieee = !(mag_ok && fabsf(den) > 0x1p-60f);
-        if (__builtin_expect(__any(need_ieee && open[k]), 0)) {
-          if (need_ieee) qv = f32x2{sp.x / den, sp.y / den};
-        }
-        const f32x2 t = qv * fxy + cxy;
-        const int ix = round_to_int(t.x);
-        const int iy = round_to_int(t.y);
-        inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
-        idx[k][g] = inb[k][g] ? p.W * iy + ix : 0;
-        spzv[k][g] = spz;
-      }
-    }
+    min_den = fminf(min_den, group_coords<kPow2, kGroup, kRays, kExact>(p, pos, a, sv, cx, cy, mag_ok, j0, off, inb, spzv));
 #pragma unroll
     for (int g = 0; g < kGroup; g++)
 #pragma unroll
-      for (int k = 0; k < kRays; k++) zv[k][g] = pos_z[idx[k][g]];
+      for (int k = 0; k < kRays; k++) zv[k][g] = *reinterpret_cast<const float*>(zbase + off[k][g]);
     bool any_open = false;
 #pragma unroll
     for (int k = 0; k < kRays; k++) {
 #pragma unroll
       for (int g = 0; g < kGroup; g++) {
         const bool h = inb[k][g] && (zv[k][g] <= spzv[k][g] + p.bias) && (zv[k][g] >= spzv[k][g] - p.thick);
-        hit[k] = (open[k] && h) ? idx[k][g] : hit[k];
+        hit[k] = (open[k] && h) ? (int)(off[k][g] >> 2) : hit[k];
         open[k] = open[k] && inb[k][g] && !h;
       }
       any_open = any_open || open[k];
     }
     if (!__any(any_open)) break;
   }
+  return !(mag_ok && min_den > 0x1p-60f);  // this lane needed an IEEE division somewhere
+}
+
+// The fast pass assumes no sample of the pixel needs the operand pre-scaling of an IEEE division and
+// reports per lane whether that held; if any lane of the wave says no (never, on real frames) the
+// rays are marched again with the per-lane exact selection -- two separate code paths, so the common
+// one carries neither the branches nor the registers of the rare one.
+template <bool kPow2, int kGroup, int kRays>
+__device__ __forceinline__ void march(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
+                                      const float* __restrict__ pos_z, bool mag_ok, int* hit) {
+  const bool bad = march_impl<kPow2, kGroup, kRays, false>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
+  if (__builtin_expect(__any(bad), 0)) march_impl<kPow2, kGroup, kRays, true>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
 }
 
 struct Tbn { v3 t, b, n; };
@@ -326,17 +360,18 @@ __device__ __forceinline__ bool tbn_never_hits(const Tbn& m) {
 constexpr int kGiGroup = 4;
 constexpr int kGiRays = 2;  // rays marched together per lane (independent instruction streams)
 constexpr int kGiWaves = 4;
+constexpr int kGiTileLog2W = 3;
 
 // One 256-lane workgroup per 8x8 pixel tile: the four waves cover the SAME 64 pixels and split the
 // ray set into four contiguous chunks (25 000 x 4 waves at 800x800 instead of 10 000 long-running
 // ones: the tail of the launch is short and empty tiles retire immediately).  Partial sums are
 // combined through LDS in the fixed order ((w0 + w1) + w2) + w3.
-__device__ __forceinline__ bool gi_pixel(int W, int H, int& x, int& y, int& wave) {
+__device__ __forceinline__ bool gi_pixel(const GiParams& p, int& x, int& y, int& wave) {
   const int lane = threadIdx.x & 63;
   wave = threadIdx.x >> 6;
-  x = blockIdx.x * 8 + (lane & 7);
-  y = blockIdx.y * 8 + (lane >> 3);
-  return x < W && y < H;
+  x = (blockIdx.x << p.tile_log2w) + (lane & ((1 << p.tile_log2w) - 1));
+  y = blockIdx.y * (64 >> p.tile_log2w) + (lane >> p.tile_log2w);
+  return x < p.W && y < p.H;
 }
 
 template <bool kPow2>
@@ -346,7 +381,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             float* __restrict__ occlusion) {
   __shared__ float s_part[kGiWaves][64];
   int x, y, wave;
-  const bool inside = gi_pixel(p.W, p.H, x, y, wave);
+  const bool inside = gi_pixel(p, x, y, wave);
   const int lane = threadIdx.x & 63;
   const size_t HW = (size_t)p.H * p.W;
   const size_t pix_id = inside ? (size_t)p.W * y + x : 0;
@@ -404,7 +439,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
            const float* __restrict__ F0_map, float* __restrict__ color, float* __restrict__ abd) {
   __shared__ float s_part[kGiWaves][3][64];
   int x, y, wave;
-  const bool inside = gi_pixel(p.W, p.H, x, y, wave);
+  const bool inside = gi_pixel(p, x, y, wave);
   const int lane = threadIdx.x & 63;
   const size_t HW = (size_t)p.H * p.W;
   const size_t pix_id = inside ? (size_t)p.W * y + x : 0;
@@ -503,7 +538,14 @@ static GiParams make_params(int W, int H, float fx, float fy, float radius, floa
   p.step = step; p.start = start; p.nrays = nrays;
   pow2 = step > 0 && (step & (step - 1)) == 0 && step <= (1 << 20);
   p.inv_step = pow2 ? 1.0f / (float)step : 0.0f;
+  // GIGS_GI_TILE_LOG2W: tuning knob for the pixel rectangle of a workgroup (3 = 8x8 ... 6 = 64x1)
+  const char* e = getenv("GIGS_GI_TILE_LOG2W");
+  p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
   return p;
+}
+static dim3 gi_grid(const GiParams& p) {
+  const int tw = 1 << p.tile_log2w, th = 64 >> p.tile_log2w;
+  return dim3((p.W + tw - 1) / tw, (p.H + th - 1) / th);
 }
 
 int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, float thick,
@@ -514,7 +556,8 @@ int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, floa
   if (rc) return rc;
   bool pow2;
   const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
-  dim3 grid((W + 7) / 8, (H + 7) / 8);
+  if (W >= (1 << 15) || H >= (1 << 15)) return -2;  // rejected with a message by the C-ABI wrapper
+  const dim3 grid = gi_grid(p);
   if (pow2)
     hipLaunchKernelGGL(ssao_kernel<true>, grid, dim3(256), 0, s, p, t.dev, t.sum_w, normal, pos, occlusion);
   else
@@ -531,7 +574,8 @@ int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float
   if (rc) return rc;
   bool pow2;
   const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
-  dim3 grid((W + 7) / 8, (H + 7) / 8);
+  if (W >= (1 << 15) || H >= (1 << 15)) return -2;  // rejected with a message by the C-ABI wrapper
+  const dim3 grid = gi_grid(p);
   if (pow2)
     hipLaunchKernelGGL(ssr_kernel<true>, grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd);
   else
