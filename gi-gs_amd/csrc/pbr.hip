@@ -335,56 +335,127 @@ specular_weights_kernel(int N, const float4* __restrict__ table, const float* __
 // kNorm: the forward writes rgb / wsum to dst [.,3] and wsum to `wsum_out` (the division
 // ops.py:458 does in torch); the backward then reads a 3-channel gradient that the caller has
 // already divided by wsum.
-template <bool kBackward, bool kNorm>
+// Sum over groups of kLanes consecutive lanes (8 = half a DPP row, 16 = a row, 64 = the wave); the total is
+// valid in the last lane of every group.
+template <int kLanes>
+__device__ __forceinline__ float group_sum_last(float v) {
+  v += pbr_dpp<0xb1>(v);
+  v += pbr_dpp<0x4e>(v);
+  if (kLanes == 8) return v + pbr_dpp<0x141>(v);  // row_half_mirror: the other quad of the 8-lane group
+  v += pbr_dpp<0x124>(v);
+  v += pbr_dpp<0x128>(v);
+  if (kLanes == 64) {
+    v += pbr_dpp<0x142, 0xa>(v);
+    v += pbr_dpp<0x143, 0xc>(v);
+  }
+  return v;
+}
+
+// Applies the cached GGX weights: out[o] = sum_i W[o][i] * src[window_o[i]].  A texel's window is up to six
+// face rectangles (`bounds`), and its weights are ONE contiguous run of the table (the rectangles in face
+// order, `offsets[6 o]` onward), so the kernel treats the window as a flat candidate list:
+//   * all six rectangles are loaded up front (six independent 16-byte loads: one memory round trip instead
+//     of one per face) and every candidate index is mapped to its face with selects;
+//   * the weight stream and the texel gathers of kU candidates per lane are issued together, the gathers
+//     unconditionally (a rejected candidate, weight -1, still lies inside its face);
+//   * kLanes = 8 / 16 pack eight / four texels into a wave for the levels whose windows hold ~10^2..10^3
+//     candidates (the fixed per-texel work is shared by the wave), kLanes = 64 gives a whole wave to a texel.
+// The pass streams the table once (0.74 GB per direction for the reference's 256..16 chain): it is HBM-bound.
+template <bool kBackward, bool kNorm, int kLanes>
 __global__ void __launch_bounds__(256)
-specular_apply_kernel(int N, const float4* __restrict__ table, const float* __restrict__ src,
-                      const float* __restrict__ bounds, const uint32_t* __restrict__ offsets,
-                      const float* __restrict__ W, float* __restrict__ dst, float* __restrict__ wsum_out) {
-  (void)table;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+specular_apply_kernel(int N, const float* __restrict__ src, const float* __restrict__ bounds,
+                      const uint32_t* __restrict__ offsets, const float* __restrict__ W,
+                      float* __restrict__ dst, float* __restrict__ wsum_out) {
+  constexpr int kPerWave = 64 / kLanes;
+  constexpr int kU = 4;
   const int lane = threadIdx.x & 63;
-  if (o >= 6 * N * N) return;
-  float wsum = 0.0f, c0 = 0, c1 = 0, c2 = 0;
+  const int total = 6 * N * N;
+  const int o_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kPerWave + lane / kLanes;
+  const bool valid = o_raw < total;
+  const int o = valid ? o_raw : total - 1;  // surplus groups stay in the wave for the DPP sums
+  const int g = lane % kLanes;
   const int stride = (kBackward && !kNorm) ? 4 : 3;
+
+  int wd[6], pre[7], base[6];
+  float inv[6];
   const float4* b4 = reinterpret_cast<const float4*>(bounds + 24 * (size_t)o);
-  constexpr int kU = 4;  // candidates per lane in flight: the pass is latency-bound, not bandwidth-bound
+  const uint32_t first = offsets[6 * (size_t)o];
+  pre[0] = 0;
+#pragma unroll
   for (int s = 0; s < 6; ++s) {
     const float4 b = b4[s];
     const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
-    if (xmin > xmax || ymin > ymax) continue;
-    const int wd = xmax - xmin + 1, n = wd * (ymax - ymin + 1);
-    const float inv = 1.0f / (float)wd;
-    const float* wrow = W + offsets[6 * (size_t)o + s];
-    const int face_base = (s * N + ymin) * N + xmin;
-    for (int i0 = lane; i0 < n; i0 += 64 * kU) {
-      float w[kU];
-      int idx[kU];
+    const bool empty = xmin > xmax || ymin > ymax;
+    wd[s] = empty ? 1 : xmax - xmin + 1;
+    pre[s + 1] = pre[s] + (empty ? 0 : wd[s] * (ymax - ymin + 1));
+    base[s] = empty ? 0 : (s * N + ymin) * N + xmin;
+    // row = floor((loc + 0.5) / wd): the half-texel slack dwarfs the 1-ulp error of the hardware reciprocal
+    inv[s] = __builtin_amdgcn_rcpf((float)wd[s]);
+  }
+  const int n = valid ? pre[6] : 0;
+  const float* wrow = W + first;
+
+  float wsum = 0.0f, c0 = 0, c1 = 0, c2 = 0;
+  // face of candidate i: the last face with pre[k] <= i (empty faces are overridden by the next one)
+  int f_wd, f_base, f_pre, f_end;
+  float f_inv;
+  auto find_face = [&](int i) {
+    f_wd = wd[0]; f_base = base[0]; f_pre = 0; f_end = pre[1]; f_inv = inv[0];
+#pragma unroll
+    for (int k = 1; k < 6; k++) {
+      const bool ge = i >= pre[k];
+      f_wd = ge ? wd[k] : f_wd; f_base = ge ? base[k] : f_base; f_pre = ge ? pre[k] : f_pre;
+      f_end = ge ? pre[k + 1] : f_end; f_inv = ge ? inv[k] : f_inv;
+    }
+  };
+  find_face(g);
+  for (int i0 = g; i0 < n; i0 += kLanes * kU) {
+    float w[kU];
+    int idx[kU];
+    // Lanes walk their candidates in increasing order, so the face changes at most five times per texel:
+    // the select chain runs only in iterations where some lane of the wave crosses a face (or the list) end.
+    const bool cross = i0 + kLanes * (kU - 1) >= f_end && f_end < n;  // running past the END OF THE LIST is handled below
+    if (__any(cross)) {
 #pragma unroll
       for (int u = 0; u < kU; u++) {
-        const int i = i0 + 64 * u;
-        w[u] = i < n ? wrow[i] : -1.0f;
-        const int yy = (int)(((float)i + 0.5f) * inv), xx = i - yy * wd;
-        idx[u] = face_base + yy * N + xx;
+        const int i = i0 + kLanes * u;
+        const bool in = i < n;
+        const int ic = in ? i : 0;
+        w[u] = in ? wrow[i] : -1.0f;
+        find_face(ic);
+        const int loc = ic - f_pre;
+        const int yy = (int)(((float)loc + 0.5f) * f_inv), xx = loc - yy * f_wd;
+        idx[u] = f_base + yy * N + xx;
       }
-      float t0[kU], t1[kU], t2[kU];
+      find_face(min(i0 + kLanes * kU, n - 1));
+    } else {
 #pragma unroll
       for (int u = 0; u < kU; u++) {
-        const bool ok = w[u] >= 0.0f;  // -1 marks candidates outside the cone (never read, as in the reference)
-        const float* t = src + (size_t)stride * (ok ? idx[u] : face_base);
-        t0[u] = t[0]; t1[u] = t[1]; t2[u] = t[2];
+        const int i = i0 + kLanes * u;
+        const bool in = i < n;
+        w[u] = in ? wrow[i] : -1.0f;
+        const int loc = in ? i - f_pre : 0;
+        const int yy = (int)(((float)loc + 0.5f) * f_inv), xx = loc - yy * f_wd;
+        idx[u] = f_base + yy * N + xx;
       }
+    }
+    float t0[kU], t1[kU], t2[kU];
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        if (w[u] >= 0.0f) {
-          c0 += t0[u] * w[u]; c1 += t1[u] * w[u]; c2 += t2[u] * w[u];
-          wsum += w[u];
-        }
+    for (int u = 0; u < kU; u++) {
+      const float* t = src + (size_t)stride * idx[u];
+      t0[u] = t[0]; t1[u] = t[1]; t2[u] = t[2];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      if (w[u] >= 0.0f) {  // -1 marks candidates outside the cone
+        c0 += t0[u] * w[u]; c1 += t1[u] * w[u]; c2 += t2[u] * w[u];
+        wsum += w[u];
       }
     }
   }
-  c0 = wave_sum63(c0); c1 = wave_sum63(c1); c2 = wave_sum63(c2);
-  if (!kBackward) wsum = wave_sum63(wsum);
-  if (lane == 63) {
+  c0 = group_sum_last<kLanes>(c0); c1 = group_sum_last<kLanes>(c1); c2 = group_sum_last<kLanes>(c2);
+  if (!kBackward) wsum = group_sum_last<kLanes>(wsum);
+  if (g == kLanes - 1 && valid) {
     if (kBackward) {
       float* q = dst + 3 * (size_t)o;
       q[0] = c0; q[1] = c1; q[2] = c2;
@@ -396,6 +467,27 @@ specular_apply_kernel(int N, const float4* __restrict__ table, const float* __re
       float* q = dst + 4 * (size_t)o;
       q[0] = c0; q[1] = c1; q[2] = c2; q[3] = wsum;
     }
+  }
+}
+
+template <bool kBackward, bool kNorm>
+static void launch_specular_apply(int res, int avg_window, const float* src, const float* bounds, const uint32_t* offsets,
+                                  const float* W, float* dst, float* wsum_out, hipStream_t s) {
+  const int total = 6 * res * res;
+  // tuning knobs: largest mean window served by 8- and by 16-lane groups
+  static const int max8 = [] { const char* e = getenv("GIGS_SPEC_MAX8"); return e ? atoi(e) : 128; }();
+  static const int max16 = [] { const char* e = getenv("GIGS_SPEC_MAX16"); return e ? atoi(e) : 1500; }();
+  if (avg_window > 0 && avg_window <= max8) {
+    const int waves = (total + 7) / 8;
+    hipLaunchKernelGGL((specular_apply_kernel<kBackward, kNorm, 8>), dim3((waves + 3) / 4), dim3(256), 0, s, res, src,
+                       bounds, offsets, W, dst, wsum_out);
+  } else if (avg_window > 0 && avg_window <= max16) {
+    const int waves = (total + 3) / 4;
+    hipLaunchKernelGGL((specular_apply_kernel<kBackward, kNorm, 16>), dim3((waves + 3) / 4), dim3(256), 0, s, res, src,
+                       bounds, offsets, W, dst, wsum_out);
+  } else {
+    hipLaunchKernelGGL((specular_apply_kernel<kBackward, kNorm, 64>), dim3((total + 3) / 4), dim3(256), 0, s, res, src,
+                       bounds, offsets, W, dst, wsum_out);
   }
 }
 
@@ -913,32 +1005,28 @@ int gigs_specular_weights(int res, const float* bounds, const uint32_t* offsets,
 }
 
 int gigs_specular_cubemap_fwd_w(int res, const float* cubemap, const float* bounds, const uint32_t* offsets,
-                                const float* weights, float* out, float* wsum_out, void* stream) {
+                                const float* weights, int avg_window, float* out, float* wsum_out, void* stream) {
   if (res <= 0 || !cubemap || !bounds || !offsets || !weights || !out) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_fwd_w: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  const float4* table = gigs::texel_table(res, s);
-  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
   void* tok; gigs_internal_stage_begin(16, stream, &tok);
   if (wsum_out)
-    hipLaunchKernelGGL((gigs::specular_apply_kernel<false, true>), dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, cubemap, bounds, offsets, weights, out, wsum_out);
+    gigs::launch_specular_apply<false, true>(res, avg_window, cubemap, bounds, offsets, weights, out, wsum_out, s);
   else
-    hipLaunchKernelGGL((gigs::specular_apply_kernel<false, false>), dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, cubemap, bounds, offsets, weights, out, (float*)nullptr);
+    gigs::launch_specular_apply<false, false>(res, avg_window, cubemap, bounds, offsets, weights, out, nullptr, s);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;
 }
 
 int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* offsets, const float* weights_swapped,
-                                const float* grad_out, int grad_is_rgb, float* grad_cubemap, void* stream) {
+                                int avg_window, const float* grad_out, int grad_is_rgb, float* grad_cubemap, void* stream) {
   if (res <= 0 || !bounds || !offsets || !weights_swapped || !grad_out || !grad_cubemap) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_bwd_w: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  const float4* table = gigs::texel_table(res, s);
-  if (!table) return gigs_internal_fail(GIGS_ERR_HIP, "texel table");
   void* tok; gigs_internal_stage_begin(17, stream, &tok);
   if (grad_is_rgb)
-    hipLaunchKernelGGL((gigs::specular_apply_kernel<true, true>), dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, grad_out, bounds, offsets, weights_swapped, grad_cubemap, (float*)nullptr);
+    gigs::launch_specular_apply<true, true>(res, avg_window, grad_out, bounds, offsets, weights_swapped, grad_cubemap, nullptr, s);
   else
-    hipLaunchKernelGGL((gigs::specular_apply_kernel<true, false>), dim3((6 * res * res + 3) / 4), dim3(256), 0, s, res, table, grad_out, bounds, offsets, weights_swapped, grad_cubemap, (float*)nullptr);
+    gigs::launch_specular_apply<true, false>(res, avg_window, grad_out, bounds, offsets, weights_swapped, grad_cubemap, nullptr, s);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;

@@ -69,7 +69,8 @@ class _specular_cubemap(torch.autograd.Function):
                                "specular_cubemap_fwd")
             else:
                 gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(res, c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
-                                                                tables[1].data_ptr(), out.data_ptr(), None, _stream()),
+                                                                tables[1].data_ptr(), _avg_window(tables, res),
+                                                                out.data_ptr(), None, _stream()),
                                "specular_cubemap_fwd_w")
         ctx.save_for_backward(bounds)
         ctx.tables = tables
@@ -88,9 +89,15 @@ class _specular_cubemap(torch.autograd.Function):
                                "specular_cubemap_bwd")
             else:
                 gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
-                                                                ctx.tables[2].data_ptr(), d.data_ptr(), 0, g.data_ptr(),
-                                                                _stream()), "specular_cubemap_bwd_w")
+                                                                ctx.tables[2].data_ptr(), _avg_window(ctx.tables, ctx.res),
+                                                                d.data_ptr(), 0, g.data_ptr(), _stream()),
+                               "specular_cubemap_bwd_w")
         return g, None, None, None, None
+
+
+def _avg_window(tables, res: int) -> int:
+    """Mean number of window candidates per texel (scheduling hint of the *_w entry points)."""
+    return max(1, tables[1].numel() // (6 * res * res))
 
 
 def _ndf_cutoff(roughness: float, cutoff: float) -> float:
@@ -133,7 +140,8 @@ class _specular_cubemap_normalized(torch.autograd.Function):
         wsum = torch.empty((6, res, res, 1), dtype=torch.float32, device=c.device)
         with torch.cuda.device(c.device):
             gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(res, c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
-                                                            tables[1].data_ptr(), out.data_ptr(), wsum.data_ptr(), _stream()),
+                                                            tables[1].data_ptr(), _avg_window(tables, res), out.data_ptr(),
+                                                            wsum.data_ptr(), _stream()),
                            "specular_cubemap_fwd_w")
         ctx.save_for_backward(bounds, wsum)
         ctx.tables, ctx.res = tables, res
@@ -146,7 +154,8 @@ class _specular_cubemap_normalized(torch.autograd.Function):
         g = torch.empty((6, ctx.res, ctx.res, 3), dtype=torch.float32, device=d.device)
         with torch.cuda.device(d.device):
             gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
-                                                            ctx.tables[2].data_ptr(), d.data_ptr(), 1, g.data_ptr(), _stream()),
+                                                            ctx.tables[2].data_ptr(), _avg_window(ctx.tables, ctx.res),
+                                                            d.data_ptr(), 1, g.data_ptr(), _stream()),
                            "specular_cubemap_bwd_w")
         return g, None, None
 

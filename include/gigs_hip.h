@@ -154,12 +154,13 @@ int gigs_specular_weights(int res, const float* bounds, const uint32_t* offsets,
 /* wsum_out == NULL: out = [6,res,res,4] (rgb, weight sum) like the table-free entry point;
  * wsum_out != NULL: out = [6,res,res,3] = rgb / wsum (the division of ops.py:458 folded in) and the
  * weight sums go to wsum_out [6,res,res].  grad_is_rgb: grad_out is [6,res,res,3] (already divided
- * by wsum by the caller) instead of [6,res,res,4]. */
+ * by wsum by the caller) instead of [6,res,res,4].  avg_window = table length / (6 res^2), the mean
+ * number of candidates per texel: a scheduling hint only (lanes per texel), 0 = unknown. */
 int gigs_specular_cubemap_fwd_w(int res, const float* cubemap, const float* bounds, const uint32_t* offsets,
-                                const float* weights, float* out, float* wsum_out, void* stream);
+                                const float* weights, int avg_window, float* out, float* wsum_out, void* stream);
 int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* offsets,
-                                const float* weights_swapped, const float* grad_out, int grad_is_rgb,
-                                float* grad_cubemap, void* stream);
+                                const float* weights_swapped, int avg_window, const float* grad_out,
+                                int grad_is_rgb, float* grad_cubemap, void* stream);
 /* cubemap_mip (pbr/light.py:54-79): forward 2x2 average pool [6,2r,2r,C] -> [6,r,r,C]; backward =
  * bilinear cube lookup of 0.25*dout at every fine texel direction, dout [6,r,r,3] -> din [6,2r,2r,3]. */
 int gigs_cubemap_mip_fwd(int res_out, int channels, const float* in, float* out, void* stream);

@@ -9,7 +9,9 @@ for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursiv
         name = m.group(1) if m else ('rocprim_sort' if 'radix' in k or 'merge' in k else None)
         if name is None:
             continue
-        if 'ILb1E' in k or '<true>' in k: name += '<true>'
+        t = re.search(r'gigs::\w+(<[^>]*>)', k)
+        if t: name += t.group(1).replace(' ', '')
+        if name.startswith('specular_apply'): name += '@' + r.get('Grid_Size', r.get('Grid_Size_X', '?'))
         agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {}
 for k, cs in sorted(agg.items()):
