@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--shade", choices=["auto", "hip", "none"], default="auto")
     ap.add_argument("--graphs", choices=["on", "off"], default="on",
                     help="capture the launch-bound glue segments of the step into hipGraphs")
+    ap.add_argument("--fused", choices=["on", "off"], default="on",
+                    help="run the tensor glue between rasterizer and loss.backward() as the fused stage-2 node "
+                         "(gi-gs_amd/stage2_fused.py) instead of op-by-op torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -208,7 +211,8 @@ def main():
     flat_params = [g[k] for k in PARAM_KEYS] + params_light
     stepper = None
     if shade == "hip":
-        stepper = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=(args.graphs == "on"))
+        stepper = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=(args.graphs == "on"),
+                                      fused=(args.fused == "on"))
 
     def one_step(i):
         vi = dp.view_for(i, rank, world, n_views)
@@ -287,7 +291,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2 stand-in: %dk surface Gaussians, %dx%d, SH deg %d, GI step=%d start=%d delta=%g"
                                    % (P // 1000, W, H, args.sh_degree, gi["step"], gi["start"], gi["delta"]),
-                       "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade, "hip_graphs": args.graphs,
+                       "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade, "hip_graphs": args.graphs, "fused_glue": args.fused,
                        "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

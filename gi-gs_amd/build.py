@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgigs_hip.so")
-SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "blend.hip", "gi.hip", "pbr.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "blend.hip", "gi.hip", "pbr.hip", "stage2.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
@@ -28,6 +28,7 @@ FLAGS = [
 def _deps(src: str):
     yield os.path.join(CSRC, src)
     yield os.path.join(CSRC, "gigs_common.h")
+    yield os.path.join(CSRC, "pixel_ops.h")
     yield os.path.join(HERE, "..", "include", "gigs_hip.h")
 
 

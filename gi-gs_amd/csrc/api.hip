@@ -87,12 +87,13 @@ uint32_t higher_msb(uint32_t n) {
 enum Stage {
   kPreprocess = 0, kScan, kDuplicate, kSort, kRanges, kBlendFwd, kBlendBwd, kPreprocessBwd,
   kDepthToNormal, kSsao, kSsr, kMedian, kBilateral, kMedianBwd, kShadeFwd, kShadeBwd,
-  kCubemapFwd, kCubemapBwd, kNumStages
+  kCubemapFwd, kCubemapBwd, kGbufferPost, kLossFwd, kLossBwd, kNumStages
 };
 const char* kStageNames[kNumStages] = {
   "preprocess_fwd", "scan", "duplicate", "sort", "tile_ranges", "blend_fwd", "blend_bwd",
   "preprocess_bwd", "depth_to_normal", "ssao", "ssr", "median3x3", "bilateral3x3",
-  "median3x3_bwd", "shade_fwd", "shade_bwd", "cubemap_fwd", "cubemap_bwd"};
+  "median3x3_bwd", "shade_fwd", "shade_bwd", "cubemap_fwd", "cubemap_bwd", "gbuffer_post",
+  "stage2_loss_fwd", "stage2_loss_bwd"};
 
 struct ProfRec { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "gigs_common.h"
+#include "pixel_ops.h"
 
 namespace gigs {
 
@@ -586,23 +587,6 @@ int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float
 // ------------------------------------------------------------------------------------------
 // 3x3 filters
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cswap(float& a, float& b) {
-  const float lo = fminf(a, b), hi = fmaxf(a, b);
-  a = lo;
-  b = hi;
-}
-// median of 9 by the classic 19-exchange network (NaN-free inputs)
-__device__ __forceinline__ float median9(float* v) {
-  cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
-  cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
-  cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
-  cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
-  cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
-  cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
-  cswap(v[4], v[2]);
-  return v[4];
-}
-
 __device__ __forceinline__ bool load_taps(const float* __restrict__ src, int H, int W, int y, int x,
                                           float* v) {
   bool has_nan = false;

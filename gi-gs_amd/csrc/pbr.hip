@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "gigs_common.h"
+#include "pixel_ops.h"
 
 namespace gigs {
 
@@ -633,6 +634,13 @@ struct ShadeArgs {
   const float *g_render, *g_diffuse_rgb, *g_specular_rgb, *g_diffuse_light;
   float *d_albedo, *d_roughness, *d_metallic, *d_diffuse;
   float* d_spec[8];
+  // layout of normals / albedo and of every [H,W,3] output and gradient: element (p, c) at p * ps + c * cs
+  // ([H,W,3]: ps = 3, cs = 1;  [3,H,W] planes: ps = 1, cs = H*W).  view_dirs is always [H,W,3].
+  int ps, cs;
+  // gigs_shade_ext (stage-2 fusion): roughness = raw * rough_scale + rough_bias, extra outputs / gradients
+  float rough_scale, rough_bias;
+  float *out_F0, *out_linear, *out_roughness;
+  const float *g_albedo_mul_a, *g_albedo_mul_b, *g_roughness_add, *g_metallic_add;
 };
 
 __device__ __forceinline__ float get_mip(float r, int L, float& dmip_dr) {  // pbr/light.py:142-152
@@ -645,14 +653,6 @@ __device__ __forceinline__ float get_mip(float r, int L, float& dmip_dr) {  // p
   const float c = fminf(fmaxf(r, MAXR), 1.0f);
   dmip_dr = (r >= MAXR && r <= 1.0f) ? 1.0f / (1.0f - MAXR) : 0.0f;
   return (c - MAXR) / (1.0f - MAXR) + (float)L - 2.0f;
-}
-__device__ __forceinline__ float lin2srgb(float x, float& d) {  // pbr/shade.py:50-63
-  const float eps = 1.1920929e-07f;
-  if (x <= 0.0031308f) { d = 323.0f / 25.0f; return 323.0f / 25.0f * x; }
-  const float c = fmaxf(x, eps);
-  const float p = powf(c, 5.0f / 12.0f);
-  d = x >= eps ? 211.0f * (5.0f / 12.0f) * p / c / 200.0f : 0.0f;
-  return (211.0f * p - 11.0f) / 200.0f;
 }
 __device__ __forceinline__ float aces(float x, float& d) {  // pbr/shade.py:33-47
   const float a = 2.51f, b = 0.03f, c = 2.43f, dd = 0.59f, e = 0.14f;
@@ -672,10 +672,11 @@ struct ShadePix {
 };
 
 __device__ __forceinline__ void shade_pixel(const ShadeArgs& A, int p, ShadePix& q) {
-  const v3 n = {A.normals[3 * p], A.normals[3 * p + 1], A.normals[3 * p + 2]};
+  const size_t e = (size_t)p * A.ps, cs = A.cs;
+  const v3 n = {A.normals[e], A.normals[e + cs], A.normals[e + 2 * cs]};
   const v3 v = {A.view_dirs[3 * p], A.view_dirs[3 * p + 1], A.view_dirs[3 * p + 2]};
-  q.a = {A.albedo[3 * p], A.albedo[3 * p + 1], A.albedo[3 * p + 2]};
-  q.r = A.roughness[p];
+  q.a = {A.albedo[e], A.albedo[e + cs], A.albedo[e + 2 * cs]};
+  q.r = A.roughness[p] * A.rough_scale + A.rough_bias;  // scale 1, bias 0 (exact) unless the caller fuses the remap
   const float ndv = n.x * v.x + n.y * v.y + n.z * v.z;
   const float c2 = 2.0f * fmaxf(ndv, 0.0f);
   const v3 ref = {c2 * n.x - v.x, c2 * n.y - v.y, c2 * n.z - v.z};
@@ -753,11 +754,21 @@ shade_fwd_kernel(ShadeArgs A) {
     srgb = {lin2srgb(srgb.x, dd), lin2srgb(srgb.y, dd), lin2srgb(srgb.z, dd)};
   }
   const bool mk = A.mask[p] != 0;
+  const size_t e = (size_t)p * A.ps, cs = A.cs;
 #pragma unroll
-  for (int c = 0; c < 3; c++) A.render_rgb[3 * p + c] = mk ? rr[c] : (A.background ? A.background[3 * p + c] : 0.0f);
-  A.diffuse_rgb[3 * p] = drgb.x; A.diffuse_rgb[3 * p + 1] = drgb.y; A.diffuse_rgb[3 * p + 2] = drgb.z;
-  A.specular_rgb[3 * p] = srgb.x; A.specular_rgb[3 * p + 1] = srgb.y; A.specular_rgb[3 * p + 2] = srgb.z;
-  A.diffuse_light[3 * p] = q.dl.x; A.diffuse_light[3 * p + 1] = q.dl.y; A.diffuse_light[3 * p + 2] = q.dl.z;
+  for (int c = 0; c < 3; c++) {
+    rr[c] = mk ? rr[c] : (A.background ? A.background[e + c * cs] : 0.0f);
+    A.render_rgb[e + c * cs] = rr[c];
+  }
+  if (A.diffuse_rgb) { A.diffuse_rgb[e] = drgb.x; A.diffuse_rgb[e + cs] = drgb.y; A.diffuse_rgb[e + 2 * cs] = drgb.z; }
+  if (A.specular_rgb) { A.specular_rgb[e] = srgb.x; A.specular_rgb[e + cs] = srgb.y; A.specular_rgb[e + 2 * cs] = srgb.z; }
+  if (A.diffuse_light) { A.diffuse_light[e] = q.dl.x; A.diffuse_light[e + cs] = q.dl.y; A.diffuse_light[e + 2 * cs] = q.dl.z; }
+  if (A.out_F0) { A.out_F0[e] = q.F0.x; A.out_F0[e + cs] = q.F0.y; A.out_F0[e + 2 * cs] = q.F0.z; }
+  if (A.out_linear) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) A.out_linear[e + c * cs] = srgb2lin(rr[c]);
+  }
+  if (A.out_roughness) A.out_roughness[p] = q.r;
 }
 
 constexpr int kShadeBwdBlock = 1024;     // 16 waves share one set of LDS accumulators
@@ -815,12 +826,13 @@ shade_bwd_kernel(ShadeArgs A) {
   float g_dl[3] = {0, 0, 0}, g_sp[3] = {0, 0, 0};
   if (live) {
     const bool mk = A.mask[p] != 0;
+    const size_t e = (size_t)p * A.ps, cs = A.cs;
     float g_d[3] = {0, 0, 0}, g_s[3] = {0, 0, 0};  // grads w.r.t. linear diffuse_rgb / specular_rgb
     const float pre_d[3] = {q.drgb.x, q.drgb.y, q.drgb.z}, pre_s[3] = {q.srgb.x, q.srgb.y, q.srgb.z};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       // render = where(mask, gamma(clamp(tone(d + s))), bg)
-      float g = (A.g_render && mk) ? A.g_render[3 * p + c] : 0.0f;
+      float g = (A.g_render && mk) ? A.g_render[e + c * cs] : 0.0f;
       if (g != 0.0f) {
         float x = pre_d[c] + pre_s[c], d_tone = 1.0f, d_gam = 1.0f;
         if (A.tone) x = aces(x, d_tone);
@@ -829,8 +841,8 @@ shade_bwd_kernel(ShadeArgs A) {
         if (A.gamma) lin2srgb(xc, d_gam);
         g = g * d_gam * d_clamp * d_tone;
       }
-      float gd = A.g_diffuse_rgb ? A.g_diffuse_rgb[3 * p + c] : 0.0f;
-      float gs = A.g_specular_rgb ? A.g_specular_rgb[3 * p + c] : 0.0f;
+      float gd = A.g_diffuse_rgb ? A.g_diffuse_rgb[e + c * cs] : 0.0f;
+      float gs = A.g_specular_rgb ? A.g_specular_rgb[e + c * cs] : 0.0f;
       if (A.gamma) {
         float d1, d2;
         lin2srgb(pre_d[c], d1);
@@ -849,7 +861,7 @@ shade_bwd_kernel(ShadeArgs A) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       d_alb[c] = g_d[c] * dlv[c];
-      g_dl[c] = g_d[c] * av[c] + (A.g_diffuse_light ? A.g_diffuse_light[3 * p + c] : 0.0f);
+      g_dl[c] = g_d[c] * av[c] + (A.g_diffuse_light ? A.g_diffuse_light[e + c * cs] : 0.0f);
       g_sp[c] = g_s[c] * reflv[c];
       const float g_refl = g_s[c] * spv[c];
       const float dF0 = g_refl * q.fgx;
@@ -861,9 +873,14 @@ shade_bwd_kernel(ShadeArgs A) {
       }
       if (q.l1 != q.l0) d_lvl += g_sp[c] * (s1v[c] - s0v[c]);
     }
-    A.d_albedo[3 * p] = d_alb[0]; A.d_albedo[3 * p + 1] = d_alb[1]; A.d_albedo[3 * p + 2] = d_alb[2];
-    if (A.d_metallic) A.d_metallic[p] = d_m;
-    A.d_roughness[p] = d_fgx * q.dfgx_dv + d_fgy * q.dfgy_dv + (q.lvl_inside ? d_lvl * q.dmdr : 0.0f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      if (A.g_albedo_mul_a) d_alb[c] += A.g_albedo_mul_a[e + c * cs] * A.g_albedo_mul_b[e + c * cs];
+      A.d_albedo[e + c * cs] = d_alb[c];
+    }
+    if (A.d_metallic) A.d_metallic[p] = d_m + (A.g_metallic_add ? A.g_metallic_add[p] : 0.0f);
+    const float d_r = d_fgx * q.dfgx_dv + d_fgy * q.dfgy_dv + (q.lvl_inside ? d_lvl * q.dmdr : 0.0f);
+    A.d_roughness[p] = (d_r + (A.g_roughness_add ? A.g_roughness_add[p] : 0.0f)) * A.rough_scale;
   }
   // ---- light textures (wave-uniform control flow from here on) ----
   if (A.d_diffuse && !(A.ablate & 1)) {
@@ -1072,6 +1089,22 @@ static int fill_shade(gigs::ShadeArgs& A, int H, int W, const float* normals, co
   A.lut = lut; A.lut_w = lut_w; A.lut_h = lut_h; A.tone = tone; A.gamma = gamma;
   const char* ab = getenv("GIGS_ABLATE");
   A.ablate = ab ? atoi(ab) : 0;
+  A.ps = 3; A.cs = 1; A.rough_scale = 1.0f; A.rough_bias = 0.0f;
+  return 0;
+}
+
+static int apply_shade_ext(gigs::ShadeArgs& A, const gigs_shade_ext* ext, bool backward) {
+  if (!ext) return 0;
+  if (ext->planar) { A.ps = 1; A.cs = A.H * A.W; }
+  A.rough_scale = ext->rough_scale; A.rough_bias = ext->rough_bias;
+  if (!backward) {
+    A.out_F0 = ext->out_F0; A.out_linear = ext->out_linear; A.out_roughness = ext->out_roughness;
+  } else {
+    if ((ext->g_albedo_mul_a == nullptr) != (ext->g_albedo_mul_b == nullptr))
+      return gigs_internal_fail(GIGS_ERR_INVALID, "shade_bwd: g_albedo_mul_a/b must be given together");
+    A.g_albedo_mul_a = ext->g_albedo_mul_a; A.g_albedo_mul_b = ext->g_albedo_mul_b;
+    A.g_roughness_add = ext->g_roughness_add; A.g_metallic_add = ext->g_metallic_add;
+  }
   return 0;
 }
 
@@ -1081,11 +1114,24 @@ int gigs_shade_fwd(int H, int W, const float* normals, const float* view_dirs, c
                    int n_levels, const float* const* spec, const int* spec_res, const float* lut,
                    int lut_w, int lut_h, int tone, int gamma, float* render_rgb, float* diffuse_rgb,
                    float* specular_rgb, float* diffuse_light, void* stream) {
+  return gigs_shade_fwd_ex(H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, background, diffuse,
+                           diffuse_res, n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma, render_rgb,
+                           diffuse_rgb, specular_rgb, diffuse_light, nullptr, stream);
+}
+
+int gigs_shade_fwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+                      const float* roughness, const uint8_t* mask, const float* occlusion,
+                      const float* metallic, const float* background, const float* diffuse, int diffuse_res,
+                      int n_levels, const float* const* spec, const int* spec_res, const float* lut,
+                      int lut_w, int lut_h, int tone, int gamma, float* render_rgb, float* diffuse_rgb,
+                      float* specular_rgb, float* diffuse_light, const gigs_shade_ext* ext, void* stream) {
   gigs::ShadeArgs A;
   const int rc = fill_shade(A, H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, background,
                             diffuse, diffuse_res, n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma);
   if (rc) return rc;
-  if (!render_rgb || !diffuse_rgb || !specular_rgb || !diffuse_light) return gigs_internal_fail(GIGS_ERR_INVALID, "shade_fwd: null output");
+  if (!render_rgb || (!ext && (!diffuse_rgb || !specular_rgb || !diffuse_light)))
+    return gigs_internal_fail(GIGS_ERR_INVALID, "shade_fwd: null output");
+  if (apply_shade_ext(A, ext, false)) return GIGS_ERR_INVALID;
   A.render_rgb = render_rgb; A.diffuse_rgb = diffuse_rgb; A.specular_rgb = specular_rgb; A.diffuse_light = diffuse_light;
   void* tok; gigs_internal_stage_begin(14, stream, &tok);
   hipLaunchKernelGGL(gigs::shade_fwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, A);
@@ -1102,11 +1148,26 @@ int gigs_shade_bwd(int H, int W, const float* normals, const float* view_dirs, c
                    const float* g_specular_rgb, const float* g_diffuse_light, float* d_albedo,
                    float* d_roughness, float* d_metallic, float* d_diffuse, float* const* d_spec,
                    void* stream) {
+  return gigs_shade_bwd_ex(H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, diffuse, diffuse_res,
+                           n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma, g_render, g_diffuse_rgb,
+                           g_specular_rgb, g_diffuse_light, d_albedo, d_roughness, d_metallic, d_diffuse, d_spec, nullptr,
+                           stream);
+}
+
+int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+                      const float* roughness, const uint8_t* mask, const float* occlusion,
+                      const float* metallic, const float* diffuse, int diffuse_res, int n_levels,
+                      const float* const* spec, const int* spec_res, const float* lut, int lut_w, int lut_h,
+                      int tone, int gamma, const float* g_render, const float* g_diffuse_rgb,
+                      const float* g_specular_rgb, const float* g_diffuse_light, float* d_albedo,
+                      float* d_roughness, float* d_metallic, float* d_diffuse, float* const* d_spec,
+                      const gigs_shade_ext* ext, void* stream) {
   gigs::ShadeArgs A;
   const int rc = fill_shade(A, H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, nullptr,
                             diffuse, diffuse_res, n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma);
   if (rc) return rc;
   if (!d_albedo || !d_roughness) return gigs_internal_fail(GIGS_ERR_INVALID, "shade_bwd: null output");
+  if (apply_shade_ext(A, ext, true)) return GIGS_ERR_INVALID;
   A.g_render = g_render; A.g_diffuse_rgb = g_diffuse_rgb; A.g_specular_rgb = g_specular_rgb; A.g_diffuse_light = g_diffuse_light;
   A.d_albedo = d_albedo; A.d_roughness = d_roughness; A.d_metallic = d_metallic; A.d_diffuse = d_diffuse;
   for (int i = 0; i < n_levels; i++) A.d_spec[i] = d_spec ? d_spec[i] : nullptr;

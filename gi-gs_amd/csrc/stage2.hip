@@ -1,0 +1,266 @@
+// stage2.hip -- the tensor glue of one stage-2 ("PBR + indirect") iteration as three kernels.
+//
+// The reference expresses these steps as a few dozen torch elementwise / reduction ops in
+// gaussian_renderer/__init__.py:157-199 (G-buffer post-processing) and train.py:382-402 (loss); on
+// an MI355X each of those ops is a 3-10 us launch over 0.6 M pixels, ~1.8 ms per iteration in total.
+// Here they are one pass each.  Results agree with the torch formulation to fp32 rounding (the same
+// formulas; tests/test_gpu_pbr.py compares them).
+//
+//   gbuffer_post_kernel   masks, F.normalize, 3x3 median and the rotation of the shading normal into
+//                         view space, for normal_map and out_normal_view (no gradient: train.py detaches
+//                         both before they are used in stage 2)
+//   stage2_loss_fwd       IRR -> sRGB -> 3x3 median -> + direct -> L1 vs ground truth, plus the masked
+//                         sums of the "lamb" regulariser; block-reduced, 4 atomics per workgroup
+//   stage2_loss_bwd       the gradient of that loss w.r.t. render_direct, IRR (through the median's tap
+//                         selection and the sRGB curve) and the roughness / metallic maps
+// All planes are [C,H,W] fp32, the rasterizer's layout.  HBM-bound streaming kernels.
+#include "../../include/gigs_hip.h"
+#include "gigs_common.h"
+#include "pixel_ops.h"
+
+namespace gigs {
+
+// F.normalize(v, dim=0) where |v| > 0, v itself otherwise (gaussian_renderer/__init__.py:160-163, 191-194);
+// a NaN vector stays NaN (|v| > 0 is false).
+__device__ __forceinline__ v3 normalize_where(v3 v) {
+  const float n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+  if (!(n > 0.0f)) return v;
+  const float d = fmaxf(n, 1e-12f);
+  return {v.x / d, v.y / d, v.z / d};
+}
+
+// per-channel 3x3 median of normalize_where(src) with zero padding; NaN window -> NaN (as median3x3_kernel)
+__device__ __forceinline__ v3 median_of_normalized(const float* __restrict__ src, int H, int W, int y, int x) {
+  const size_t HW = (size_t)H * W;
+  float t0[9], t1[9], t2[9];
+  bool n0 = false, n1 = false, n2 = false;
+  int k = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++, k++) {
+      const int yy = y + dy, xx = x + dx;
+      v3 v = {0.0f, 0.0f, 0.0f};
+      if (!(yy < 0 || yy >= H || xx < 0 || xx >= W)) {
+        const size_t q = (size_t)yy * W + xx;
+        v = normalize_where({src[q], src[HW + q], src[2 * HW + q]});
+      }
+      t0[k] = v.x; t1[k] = v.y; t2[k] = v.z;
+      n0 |= v.x != v.x; n1 |= v.y != v.y; n2 |= v.z != v.z;
+    }
+  const float nan = __builtin_nanf("");
+  return {n0 ? nan : median9(t0), n1 ? nan : median9(t1), n2 ? nan : median9(t2)};
+}
+
+__global__ void __launch_bounds__(256)
+gbuffer_post_kernel(int H, int W, const float* __restrict__ normal_map, const float* __restrict__ out_normal_view,
+                    const float* __restrict__ vm, float* __restrict__ normals_view, uint8_t* __restrict__ mask_u8,
+                    float* __restrict__ mask_f, float* __restrict__ onv) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const size_t HW = (size_t)H * W, p = (size_t)y * W + x;
+  const bool mk = normal_map[p] != 0.0f && normal_map[HW + p] != 0.0f && normal_map[2 * HW + p] != 0.0f;
+  if (mask_u8) mask_u8[p] = mk ? 1 : 0;
+  if (mask_f) mask_f[p] = mk ? 1.0f : 0.0f;
+  const v3 n = median_of_normalized(normal_map, H, W, y, x);
+  // -(n @ R), R = viewmatrix[:3, :3] of the row-major 4x4 tensor
+  normals_view[p] = -(n.x * vm[0] + n.y * vm[4] + n.z * vm[8]);
+  normals_view[HW + p] = -(n.x * vm[1] + n.y * vm[5] + n.z * vm[9]);
+  normals_view[2 * HW + p] = -(n.x * vm[2] + n.y * vm[6] + n.z * vm[10]);
+  const v3 o = median_of_normalized(out_normal_view, H, W, y, x);
+  onv[p] = o.x; onv[HW + p] = o.y; onv[2 * HW + p] = o.z;
+}
+
+// ---- loss -------------------------------------------------------------------------------------
+// acc[0] = sum |render_rgb - gt|, acc[1] = sum (1 - roughness) * mask, acc[2] = sum metallic * mask,
+// acc[3] = sum mask;  loss = acc0 / (3 H W) + 0.001 * (acc1 / acc3 + acc2 / acc3)   (train.py:396-402)
+struct LossTaps {
+  float v[9];
+  bool has_nan;
+};
+__device__ __forceinline__ LossTaps srgb_taps(const float* __restrict__ irr, int H, int W, int y, int x) {
+  LossTaps t;
+  t.has_nan = false;
+  int k = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++, k++) {
+      const int yy = y + dy, xx = x + dx;
+      float s = 0.0f, d;
+      if (!(yy < 0 || yy >= H || xx < 0 || xx >= W)) s = lin2srgb(irr[(size_t)yy * W + xx], d);
+      t.v[k] = s;
+      t.has_nan |= s != s;
+    }
+  return t;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+  // wave sum by shuffles, then the 4 waves through LDS; result valid in thread 0
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[wave] = v;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ void __launch_bounds__(256)
+stage2_loss_fwd_kernel(int H, int W, const float* __restrict__ direct, const float* __restrict__ irr,
+                       const float* __restrict__ gt, const float* __restrict__ mask_f,
+                       const float* __restrict__ roughness, const float* __restrict__ metallic,
+                       float* __restrict__ render_rgb, float* __restrict__ acc) {
+  __shared__ float s_red[4];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const bool live = x < W && y < H;
+  const size_t HW = (size_t)H * W, p = live ? (size_t)y * W + x : 0;
+  float l1 = 0.0f, rs = 0.0f, ms = 0.0f, cnt = 0.0f;
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      LossTaps t = srgb_taps(irr + c * HW, H, W, y, x);
+      const float med = t.has_nan ? __builtin_nanf("") : median9(t.v);
+      const float r = direct[c * HW + p] + med;
+      if (render_rgb) render_rgb[c * HW + p] = r;
+      l1 += fabsf(r - gt[c * HW + p]);
+    }
+    const float m = mask_f[p];
+    rs = (1.0f - roughness[p]) * m;
+    ms = metallic[p] * m;
+    cnt = m;
+  }
+  l1 = block_sum_256(l1, s_red);
+  rs = block_sum_256(rs, s_red);
+  ms = block_sum_256(ms, s_red);
+  cnt = block_sum_256(cnt, s_red);
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + 0, l1);
+    atomicAdd(acc + 1, rs);
+    atomicAdd(acc + 2, ms);
+    atomicAdd(acc + 3, cnt);
+  }
+}
+
+__global__ void stage2_loss_finish_kernel(int H, int W, const float* __restrict__ acc, float* __restrict__ loss) {
+  const float n = 3.0f * (float)H * (float)W;
+  const float l1 = acc[0] / n;
+  const float lamb = acc[1] / acc[3] + acc[2] / acc[3];
+  loss[0] = l1 + lamb * 0.001f;
+}
+
+__global__ void __launch_bounds__(256)
+stage2_loss_bwd_kernel(int H, int W, const float* __restrict__ direct, const float* __restrict__ irr,
+                       const float* __restrict__ gt, const float* __restrict__ mask_f, const float* __restrict__ acc,
+                       const float* __restrict__ g_loss, float* __restrict__ d_direct, float* __restrict__ d_irr,
+                       float* __restrict__ d_roughness, float* __restrict__ d_metallic) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const size_t HW = (size_t)H * W, p = (size_t)y * W + x;
+  const float gl = g_loss ? g_loss[0] : 1.0f;
+  const float gs = gl / (3.0f * (float)H * (float)W);
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float* src = irr + c * HW;
+    LossTaps t = srgb_taps(src, H, W, y, x);
+    float sorted[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) sorted[k] = t.v[k];
+    const float med = t.has_nan ? __builtin_nanf("") : median9(sorted);
+    const float diff = direct[c * HW + p] + med - gt[c * HW + p];
+    const float s = diff > 0.0f ? gs : (diff < 0.0f ? -gs : 0.0f);  // d|x| = sign(x), 0 at 0 and for NaN
+    d_direct[c * HW + p] = s;
+    if (t.has_nan || s == 0.0f) continue;
+    // the whole gradient goes to the first tap (row-major) equal to the median (median3x3_bwd_kernel)
+    int k = 0;
+    bool routed = false;
+    for (int dy = -1; dy <= 1 && !routed; dy++)
+      for (int dx = -1; dx <= 1; dx++, k++) {
+        if (t.v[k] == med) {
+          const int yy = y + dy, xx = x + dx;
+          if (!(yy < 0 || yy >= H || xx < 0 || xx >= W)) {
+            const size_t q = (size_t)yy * W + xx;
+            float d;
+            lin2srgb(src[q], d);
+            if (d != 0.0f) atomicAdd(d_irr + c * HW + q, s * d);
+          }
+          routed = true;  // a padding tap selected: the gradient is dropped
+          break;
+        }
+      }
+  }
+  const float m = mask_f[p], cnt = acc[3];
+  d_roughness[p] = -m / cnt * (0.001f * gl);
+  d_metallic[p] = m / cnt * (0.001f * gl);
+}
+
+// plain zero-fill (a kernel node rather than a memset node when the caller captures into a hipGraph)
+__global__ void __launch_bounds__(256) zero_kernel(float* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.0f;
+}
+static void launch_zero(float* p, size_t n, hipStream_t s) {
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, p, n);
+}
+
+}  // namespace gigs
+
+extern "C" {
+int gigs_internal_fail(int code, const char* fmt, ...);
+void gigs_internal_stage_begin(int stage, void* stream, void** token);
+void gigs_internal_stage_end(void* token);
+
+int gigs_gbuffer_post(int height, int width, const float* normal_map, const float* out_normal_view,
+                      const float* viewmatrix, float* normals_view, uint8_t* normal_mask, float* normal_mask_f,
+                      float* out_normal_view_filtered, void* stream) {
+  if (height <= 0 || width <= 0 || !normal_map || !out_normal_view || !viewmatrix || !normals_view ||
+      !out_normal_view_filtered)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "gbuffer_post: bad argument");
+  void* tok; gigs_internal_stage_begin(18, stream, &tok);
+  hipLaunchKernelGGL(gigs::gbuffer_post_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, height, width, normal_map, out_normal_view, viewmatrix, normals_view,
+                     normal_mask, normal_mask_f, out_normal_view_filtered);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "gbuffer_post: launch failed");
+  return 0;
+}
+
+int gigs_stage2_loss_fwd(int height, int width, const float* render_direct, const float* irr_linear,
+                         const float* gt_image, const float* normal_mask_f, const float* roughness,
+                         const float* metallic, float* render_rgb, float* acc4, float* loss, void* stream) {
+  if (height <= 0 || width <= 0 || !render_direct || !irr_linear || !gt_image || !normal_mask_f || !roughness ||
+      !metallic || !acc4 || !loss)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "stage2_loss_fwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  void* tok; gigs_internal_stage_begin(19, stream, &tok);
+  gigs::launch_zero(acc4, 4, s);
+  hipLaunchKernelGGL(gigs::stage2_loss_fwd_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, s, height,
+                     width, render_direct, irr_linear, gt_image, normal_mask_f, roughness, metallic, render_rgb, acc4);
+  hipLaunchKernelGGL(gigs::stage2_loss_finish_kernel, dim3(1), dim3(1), 0, s, height, width, acc4, loss);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "stage2_loss_fwd: launch failed");
+  return 0;
+}
+
+int gigs_stage2_loss_bwd(int height, int width, const float* render_direct, const float* irr_linear,
+                         const float* gt_image, const float* normal_mask_f, const float* acc4, const float* g_loss,
+                         float* d_render_direct, float* d_irr_linear, float* d_roughness, float* d_metallic,
+                         void* stream) {
+  if (height <= 0 || width <= 0 || !render_direct || !irr_linear || !gt_image || !normal_mask_f || !acc4 ||
+      !d_render_direct || !d_irr_linear || !d_roughness || !d_metallic)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "stage2_loss_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  void* tok; gigs_internal_stage_begin(20, stream, &tok);
+  gigs::launch_zero(d_irr_linear, 3 * (size_t)height * width, s);
+  hipLaunchKernelGGL(gigs::stage2_loss_bwd_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, s, height,
+                     width, render_direct, irr_linear, gt_image, normal_mask_f, acc4, g_loss, d_render_direct,
+                     d_irr_linear, d_roughness, d_metallic);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "stage2_loss_bwd: launch failed");
+  return 0;
+}
+
+}  // extern "C"

@@ -64,6 +64,14 @@ SIGNATURES = {
     "gigs_shade_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
                             C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
                             C.POINTER(C.c_void_p), C.c_void_p]),
+    "gigs_shade_fwd_ex": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, C.c_void_p, C.c_void_p]),
+    "gigs_shade_bwd_ex": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
+                               C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    "gigs_gbuffer_post": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_stage2_loss_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_stage2_loss_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_geom_offset": (C.c_longlong, [_i, _i]),
     "gigs_binning_offset": (C.c_longlong, [_i, _i]),
     "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),
@@ -72,6 +80,14 @@ SIGNATURES = {
     "gigs_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
     "gigs_profile_stage_name": (C.c_char_p, [_i]),
 }
+
+class ShadeExt(C.Structure):
+    """gigs_shade_ext of include/gigs_hip.h."""
+    _fields_ = [("planar", C.c_int), ("rough_scale", C.c_float), ("rough_bias", C.c_float),
+                ("out_F0", C.c_void_p), ("out_linear", C.c_void_p), ("out_roughness", C.c_void_p),
+                ("g_albedo_mul_a", C.c_void_p), ("g_albedo_mul_b", C.c_void_p),
+                ("g_roughness_add", C.c_void_p), ("g_metallic_add", C.c_void_p)]
+
 
 _lib = None
 

@@ -57,6 +57,21 @@ def make_settings(cam: Dict, sh_degree: int, bg: torch.Tensor, gi: Dict, device,
         debug=debug, inference=inference, argmax_depth=False)
 
 
+def graphed(callable_, sample_args):
+    """torch.cuda.make_graphed_callables with the garbage collector parked: a cyclic-GC pass that runs while
+    the stream is capturing may destroy older HIP objects (graphs, events, pooled blocks), which HIP refuses
+    during capture and aborts the process."""
+    import gc
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return torch.cuda.make_graphed_callables(callable_, sample_args, allow_unused_input=True)
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
 def gbuffer_post(normal_map_from_depth: torch.Tensor, normal_map: torch.Tensor, out_normal_view: torch.Tensor,
                  viewmatrix: torch.Tensor):
     """The tensor post-processing of gaussian_renderer.render (:157-199, pad_normal=False): masks,
@@ -175,8 +190,11 @@ class Stage2Step:
     individually.  Results are identical to graphs=False (same kernels, same order)."""
 
     def __init__(self, light, brdf_lut, gi: Dict, sh_degree: int, metallic: bool = True, indirect: bool = True,
-                 gamma: bool = False, tone: bool = False, graphs: bool = False):
+                 gamma: bool = False, tone: bool = False, graphs: bool = False, fused: bool = False):
         self.gi, self.sh_degree, self.metallic = gi, sh_degree, metallic
+        self.fused, self.light, self.brdf_lut = fused, light, brdf_lut
+        self.flags = dict(metallic=metallic, indirect=indirect, gamma=gamma, tone=tone)
+        self.back = None
         self.front = Stage2Front(light, brdf_lut, metallic=metallic, indirect=indirect, tone=tone, gamma=gamma)
         self.loss_fn = stage2_loss
         self.graphs = graphs
@@ -185,8 +203,8 @@ class Stage2Step:
     def _capture(self, front_args, loss_args):
         def clone(args):
             return tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
-        self.front = torch.cuda.make_graphed_callables(self.front, clone(front_args), allow_unused_input=True)
-        self.loss_fn = torch.cuda.make_graphed_callables(self.loss_fn, clone(loss_args), allow_unused_input=True)
+        self.front = graphed(self.front, clone(front_args))
+        self.loss_fn = graphed(self.loss_fn, clone(loss_args))
         self._captured = True
 
     def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], gt_image: torch.Tensor, view_dirs: torch.Tensor):
@@ -196,6 +214,9 @@ class Stage2Step:
           out_normal_view, depth_pos), screenspace_points, st) = rasterize(cam, g, self.sh_degree, background, self.gi)
         H, W = cam["image_height"], cam["image_width"]
         gi = self.gi
+        if self.fused:
+            return self._fused_step(cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view,
+                                    albedo_map, roughness_map, metallic_map, occlusion_map, depth_pos)
         front_args = (normal_map_from_depth, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
                       occlusion_map.detach(), st.viewmatrix, view_dirs)
         if self.graphs and not self._captured:
@@ -213,6 +234,31 @@ class Stage2Step:
         loss.backward()
         return dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct.detach(),
                     IRR=IRR.detach(), viewspace_points=screenspace_points, radii=radii)
+
+
+def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view, albedo_map,
+                roughness_map, metallic_map, occlusion_map, depth_pos):
+    """fused=True: everything after the rasterizer is stage2_fused._Stage2Fused (7 kernels instead of ~250)."""
+    from stage2_fused import Stage2FusedBack
+    H, W = cam["image_height"], cam["image_width"]
+    args = (normal_map.detach(), out_normal_view.detach(), albedo_map, roughness_map, metallic_map,
+            occlusion_map.detach(), depth_pos.detach(), st.viewmatrix, view_dirs, gt_image)
+    if self.back is None:
+        cfg = dict(H=H, W=W, gi=self.gi, focal_x=W / (2.0 * cam["tanfovx"]), focal_y=H / (2.0 * cam["tanfovy"]),
+                   **self.flags)
+        self.back = Stage2FusedBack(self.light, self.brdf_lut, cfg)
+        if self.graphs:
+            with torch.no_grad():
+                self.back(*args)  # builds the cached filter tables outside the capture
+            sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
+            self.back = graphed(self.back, sample)
+    loss, render_rgb, render_direct, IRR = self.back(*args)
+    loss.backward()
+    return dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct, IRR=IRR,
+                viewspace_points=screenspace_points, radii=radii)
+
+
+Stage2Step._fused_step = _fused_step
 
 
 def stage2_step(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, gi: Dict, light, brdf_lut: torch.Tensor,

@@ -190,6 +190,60 @@ int gigs_shade_bwd(int H, int W, const float* normals, const float* view_dirs, c
                    float* d_roughness, float* d_metallic, float* d_diffuse, float* const* d_spec,
                    void* stream);
 
+/* Stage-2 fusion hooks for the two shade entry points (gigs-hip extension; NULL = the plain operator).
+ * They fold the tensor glue train.py wraps around pbr_shading into the same kernels:
+ *   planar         1: normals, albedo and every [H,W,3] output / gradient are [3,H,W] planes, i.e. the
+ *                  rasterizer's own layout (no permute + copy);  view_dirs stays [H,W,3]
+ *   rough_scale/bias  roughness = raw * scale + bias (train.py:293-295); d_roughness is w.r.t. raw
+ *   forward extras (may be NULL, output layout): out_F0 = (1-m)*0.04 + albedo*m (train.py:352-356),
+ *                  out_linear = srgb_to_linear(render_rgb) (train.py:70-81), out_roughness [H,W]
+ *   backward extras (may be NULL): d_albedo += g_albedo_mul_a * g_albedo_mul_b (Gaussian_SSR's closed-form
+ *                  backward grad_out * abd, R/diff_gaussian_rasterization/__init__.py:671-673);
+ *                  g_roughness_add / g_metallic_add [H,W] are added to the roughness (remapped) / metallic
+ *                  gradients (the lamb regulariser, train.py:401-402).
+ * With ext != NULL diffuse_rgb / specular_rgb / diffuse_light may be NULL (not written). */
+typedef struct gigs_shade_ext {
+  int planar;
+  float rough_scale, rough_bias;
+  float *out_F0, *out_linear, *out_roughness;
+  const float *g_albedo_mul_a, *g_albedo_mul_b, *g_roughness_add, *g_metallic_add;
+} gigs_shade_ext;
+int gigs_shade_fwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+                      const float* roughness, const uint8_t* mask, const float* occlusion,
+                      const float* metallic, const float* background, const float* diffuse, int diffuse_res,
+                      int n_levels, const float* const* spec, const int* spec_res, const float* lut,
+                      int lut_w, int lut_h, int tone, int gamma, float* render_rgb, float* diffuse_rgb,
+                      float* specular_rgb, float* diffuse_light, const gigs_shade_ext* ext, void* stream);
+int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+                      const float* roughness, const uint8_t* mask, const float* occlusion,
+                      const float* metallic, const float* diffuse, int diffuse_res, int n_levels,
+                      const float* const* spec, const int* spec_res, const float* lut, int lut_w, int lut_h,
+                      int tone, int gamma, const float* g_render, const float* g_diffuse_rgb,
+                      const float* g_specular_rgb, const float* g_diffuse_light, float* d_albedo,
+                      float* d_roughness, float* d_metallic, float* d_diffuse, float* const* d_spec,
+                      const gigs_shade_ext* ext, void* stream);
+
+/* The rest of the stage-2 tensor glue as single passes (gigs-hip extension; all planes [C,H,W] fp32).
+ * gigs_gbuffer_post = gaussian_renderer/__init__.py:157-199 for normal_map and out_normal_view:
+ *   normal_mask = (normal_map != 0).all(0)  (u8 and/or f32 copies, either may be NULL);
+ *   normals_view = -(median3x3(normalize_where(normal_map)) @ viewmatrix[:3,:3]);
+ *   out_normal_view_filtered = median3x3(normalize_where(out_normal_view)).  No gradient (detached in stage 2).
+ * gigs_stage2_loss_fwd = train.py:382-402: render_rgb = render_direct + median3x3(linear_to_srgb(irr));
+ *   loss = mean|render_rgb - gt| + 0.001 * (mean_mask(1 - roughness) + mean_mask(metallic)); acc4 receives
+ *   {sum|.|, sum(1-r)m, sum(metallic m), sum m} (kept for the backward), render_rgb may be NULL.
+ * gigs_stage2_loss_bwd: gradients of that loss (times *g_loss, NULL = 1) w.r.t. render_direct, irr (through the
+ *   median's tap selection and the sRGB curve; overwritten), roughness and metallic [H,W]. */
+int gigs_gbuffer_post(int height, int width, const float* normal_map, const float* out_normal_view,
+                      const float* viewmatrix, float* normals_view, uint8_t* normal_mask, float* normal_mask_f,
+                      float* out_normal_view_filtered, void* stream);
+int gigs_stage2_loss_fwd(int height, int width, const float* render_direct, const float* irr_linear,
+                         const float* gt_image, const float* normal_mask_f, const float* roughness,
+                         const float* metallic, float* render_rgb, float* acc4, float* loss, void* stream);
+int gigs_stage2_loss_bwd(int height, int width, const float* render_direct, const float* irr_linear,
+                         const float* gt_image, const float* normal_mask_f, const float* acc4, const float* g_loss,
+                         float* d_render_direct, float* d_irr_linear, float* d_roughness, float* d_metallic,
+                         void* stream);
+
 /* Test/diagnostic views into the opaque scratch buffers (byte offsets from the buffer
  * start, or -1).  `which`: geometry 0 depths f32[P], 1 pos_view f32[3P], 2 means2D f32[2P],
  * 3 cov3D f32[6P], 4 conic_opacity f32[4P], 5 rgb f32[3P], 6 clamped u8[3P],

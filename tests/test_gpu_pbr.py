@@ -219,3 +219,49 @@ def test_stage2_hipgraph_capture_matches_eager(orc):
         assert rel_peak(bg_.cpu().numpy(), be.cpu().numpy()) < 1e-4
     # the two views give different results (the graphs are not replaying stale inputs)
     assert abs(results["graph"][0][0] - results["graph"][1][0]) > 1e-6
+
+
+@pytest.mark.parametrize("metallic", [True, False])
+def test_stage2_fused_matches_unfused(orc, metallic):
+    """stage2_fused (gbuffer_post + shade_ex + SSR + loss as one autograd node, 7 kernels) against the
+    op-by-op torch formulation of train.py:293-402 in pipeline.Stage2Front / stage2_loss: same loss, image
+    and gradients, eagerly and replayed from a hipGraph on a second view."""
+    import pbr
+    import pipeline
+    sc = scenes.surface_scene(P=10_000, sh_degree=2, seed=9, scale_mu=0.025)
+    gi = scenes.GI_DEFAULTS
+    H, W = 128, 160
+    cams = [scenes.orbit_camera(i, 6, W, H, radius=3.5) for i in (1, 4)]
+    camts = [{k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    torch.manual_seed(1)
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    rays = pipeline.canonical_rays(cams[0], DEV)
+    vds = [pipeline.view_dirs_for(c, rays, DEV) for c in camts]
+    results = {}
+    for mode in ("unfused", "fused", "fused_graph"):
+        torch.manual_seed(2)
+        light = pbr.CubemapLight(base_res=64, device=DEV)
+        g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        step = pipeline.Stage2Step(light, lut, gi, 2, metallic=metallic, fused=mode != "unfused",
+                                   graphs=mode == "fused_graph")
+        outs = []
+        for ci in (0, 1, 0):
+            for t in list(g.values()) + [light.base]:
+                t.grad = None
+            o = step(camts[ci], g, gt, vds[ci])
+            torch.cuda.synchronize()
+            outs.append((float(o["loss"]), {k: g[k].grad.clone() for k in ("albedo", "roughness", "metallic")},
+                         light.base.grad.clone(), o["render_rgb"].clone(), o["IRR"].clone()))
+        results[mode] = outs
+    for mode in ("fused", "fused_graph"):
+        for (lu, gu, bu, ru, iu), (lf, gf, bf, rf, irf) in zip(results["unfused"], results[mode]):
+            assert abs(lu - lf) <= 2e-6 * max(1.0, abs(lu)), (mode, lu, lf)
+            torch.testing.assert_close(irf, iu, rtol=0, atol=2e-6)
+            # a median tie / sRGB knee can move single pixels: compare the image in the mean and at the 99.9th percentile
+            d = (rf - ru).abs().flatten()
+            assert float(d.mean()) <= 1e-6 and float(torch.quantile(d, 0.999)) <= 1e-5, (mode, float(d.mean()), float(d.max()))
+            for k in gu:
+                assert rel_peak(gf[k].cpu().numpy(), gu[k].cpu().numpy()) < 2e-3, (mode, k)
+            assert rel_peak(bf.cpu().numpy(), bu.cpu().numpy()) < 2e-3, mode
+    assert abs(results["fused_graph"][0][0] - results["fused_graph"][1][0]) > 1e-6
