@@ -75,21 +75,36 @@ gbuffer_post_kernel(int H, int W, const float* __restrict__ normal_map, const fl
 // ---- loss -------------------------------------------------------------------------------------
 // acc[0] = sum |render_rgb - gt|, acc[1] = sum (1 - roughness) * mask, acc[2] = sum metallic * mask,
 // acc[3] = sum mask;  loss = acc0 / (3 H W) + 0.001 * (acc1 / acc3 + acc2 / acc3)   (train.py:396-402)
+// linear_to_srgb is a powf per texel; the 3x3 median needs it for 9 taps per pixel and channel.  A workgroup
+// (64 x 4 pixels) therefore converts its (64+2) x (4+2) halo tile once per channel into LDS (1.5 powf per pixel
+// and channel instead of 9) and the taps are read from there.  Out-of-image taps are 0 (median_blur pads zeros).
+constexpr int kTileW = 64, kTileH = 4, kHaloW = kTileW + 2, kHaloH = kTileH + 2;
 struct LossTaps {
   float v[9];
   bool has_nan;
 };
-__device__ __forceinline__ LossTaps srgb_taps(const float* __restrict__ irr, int H, int W, int y, int x) {
+__device__ __forceinline__ void srgb_tile(const float* __restrict__ irr, int H, int W, float (*s_t)[kHaloH][kHaloW]) {
+  const size_t HW = (size_t)H * W;
+  const int x0 = blockIdx.x * kTileW - 1, y0 = blockIdx.y * kTileH - 1;
+  for (int i = threadIdx.x; i < 3 * kHaloH * kHaloW; i += 256) {
+    const int c = i / (kHaloH * kHaloW), r = i - c * (kHaloH * kHaloW);
+    const int ty = r / kHaloW, tx = r - ty * kHaloW;
+    const int yy = y0 + ty, xx = x0 + tx;
+    float v = 0.0f, d;
+    if (!(yy < 0 || yy >= H || xx < 0 || xx >= W)) v = lin2srgb(irr[c * HW + (size_t)yy * W + xx], d);
+    s_t[c][ty][tx] = v;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ LossTaps srgb_taps(const float (*s_c)[kHaloW], int ly, int lx) {
   LossTaps t;
   t.has_nan = false;
   int k = 0;
 #pragma unroll
-  for (int dy = -1; dy <= 1; dy++)
+  for (int dy = 0; dy <= 2; dy++)
 #pragma unroll
-    for (int dx = -1; dx <= 1; dx++, k++) {
-      const int yy = y + dy, xx = x + dx;
-      float s = 0.0f, d;
-      if (!(yy < 0 || yy >= H || xx < 0 || xx >= W)) s = lin2srgb(irr[(size_t)yy * W + xx], d);
+    for (int dx = 0; dx <= 2; dx++, k++) {
+      const float s = s_c[ly + dy][lx + dx];
       t.v[k] = s;
       t.has_nan |= s != s;
     }
@@ -113,15 +128,18 @@ stage2_loss_fwd_kernel(int H, int W, const float* __restrict__ direct, const flo
                        const float* __restrict__ roughness, const float* __restrict__ metallic,
                        float* __restrict__ render_rgb, float* __restrict__ acc) {
   __shared__ float s_red[4];
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  __shared__ float s_t[3][kHaloH][kHaloW];
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int x = blockIdx.x * kTileW + lx;
+  const int y = blockIdx.y * kTileH + ly;
   const bool live = x < W && y < H;
   const size_t HW = (size_t)H * W, p = live ? (size_t)y * W + x : 0;
   float l1 = 0.0f, rs = 0.0f, ms = 0.0f, cnt = 0.0f;
+  srgb_tile(irr, H, W, s_t);
   if (live) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      LossTaps t = srgb_taps(irr + c * HW, H, W, y, x);
+      LossTaps t = srgb_taps(s_t[c], ly, lx);
       const float med = t.has_nan ? __builtin_nanf("") : median9(t.v);
       const float r = direct[c * HW + p] + med;
       if (render_rgb) render_rgb[c * HW + p] = r;
@@ -156,8 +174,11 @@ stage2_loss_bwd_kernel(int H, int W, const float* __restrict__ direct, const flo
                        const float* __restrict__ gt, const float* __restrict__ mask_f, const float* __restrict__ acc,
                        const float* __restrict__ g_loss, float* __restrict__ d_direct, float* __restrict__ d_irr,
                        float* __restrict__ d_roughness, float* __restrict__ d_metallic) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  __shared__ float s_t[3][kHaloH][kHaloW];
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int x = blockIdx.x * kTileW + lx;
+  const int y = blockIdx.y * kTileH + ly;
+  srgb_tile(irr, H, W, s_t);
   if (x >= W || y >= H) return;
   const size_t HW = (size_t)H * W, p = (size_t)y * W + x;
   const float gl = g_loss ? g_loss[0] : 1.0f;
@@ -165,7 +186,7 @@ stage2_loss_bwd_kernel(int H, int W, const float* __restrict__ direct, const flo
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     const float* src = irr + c * HW;
-    LossTaps t = srgb_taps(src, H, W, y, x);
+    LossTaps t = srgb_taps(s_t[c], ly, lx);
     float sorted[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) sorted[k] = t.v[k];
