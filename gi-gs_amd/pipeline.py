@@ -194,7 +194,7 @@ class Stage2Step:
         self.gi, self.sh_degree, self.metallic = gi, sh_degree, metallic
         self.fused, self.light, self.brdf_lut = fused, light, brdf_lut
         self.flags = dict(metallic=metallic, indirect=indirect, gamma=gamma, tone=tone)
-        self.back = None
+        self.back = self.mips = self.side = None
         self.front = Stage2Front(light, brdf_lut, metallic=metallic, indirect=indirect, tone=tone, gamma=gamma)
         self.loss_fn = stage2_loss
         self.graphs = graphs
@@ -210,13 +210,14 @@ class Stage2Step:
     def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], gt_image: torch.Tensor, view_dirs: torch.Tensor):
         dev = g["means3D"].device
         background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
+        lights = self._fused_begin() if self.fused else None
         ((_, radii, _, _, normal_map_from_depth, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map,
           out_normal_view, depth_pos), screenspace_points, st) = rasterize(cam, g, self.sh_degree, background, self.gi)
         H, W = cam["image_height"], cam["image_width"]
         gi = self.gi
         if self.fused:
             return self._fused_step(cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view,
-                                    albedo_map, roughness_map, metallic_map, occlusion_map, depth_pos)
+                                    albedo_map, roughness_map, metallic_map, occlusion_map, depth_pos, lights)
         front_args = (normal_map_from_depth, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
                       occlusion_map.detach(), st.viewmatrix, view_dirs)
         if self.graphs and not self._captured:
@@ -236,20 +237,42 @@ class Stage2Step:
                     IRR=IRR.detach(), viewspace_points=screenspace_points, radii=radii)
 
 
+def _fused_begin(self):
+    """Starts light.build_mips() on a side stream BEFORE the rasterizer is launched: the GGX pre-filter is
+    independent of the G-buffer, and the blend kernels leave most CUs idle while their longest tile lists
+    drain, so the two overlap.  autograd runs a node's backward on the stream of its forward, so the light's
+    backward likewise overlaps the rasterizer's backward."""
+    from stage2_fused import LightMips
+    main = torch.cuda.current_stream()
+    if self.mips is None:
+        self.side = torch.cuda.Stream()
+        self.mips = LightMips(self.light)
+        self.dummy = torch.zeros(1, device=self.light.base.device)
+        if self.graphs:
+            with torch.no_grad():
+                self.mips(self.dummy)  # builds the cached filter tables outside the capture
+            self.mips = graphed(self.mips, (self.dummy,))
+    self.side.wait_stream(main)  # light.base may have been updated on the main stream
+    with torch.cuda.stream(self.side):
+        return self.mips(self.dummy)
+
+
 def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view, albedo_map,
-                roughness_map, metallic_map, occlusion_map, depth_pos):
+                roughness_map, metallic_map, occlusion_map, depth_pos, lights):
     """fused=True: everything after the rasterizer is stage2_fused._Stage2Fused (7 kernels instead of ~250)."""
     from stage2_fused import Stage2FusedBack
     H, W = cam["image_height"], cam["image_width"]
+    main = torch.cuda.current_stream()
+    main.wait_stream(self.side)
+    for t in lights:
+        t.record_stream(main)
     args = (normal_map.detach(), out_normal_view.detach(), albedo_map, roughness_map, metallic_map,
-            occlusion_map.detach(), depth_pos.detach(), st.viewmatrix, view_dirs, gt_image)
+            occlusion_map.detach(), depth_pos.detach(), st.viewmatrix, view_dirs, gt_image, *lights)
     if self.back is None:
         cfg = dict(H=H, W=W, gi=self.gi, focal_x=W / (2.0 * cam["tanfovx"]), focal_y=H / (2.0 * cam["tanfovy"]),
                    **self.flags)
-        self.back = Stage2FusedBack(self.light, self.brdf_lut, cfg)
+        self.back = Stage2FusedBack(self.brdf_lut, cfg)
         if self.graphs:
-            with torch.no_grad():
-                self.back(*args)  # builds the cached filter tables outside the capture
             sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
             self.back = graphed(self.back, sample)
     loss, render_rgb, render_direct, IRR = self.back(*args)
@@ -258,6 +281,7 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
                 viewspace_points=screenspace_points, radii=radii)
 
 
+Stage2Step._fused_begin = _fused_begin
 Stage2Step._fused_step = _fused_step
 
 

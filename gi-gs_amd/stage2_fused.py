@@ -128,18 +128,30 @@ class _Stage2Fused(torch.autograd.Function):
         return (None, None, None, d_albedo, d_rough, d_metal, None, None, None, None, None, None, d_diffuse, *d_spec)
 
 
-class Stage2FusedBack(torch.nn.Module):
-    """build_mips + the fused node as one static-shape tensor function (hipGraph-capturable)."""
+class LightMips(torch.nn.Module):
+    """light.build_mips() as a tensor function of light.base: (diffuse, *specular).  The dummy argument only
+    gives make_graphed_callables a tensor input."""
 
-    def __init__(self, light, brdf_lut: torch.Tensor, cfg: Dict):
+    def __init__(self, light):
         super().__init__()
         self.light = light
+
+    def forward(self, _dummy):
+        self.light.build_mips()
+        return (self.light.diffuse, *self.light.specular)
+
+
+class Stage2FusedBack(torch.nn.Module):
+    """The fused node as a static-shape tensor function of the G-buffer planes and the filtered light
+    (hipGraph-capturable)."""
+
+    def __init__(self, brdf_lut: torch.Tensor, cfg: Dict):
+        super().__init__()
         self.register_buffer("brdf_lut", brdf_lut, persistent=False)
         self.cfg = cfg
 
     def forward(self, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map, occlusion_map, depth_pos,
-                viewmatrix, view_dirs, gt_image):
-        self.light.build_mips()
+                viewmatrix, view_dirs, gt_image, diffuse, *specular):
         return _Stage2Fused.apply(self.cfg, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
-                                  occlusion_map, depth_pos, viewmatrix, view_dirs, gt_image, self.brdf_lut,
-                                  self.light.diffuse, *self.light.specular)
+                                  occlusion_map, depth_pos, viewmatrix, view_dirs, gt_image, self.brdf_lut, diffuse,
+                                  *specular)

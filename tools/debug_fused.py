@@ -26,7 +26,7 @@ for mode in ("eager", "graph"):
     (_, radii, _, _, nfd, normal_map, occ, albedo_map, roughness_map, metallic_map, onv, depth_pos) = out
     cfg = dict(H=H, W=W, gi=gi, focal_x=W / (2.0 * cam["tanfovx"]), focal_y=H / (2.0 * cam["tanfovy"]), metallic=True,
                indirect=True, gamma=False, tone=False)
-    back = Stage2FusedBack(light, lut, cfg)
+    back = Stage2FusedBack(lut, cfg)
     leaves = [albedo_map.detach().clone().requires_grad_(True), roughness_map.detach().clone().requires_grad_(True),
               metallic_map.detach().clone().requires_grad_(True)]
     args = (normal_map.detach(), onv.detach(), leaves[0], leaves[1], leaves[2], occ.detach(), depth_pos.detach(),
