@@ -79,6 +79,7 @@ gbuffer_post_kernel(int H, int W, const float* __restrict__ normal_map, const fl
 // (64 x 4 pixels) therefore converts its (64+2) x (4+2) halo tile once per channel into LDS (1.5 powf per pixel
 // and channel instead of 9) and the taps are read from there.  Out-of-image taps are 0 (median_blur pads zeros).
 constexpr int kTileW = 64, kTileH = 4, kHaloW = kTileW + 2, kHaloH = kTileH + 2;
+constexpr int kAccSlots = 256;  // rows of partial sums (gigs_stage2_loss_fwd's acc buffer holds 4 + 4 * kAccSlots floats)
 struct LossTaps {
   float v[9];
   bool has_nan;
@@ -154,19 +155,36 @@ stage2_loss_fwd_kernel(int H, int W, const float* __restrict__ direct, const flo
   rs = block_sum_256(rs, s_red);
   ms = block_sum_256(ms, s_red);
   cnt = block_sum_256(cnt, s_red);
+  // Thousands of workgroups adding to the same four floats serialise in L2 (measured: 0.1 ms of a 0.14 ms
+  // kernel), so the partial sums are spread over kAccSlots rows and the finish kernel adds the rows up.
   if (threadIdx.x == 0) {
-    atomicAdd(acc + 0, l1);
-    atomicAdd(acc + 1, rs);
-    atomicAdd(acc + 2, ms);
-    atomicAdd(acc + 3, cnt);
+    float* row = acc + 4 * ((blockIdx.y * gridDim.x + blockIdx.x) % kAccSlots);
+    atomicAdd(row + 0, l1);
+    atomicAdd(row + 1, rs);
+    atomicAdd(row + 2, ms);
+    atomicAdd(row + 3, cnt);
   }
 }
 
-__global__ void stage2_loss_finish_kernel(int H, int W, const float* __restrict__ acc, float* __restrict__ loss) {
-  const float n = 3.0f * (float)H * (float)W;
-  const float l1 = acc[0] / n;
-  const float lamb = acc[1] / acc[3] + acc[2] / acc[3];
-  loss[0] = l1 + lamb * 0.001f;
+// one wave: column sums of the kAccSlots x 4 partial rows -> acc4 (kept for the backward) and the loss
+__global__ void __launch_bounds__(64)
+stage2_loss_finish_kernel(int H, int W, const float* __restrict__ rows, float* __restrict__ acc4, float* __restrict__ loss) {
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int r = threadIdx.x; r < kAccSlots; r += 64)
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] += rows[4 * r + k];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+  if (threadIdx.x == 0) {
+    const float n = 3.0f * (float)H * (float)W;
+    const float l1 = v[0] / n;
+    const float lamb = v[1] / v[3] + v[2] / v[3];
+    loss[0] = l1 + lamb * 0.001f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc4[k] = v[k];
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -257,10 +275,11 @@ int gigs_stage2_loss_fwd(int height, int width, const float* render_direct, cons
     return gigs_internal_fail(GIGS_ERR_INVALID, "stage2_loss_fwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
   void* tok; gigs_internal_stage_begin(19, stream, &tok);
-  gigs::launch_zero(acc4, 4, s);
+  float* rows = acc4 + 4;  // [kAccSlots][4] partial sums behind the four totals
+  gigs::launch_zero(rows, 4 * gigs::kAccSlots, s);
   hipLaunchKernelGGL(gigs::stage2_loss_fwd_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, s, height,
-                     width, render_direct, irr_linear, gt_image, normal_mask_f, roughness, metallic, render_rgb, acc4);
-  hipLaunchKernelGGL(gigs::stage2_loss_finish_kernel, dim3(1), dim3(1), 0, s, height, width, acc4, loss);
+                     width, render_direct, irr_linear, gt_image, normal_mask_f, roughness, metallic, render_rgb, rows);
+  hipLaunchKernelGGL(gigs::stage2_loss_finish_kernel, dim3(1), dim3(64), 0, s, height, width, rows, acc4, loss);
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "stage2_loss_fwd: launch failed");
   return 0;

@@ -13,6 +13,7 @@ plain torch elementwise ops on the GPU; nothing here touches the CPU oracle.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -210,7 +211,8 @@ class Stage2Step:
     def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], gt_image: torch.Tensor, view_dirs: torch.Tensor):
         dev = g["means3D"].device
         background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
-        lights = self._fused_begin() if self.fused else None
+        if self.fused:
+            lights = self._fused_begin()
         ((_, radii, _, _, normal_map_from_depth, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map,
           out_normal_view, depth_pos), screenspace_points, st) = rasterize(cam, g, self.sh_degree, background, self.gi)
         H, W = cam["image_height"], cam["image_width"]
@@ -238,9 +240,9 @@ class Stage2Step:
 
 
 def _fused_begin(self):
-    """Starts light.build_mips() on a side stream BEFORE the rasterizer is launched: the GGX pre-filter is
-    independent of the G-buffer, and the blend kernels leave most CUs idle while their longest tile lists
-    drain, so the two overlap.  autograd runs a node's backward on the stream of its forward, so the light's
+    """Starts light.build_mips() on a side stream before the rasterizer is launched: the GGX pre-filter is
+    independent of the G-buffer and overlaps the latency-bound binning / blend kernels (launching it after the
+    rasterizer's host call instead measured the same).  autograd runs a node's backward on the stream of its forward, so the light's
     backward likewise overlaps the rasterizer's backward."""
     from stage2_fused import LightMips
     main = torch.cuda.current_stream()

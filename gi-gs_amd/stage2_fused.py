@@ -57,7 +57,7 @@ class _Stage2Fused(torch.autograd.Function):
         mask_u8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
         mask_f = new(1, H, W)
         render_direct, F0, linear_rgb, rough_f = new(3, H, W), new(3, H, W), new(3, H, W), new(1, H, W)
-        render_rgb, acc4, loss = new(3, H, W), new(4), new(1)
+        render_rgb, acc4, loss = new(3, H, W), new(4 + 4 * 256), new(1)  # GIGS_STAGE2_ACC_FLOATS
         spec_ptr = _ptr_array(specular)
         spec_res = (C.c_int * len(specular))(*[int(s.shape[1]) for s in specular])
         ext = gigs_lib.ShadeExt(planar=1, rough_scale=1.0 - 0.04, rough_bias=0.04, out_F0=_p(F0), out_linear=_p(linear_rgb),

@@ -229,10 +229,12 @@ int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs
  *   normals_view = -(median3x3(normalize_where(normal_map)) @ viewmatrix[:3,:3]);
  *   out_normal_view_filtered = median3x3(normalize_where(out_normal_view)).  No gradient (detached in stage 2).
  * gigs_stage2_loss_fwd = train.py:382-402: render_rgb = render_direct + median3x3(linear_to_srgb(irr));
- *   loss = mean|render_rgb - gt| + 0.001 * (mean_mask(1 - roughness) + mean_mask(metallic)); acc4 receives
- *   {sum|.|, sum(1-r)m, sum(metallic m), sum m} (kept for the backward), render_rgb may be NULL.
+ *   loss = mean|render_rgb - gt| + 0.001 * (mean_mask(1 - roughness) + mean_mask(metallic)); acc4 is a
+ *   scratch of GIGS_STAGE2_ACC_FLOATS floats whose first four receive {sum|.|, sum(1-r)m, sum(metallic m),
+ *   sum m} (kept for the backward; the rest holds per-workgroup partial sums), render_rgb may be NULL.
  * gigs_stage2_loss_bwd: gradients of that loss (times *g_loss, NULL = 1) w.r.t. render_direct, irr (through the
  *   median's tap selection and the sRGB curve; overwritten), roughness and metallic [H,W]. */
+#define GIGS_STAGE2_ACC_FLOATS (4 + 4 * 256)
 int gigs_gbuffer_post(int height, int width, const float* normal_map, const float* out_normal_view,
                       const float* viewmatrix, float* normals_view, uint8_t* normal_mask, float* normal_mask_f,
                       float* out_normal_view_filtered, void* stream);
