@@ -82,8 +82,12 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const float* __restrict__ viewmatrix, const float* __restrict__ bg_color,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, BlendOut o,
                  int argmax_depth, int inference, uint8_t* __restrict__ hit_mask, int cull) {
-  __shared__ float4 s_rec[GIGS_BREC_F4 * kBatch];  // [k][j], 20 KB
-  __shared__ unsigned long long s_hit[4 * (kBatch / 64)];  // [wave][chunk] contribution bits of the batch
+  // Each wave walks the tile's list on its own (no workgroup barrier anywhere): the time of a tile is the
+  // time of its busiest quadrant, not the sum over batches of the slowest quadrant of each batch, and a wave
+  // whose 64 pixels are saturated leaves at once.  The list is consumed in chunks of 64 instances, one per
+  // lane, through a two-deep register pipeline (ids two chunks ahead, the 80-byte records one chunk ahead),
+  // so the dependent index -> record gathers of the next chunk are in flight while this one is blended.
+  __shared__ float4 s_rec[4][GIGS_BREC_F4 * 64];  // per wave, [k][slot]: 4 x 5 KB
 
   const unsigned tile = blockIdx.x;
   const unsigned ty = tile / gx, tx = tile - ty * gx;
@@ -96,8 +100,9 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   bool done = !inside;
 
   const uint2 range = ranges[tile];
-  const int rounds = ((range.y - range.x + kBatch - 1) / kBatch);
-  int toDo = range.y - range.x;
+  const int n = (int)(range.y - range.x);
+  float4* sw = s_rec[wave];
+  uint8_t* hit = hit_mask + 4 * (size_t)range.x + wave;  // this quadrant's byte of instance i: hit[4 * i]
 
   float T = 1.0f;
   uint32_t last_contributor = 0;
@@ -105,87 +110,85 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   float Rr = 0, Mm = 0, O = 0, P0 = 0, P1 = 0, P2 = 0;  // P2 doubles as D (depth == pos_view.z)
   float max_weight = 0.0f, e0 = 0, e1 = 0, e2 = 0;
 
-  // Instances of batches that are never fetched (every pixel done) contribute nowhere: their mask is 0.
-  for (uint32_t k = range.x + tid; k < range.y; k += GIGS_TILE) hit_mask[k] = 0;
   // pixel-centre box of this wave's quadrant
   const float qx0 = (float)(tx * GIGS_BLOCK_X + (wave & 1) * 8), qy0 = (float)(ty * GIGS_BLOCK_Y + (wave >> 1) * 8);
-  for (int i = 0; i < rounds; i++, toDo -= kBatch) {
-    const int num_done = __syncthreads_count(done);
-    if (num_done == GIGS_TILE) break;
-    const int progress = i * kBatch + tid;
-    if (range.x + progress < range.y) {
-      const uint32_t coll_id = point_list[range.x + progress];
-      const float4* src = brec + (size_t)coll_id * GIGS_BREC_F4;
-#pragma unroll
-      for (int k = 0; k < GIGS_BREC_F4; k++) s_rec[k * kBatch + tid] = src[k];
-    }
-    __syncthreads();
 
-    const int n = min(kBatch, toDo);
-    unsigned long long hits[kBatch / 64] = {0ull, 0ull, 0ull, 0ull};
-    bool wave_done = __ballot(!done) == 0ull;
+  // pipeline prologue: records of chunk 0, ids of chunk 1
+  float4 rec[GIGS_BREC_F4];
 #pragma unroll
-    for (int c = 0; c < kBatch / 64; c++) {
-      if (wave_done || c * 64 >= n) continue;
-      // instance-parallel cull: lane l tests instance c*64+l against the quadrant, the wave then walks
-      // only the surviving bits (in list order, so the blend order is unchanged)
-      unsigned long long m;
-      {
-        const int jj = c * 64 + lane;
-        const float4 q0 = s_rec[jj], q1 = s_rec[kBatch + jj];
-        m = __ballot(jj < n && !(cull && quadrant_never_blends(q0.x - qx0, q0.y - qy0, q1.x, q1.y, q1.z, q1.w)));
-      }
-      while (m != 0ull) {
-        const int bit = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const int j = c * 64 + bit;
-        const float4 r0 = s_rec[j];           // mean2D.xy, roughness, metallic
-        const float4 r1 = s_rec[kBatch + j];  // conic xyz, opacity
-        const float dx = r0.x - pixfx, dy = r0.y - pixfy;
-        const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-        // same decisions as the reference's `continue` chain (forward.cu:533-547), kept as predicates so
-        // that the wave can record whether ANY of its pixels blends this Gaussian
-        const float alpha = fminf(0.99f, r1.w * expf(power));
-        const float test_T = T * (1 - alpha);
-        const bool cand = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        const bool stop = cand && test_T < 0.0001f;
-        const bool contrib = cand && !stop;
-        if (stop) done = true;
-        if (__ballot(contrib) != 0ull) hits[c] |= 1ull << bit;
-        if (contrib) {
-          const float weight = alpha * T;
-          const float4 r2 = s_rec[2 * kBatch + j];  // rgb, pos.x
-          const float4 r3 = s_rec[3 * kBatch + j];  // normal, pos.y
-          const float4 r4 = s_rec[4 * kBatch + j];  // albedo, pos.z
-          C0 += r2.x * weight; C1 += r2.y * weight; C2 += r2.z * weight;
-          A0 += r4.x * weight; A1 += r4.y * weight; A2 += r4.z * weight;
-          N0 += r3.x * weight; N1 += r3.y * weight; N2 += r3.z * weight;
-          Rr += r0.z * weight;
-          Mm += r0.w * weight;
-          P0 += r2.w * weight; P1 += r3.w * weight; P2 += r4.w * weight;
-          O += weight;
-          if (weight > max_weight) {
-            e0 = r2.w; e1 = r3.w; e2 = r4.w;
-            max_weight = weight;
-          }
-          T = test_T;
-          last_contributor = (uint32_t)(i * kBatch + j + 1);
-        }
-        if (__ballot(stop) != 0ull && __ballot(!done) == 0ull) { wave_done = true; break; }
-      }
-    }
-    if (lane == 0) {
+  for (int k = 0; k < GIGS_BREC_F4; k++) rec[k] = make_float4(0, 0, 0, 0);
+  if (lane < n) {
+    const float4* src = brec + (size_t)point_list[range.x + lane] * GIGS_BREC_F4;
 #pragma unroll
-      for (int c = 0; c < kBatch / 64; c++) s_hit[wave * (kBatch / 64) + c] = hits[c];
-    }
-    __syncthreads();
-    if (range.x + progress < range.y) {
-      uint32_t byte = 0;
-#pragma unroll
-      for (int w = 0; w < 4; w++) byte |= (uint32_t)((s_hit[w * (kBatch / 64) + wave] >> lane) & 1ull) << w;
-      hit_mask[range.x + progress] = (uint8_t)byte;
-    }
+    for (int k = 0; k < GIGS_BREC_F4; k++) rec[k] = src[k];
   }
+  uint32_t id_next = (64 + lane < n) ? point_list[range.x + 64 + lane] : 0u;
+
+  int base = 0;
+  bool wave_done = __ballot(!done) == 0ull;
+  for (; base < n && !wave_done; base += 64) {
+    const bool valid = base + lane < n;
+    // this chunk: stage the records for the broadcast reads of the walk, keep mean/conic/opacity for the cull
+    const float4 q0 = rec[0], q1 = rec[1];
+#pragma unroll
+    for (int k = 0; k < GIGS_BREC_F4; k++) sw[k * 64 + lane] = rec[k];
+    // next chunk's records and the ids after that: in flight while this chunk is walked
+    if (base + 64 + lane < n) {
+      const float4* src = brec + (size_t)id_next * GIGS_BREC_F4;
+#pragma unroll
+      for (int k = 0; k < GIGS_BREC_F4; k++) rec[k] = src[k];
+    }
+    id_next = (base + 128 + lane < n) ? point_list[range.x + base + 128 + lane] : 0u;
+
+    // instance-parallel cull: lane l tests instance base+l against the quadrant, the wave then walks only
+    // the surviving bits (in list order, so the blend order is unchanged)
+    unsigned long long m =
+        __ballot(valid && !(cull && quadrant_never_blends(q0.x - qx0, q0.y - qy0, q1.x, q1.y, q1.z, q1.w)));
+    unsigned long long hits = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    while (m != 0ull) {
+      const int bit = __builtin_ctzll(m);
+      m &= m - 1ull;
+      const float4 r0 = sw[bit];       // mean2D.xy, roughness, metallic
+      const float4 r1 = sw[64 + bit];  // conic xyz, opacity
+      const float dx = r0.x - pixfx, dy = r0.y - pixfy;
+      const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+      // same decisions as the reference's `continue` chain (forward.cu:533-547), kept as predicates so
+      // that the wave can record whether ANY of its pixels blends this Gaussian
+      const float alpha = fminf(0.99f, r1.w * expf(power));
+      const float test_T = T * (1 - alpha);
+      const bool cand = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+      const bool stop = cand && test_T < 0.0001f;
+      const bool contrib = cand && !stop;
+      if (stop) done = true;
+      if (__ballot(contrib) != 0ull) hits |= 1ull << bit;
+      if (contrib) {
+        const float weight = alpha * T;
+        const float4 r2 = sw[2 * 64 + bit];  // rgb, pos.x
+        const float4 r3 = sw[3 * 64 + bit];  // normal, pos.y
+        const float4 r4 = sw[4 * 64 + bit];  // albedo, pos.z
+        C0 += r2.x * weight; C1 += r2.y * weight; C2 += r2.z * weight;
+        A0 += r4.x * weight; A1 += r4.y * weight; A2 += r4.z * weight;
+        N0 += r3.x * weight; N1 += r3.y * weight; N2 += r3.z * weight;
+        Rr += r0.z * weight;
+        Mm += r0.w * weight;
+        P0 += r2.w * weight; P1 += r3.w * weight; P2 += r4.w * weight;
+        O += weight;
+        if (weight > max_weight) {
+          e0 = r2.w; e1 = r3.w; e2 = r4.w;
+          max_weight = weight;
+        }
+        T = test_T;
+        last_contributor = (uint32_t)(base + bit + 1);
+      }
+      if (__ballot(stop) != 0ull && __ballot(!done) == 0ull) { wave_done = true; break; }
+    }
+    __builtin_amdgcn_wave_barrier();  // the walk's LDS reads precede the next chunk's staging stores
+    if (valid) hit[4 * (size_t)(base + lane)] = (uint8_t)((hits >> lane) & 1ull);
+  }
+  // instances of chunks that were never fetched (every pixel of the quadrant saturated) blend nowhere here
+  for (int i = base + lane; i < n; i += 64) hit[4 * (size_t)i] = 0;
 
   if (inside) {
     const size_t HW = (size_t)H * W;
@@ -242,10 +245,13 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
                  const uint32_t* __restrict__ n_contrib, BlendGradIn gi, float* __restrict__ grec,
                  const uint8_t* __restrict__ hit_mask) {
-  __shared__ float4 s_rec[3 * kBatch];       // [k][j] k = 0..2 (mean2D, conic/opacity, rgb)
-  __shared__ uint32_t s_id[kBatch];
-  __shared__ uint32_t s_hit[kBatch];
-  __shared__ float s_acc[kBatch * GIGS_GREC];  // 20 KB, [j][20]
+  // Wave-autonomous like the forward: each wave walks the tile's list back to front in chunks of 64 instances
+  // (lane l of chunk c <-> instance n-1-(64c+l)), fetching only the instances its quadrant blended (the
+  // forward's hit byte), two-deep pipelined, no workgroup barrier.  The 19 per-Gaussian sums of a wave are
+  // reduced with DPP, bounced through 80 bytes of LDS so that lane k holds sum k, and leave as ONE
+  // global_atomic_add_f32 wave-instruction over the contiguous 80-byte gradient record (non-zero lanes only).
+  __shared__ float4 s_rec[4][3 * 64];            // per wave, [k][slot], k = 0..2 (mean2D, conic/opacity, rgb)
+  __shared__ __align__(16) float s_sum[4][GIGS_GREC];  // per wave: the reduced sums of the current instance
 
   const unsigned tile = blockIdx.x;
   const unsigned ty = tile / gx, tx = tile - ty * gx;
@@ -258,8 +264,10 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   const float pixfx = (float)px, pixfy = (float)py;
 
   const uint2 range = ranges[tile];
-  const int rounds = ((range.y - range.x + kBatch - 1) / kBatch);
-  int toDo = range.y - range.x;
+  const int n = (int)(range.y - range.x);
+  float4* sw = s_rec[wave];
+  float* ssum = s_sum[wave];
+  const uint8_t* hit = hit_mask + 4 * (size_t)range.x + wave;
 
   const float T_final = inside ? final_Ts[pix_id] : 0;
   float T = T_final;
@@ -283,56 +291,70 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   }
   const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
   const float bg_dot_dpixel = 0 + bg_color[0] * dp0 + bg_color[1] * dp1 + bg_color[2] * dp2;
-  // Which incoming gradient planes are non-zero anywhere in this tile?  A plane that is zero for
-  // all 256 pixels contributes exact zeros to every sum, so its reductions are skipped (stage-2
-  // training feeds only albedo / roughness / metallic gradients: SURVEY Appendix D).
+  // Which incoming gradient planes are non-zero anywhere in this QUADRANT?  A plane that is zero for all 64
+  // pixels contributes exact zeros to every sum, so its reductions are skipped (stage-2 training feeds only
+  // albedo / roughness / metallic gradients: SURVEY Appendix D).
   //   geo: colour or opacity grads -> dL_dalpha -> mean2D, conic, opacity, colour (v[0..9])
-  const bool any_geo = __syncthreads_or((dp0 != 0.0f) | (dp1 != 0.0f) | (dp2 != 0.0f) | (dop != 0.0f)) != 0;
-  const bool any_nrm = __syncthreads_or((dn0 != 0.0f) | (dn1 != 0.0f) | (dn2 != 0.0f)) != 0;
-  const bool any_mat = __syncthreads_or((da0 != 0.0f) | (da1 != 0.0f) | (da2 != 0.0f) | (drg != 0.0f) | (dmt != 0.0f)) != 0;
-  const bool any_dep = __syncthreads_or(ddp != 0.0f) != 0;
+  const bool any_geo = __any((dp0 != 0.0f) | (dp1 != 0.0f) | (dp2 != 0.0f) | (dop != 0.0f)) != 0;
+  const bool any_nrm = __any((dn0 != 0.0f) | (dn1 != 0.0f) | (dn2 != 0.0f)) != 0;
+  const bool any_mat = __any((da0 != 0.0f) | (da1 != 0.0f) | (da2 != 0.0f) | (drg != 0.0f) | (dmt != 0.0f)) != 0;
+  const bool any_dep = __any(ddp != 0.0f) != 0;
+  if (!(any_geo || any_nrm || any_mat || any_dep)) return;  // every sum of this quadrant is an exact zero
 
-  for (int i = 0; i < rounds; i++, toDo -= kBatch) {
-    __syncthreads();
-    const int progress = i * kBatch + tid;
-    if (range.x + progress < range.y) {
-      const uint32_t coll_id = point_list[range.y - progress - 1];
-      s_id[tid] = coll_id;
-      s_hit[tid] = hit_mask[range.y - progress - 1];
-      const float4* src = brec + (size_t)coll_id * GIGS_BREC_F4;
+  // pipeline prologue (chunk 0 = the last 64 instances): ids + hit bytes of chunks 0 and 1, records of chunk 0
+  auto fetch_id = [&](int base, uint32_t& id, bool& h) {
+    const int idx = n - 1 - (base + lane);
+    h = idx >= 0 && hit[4 * (size_t)idx] != 0;
+    id = h ? point_list[range.x + idx] : 0u;
+  };
+  uint32_t id_cur, id_next;
+  bool h_cur, h_next;
+  fetch_id(0, id_cur, h_cur);
+  fetch_id(64, id_next, h_next);
+  float4 rec[3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) s_rec[k * kBatch + tid] = src[k];
-    }
-    {
-      float4* z = reinterpret_cast<float4*>(s_acc) + tid * (GIGS_GREC / 4);
+  for (int k = 0; k < 3; k++) rec[k] = make_float4(0, 0, 0, 0);
+  if (h_cur) {
+    const float4* src = brec + (size_t)id_cur * GIGS_BREC_F4;
 #pragma unroll
-      for (int k = 0; k < GIGS_GREC / 4; k++) z[k] = make_float4(0, 0, 0, 0);
-    }
-    __syncthreads();
+    for (int k = 0; k < 3; k++) rec[k] = src[k];
+  }
 
-    const int n = min(kBatch, toDo);
-    // the forward recorded which quadrants blended each instance (same tests, same expf): the wave walks only
-    // the instances whose bit is set for its quadrant, newest first
-#pragma unroll 1
-    for (int c = 0; c < kBatch / 64; c++) {
-      unsigned long long m = __ballot(c * 64 + lane < n && ((s_hit[c * 64 + lane] >> wave) & 1u) != 0u);
-      while (m != 0ull) {
-      const int j = c * 64 + __builtin_ctzll(m);
+  for (int base = 0; base < n; base += 64) {
+    unsigned long long m = __ballot(h_cur);
+    const uint32_t my_id = id_cur;
+    if (m != 0ull) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) sw[k * 64 + lane] = rec[k];
+    }
+    // next chunk's records, and the ids / hit bytes of the chunk after it
+    id_cur = id_next; h_cur = h_next;
+    if (h_cur) {
+      const float4* src = brec + (size_t)id_cur * GIGS_BREC_F4;
+#pragma unroll
+      for (int k = 0; k < 3; k++) rec[k] = src[k];
+    }
+    fetch_id(base + 128, id_next, h_next);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    while (m != 0ull) {
+      const int bit = __builtin_ctzll(m);
       m &= m - 1ull;
-      const int contributor = toDo - 1 - j;  // index of the instance in the tile list
-      const float4 r0 = s_rec[j];
-      const float4 r1 = s_rec[kBatch + j];
+      const int contributor = n - 1 - (base + bit);  // index of the instance in the tile list
+      const float4 r0 = sw[bit];
+      const float4 r1 = sw[64 + bit];
       const float dx = r0.x - pixfx, dy = r0.y - pixfy;
       const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
       const float G = expf(power);
       const float alpha = fminf(0.99f, r1.w * G);
       const bool act = inside && (contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 
-      float v[19];
+      float v[GIGS_GREC];
 #pragma unroll
-      for (int k = 0; k < 19; k++) v[k] = 0.0f;
+      for (int k = 0; k < GIGS_GREC; k++) v[k] = 0.0f;
       if (act) {
-        const float4 r2 = s_rec[2 * kBatch + j];
+        const float4 r2 = sw[2 * 64 + bit];
         T = T / (1.f - alpha);
         const float dchannel_dcolor = alpha * T;
         float dL_dalpha = 0.0f;
@@ -365,47 +387,36 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
         v[5] = -0.5f * gdy * dy * dL_dG;
         v[6] = G * dL_dalpha;
       }
-      float* acc = s_acc + j * GIGS_GREC;
       if (any_geo) {
 #pragma unroll
         for (int k = 0; k < 10; k++) v[k] = wave_sum_lane63(v[k]);
-        if (lane == 63) {
-#pragma unroll
-          for (int k = 0; k < 10; k++) atomicAdd(acc + k, v[k]);
-        }
       }
       if (any_nrm) {
 #pragma unroll
         for (int k = 10; k < 13; k++) v[k] = wave_sum_lane63(v[k]);
-        if (lane == 63) {
-#pragma unroll
-          for (int k = 10; k < 13; k++) atomicAdd(acc + k, v[k]);
-        }
       }
       if (any_mat) {
 #pragma unroll
         for (int k = 13; k < 18; k++) v[k] = wave_sum_lane63(v[k]);
-        if (lane == 63) {
+      }
+      if (any_dep) v[18] = wave_sum_lane63(v[18]);
+      // lane 63 holds the sums of the groups that ran (exact zeros elsewhere): 80 bytes to LDS, then lane k
+      // adds sum k to float k of the Gaussian's gradient record
+      if (lane == 63) {
+        float4* d4 = reinterpret_cast<float4*>(ssum);
 #pragma unroll
-          for (int k = 13; k < 18; k++) atomicAdd(acc + k, v[k]);
-        }
+        for (int k = 0; k < GIGS_GREC / 4; k++) d4[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
       }
-      if (any_dep) {
-        v[18] = wave_sum_lane63(v[18]);
-        if (lane == 63) atomicAdd(acc + 18, v[18]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, bit);
+      if (lane < GIGS_GREC) {
+        const float val = ssum[lane];
+        if (val != 0.0f) atomicAdd(grec + (size_t)gid * GIGS_GREC + lane, val);
       }
-      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    // flush: consecutive lanes -> consecutive floats of consecutive 80-byte rows
-    const int total = n * GIGS_GREC;
-    for (int e = tid; e < total; e += GIGS_TILE) {
-      const float val = s_acc[e];
-      if (val != 0.0f) {
-        const int j = e / GIGS_GREC, k = e - j * GIGS_GREC;
-        atomicAdd(grec + (size_t)s_id[j] * GIGS_GREC + k, val);
-      }
-    }
+    __builtin_amdgcn_wave_barrier();  // the walk's LDS reads precede the next chunk's staging stores
   }
 }
 

@@ -188,7 +188,7 @@ struct BinningState {
   uint32_t* values_unsorted;
   uint64_t* keys;
   uint32_t* point_list;
-  uint8_t* hit_mask;  // per instance: bit w set iff wave (quadrant) w of the tile had a contributing pixel
+  uint8_t* hit_mask;  // [R][4]: byte w of instance i is 1 iff quadrant (wave) w of its tile had a pixel that blended it
   char* sort_space;
   size_t sort_size;
   static BinningState fromChunk(char*& chunk, size_t R, size_t sort_size) {
@@ -197,7 +197,7 @@ struct BinningState {
     carve(chunk, b.values_unsorted, R);
     carve(chunk, b.keys, R);
     carve(chunk, b.point_list, R);
-    carve(chunk, b.hit_mask, R);
+    carve(chunk, b.hit_mask, 4 * R);
     b.sort_size = sort_size;
     carve(chunk, b.sort_space, sort_size);
     return b;
