@@ -72,6 +72,20 @@ __device__ __forceinline__ bool quadrant_never_blends(float u0, float v0, float 
   return qmin > tau + 1e-5f * smax + 1e-2f;  // false for NaN
 }
 
+// exp(x) for the blend exponent (x <= 0 wherever the value is used; |x| < 6 wherever alpha passes 1/255).
+// x * log2(e) is formed as an fp32 product plus its exact FMA residual and the low word of the constant, the
+// hardware exp2 (v_exp_f32, ~1 ulp) takes the high part and the low part is applied as e * (1 + lo * ln 2):
+// 6 instructions and <= 2 ulp, against ~18 for OCML's expf (1 ulp) -- the same accuracy class as the
+// reference's CUDA expf (2 ulp).  The forward and the backward must (and do) use the SAME function: the
+// backward re-derives the forward's alpha tests bit for bit.
+__device__ __forceinline__ float blend_exp(float x) {
+  const float L = 0x1.715476p+0f, L_lo = 0x1.4ae0cp-26f;  // log2(e) = L + L_lo
+  const float y = x * L;
+  const float lo = __builtin_fmaf(x, L_lo, __builtin_fmaf(x, L, -y));
+  const float e = __builtin_amdgcn_exp2f(y);
+  return __builtin_fmaf(e, lo * 0x1.62e43p-1f, e);
+}
+
 struct BlendOut {
   float *color, *opacity, *depth, *normal, *normal_view, *pos, *albedo, *roughness, *metallic;
 };
@@ -156,7 +170,7 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
       const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
       // same decisions as the reference's `continue` chain (forward.cu:533-547), kept as predicates so
       // that the wave can record whether ANY of its pixels blends this Gaussian
-      const float alpha = fminf(0.99f, r1.w * expf(power));
+      const float alpha = fminf(0.99f, r1.w * blend_exp(power));
       const float test_T = T * (1 - alpha);
       const bool cand = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
       const bool stop = cand && test_T < 0.0001f;
@@ -175,7 +189,7 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
         Mm += r0.w * weight;
         P0 += r2.w * weight; P1 += r3.w * weight; P2 += r4.w * weight;
         O += weight;
-        if (weight > max_weight) {
+        if (argmax_depth && weight > max_weight) {  // only the argmax_depth outputs read e0..e2
           e0 = r2.w; e1 = r3.w; e2 = r4.w;
           max_weight = weight;
         }
@@ -346,7 +360,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
       const float4 r1 = sw[64 + bit];
       const float dx = r0.x - pixfx, dy = r0.y - pixfy;
       const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-      const float G = expf(power);
+      const float G = blend_exp(power);
       const float alpha = fminf(0.99f, r1.w * G);
       const bool act = inside && (contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 
@@ -354,38 +368,40 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
 #pragma unroll
       for (int k = 0; k < GIGS_GREC; k++) v[k] = 0.0f;
       if (act) {
-        const float4 r2 = sw[2 * 64 + bit];
         T = T / (1.f - alpha);
         const float dchannel_dcolor = alpha * T;
-        float dL_dalpha = 0.0f;
-        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = r2.x;
-        dL_dalpha += (r2.x - ar0) * dp0;
-        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = r2.y;
-        dL_dalpha += (r2.y - ar1) * dp1;
-        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = r2.z;
-        dL_dalpha += (r2.z - ar2) * dp2;
-        v[7] = dchannel_dcolor * dp0; v[8] = dchannel_dcolor * dp1; v[9] = dchannel_dcolor * dp2;
         v[10] = dchannel_dcolor * dn0; v[11] = dchannel_dcolor * dn1; v[12] = dchannel_dcolor * dn2;
         v[13] = dchannel_dcolor * da0; v[14] = dchannel_dcolor * da1; v[15] = dchannel_dcolor * da2;
         v[16] = dchannel_dcolor * drg;
         v[17] = dchannel_dcolor * dmt;
         v[18] = dchannel_dcolor * ddp;
-        accum_opacity = last_alpha + (1.f - last_alpha) * accum_opacity;
-        dL_dalpha += (1.0f - accum_opacity) * dop;
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-        const float dL_dG = r1.w * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
-        const float dG_ddely = -gdy * r1.z - gdx * r1.y;
-        v[0] = dL_dG * dG_ddelx * ddelx_dx;
-        v[1] = dL_dG * dG_ddely * ddely_dy;
-        v[2] = fabsf(v[0]) + fabsf(v[1]);
-        v[3] = -0.5f * gdx * dx * dL_dG;
-        v[4] = -0.5f * gdx * dy * dL_dG;
-        v[5] = -0.5f * gdy * dy * dL_dG;
-        v[6] = G * dL_dalpha;
+        if (any_geo) {  // wave-uniform: the dL_dalpha chain (and its running colour / opacity state) feeds v[0..9] only
+          const float4 r2 = sw[2 * 64 + bit];
+          float dL_dalpha = 0.0f;
+          ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = r2.x;
+          dL_dalpha += (r2.x - ar0) * dp0;
+          ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = r2.y;
+          dL_dalpha += (r2.y - ar1) * dp1;
+          ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = r2.z;
+          dL_dalpha += (r2.z - ar2) * dp2;
+          v[7] = dchannel_dcolor * dp0; v[8] = dchannel_dcolor * dp1; v[9] = dchannel_dcolor * dp2;
+          accum_opacity = last_alpha + (1.f - last_alpha) * accum_opacity;
+          dL_dalpha += (1.0f - accum_opacity) * dop;
+          dL_dalpha *= T;
+          last_alpha = alpha;
+          dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+          const float dL_dG = r1.w * dL_dalpha;
+          const float gdx = G * dx, gdy = G * dy;
+          const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
+          const float dG_ddely = -gdy * r1.z - gdx * r1.y;
+          v[0] = dL_dG * dG_ddelx * ddelx_dx;
+          v[1] = dL_dG * dG_ddely * ddely_dy;
+          v[2] = fabsf(v[0]) + fabsf(v[1]);
+          v[3] = -0.5f * gdx * dx * dL_dG;
+          v[4] = -0.5f * gdx * dy * dL_dG;
+          v[5] = -0.5f * gdy * dy * dL_dG;
+          v[6] = G * dL_dalpha;
+        }
       }
       if (any_geo) {
 #pragma unroll
