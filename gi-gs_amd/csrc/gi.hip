@@ -220,6 +220,11 @@ __device__ __forceinline__ f32x2 div2_fast(f32x2 n, float d) {
 // that trunc(t + copysign(0.5 - 2^-25, t)) rounds half away from zero like roundf.
 __device__ __forceinline__ int round_to_int(float t) { return f2i(t + copysignf(0.49999997f, t)); }
 
+// Buffer descriptor (raw, byte offsets, hardware range check) of one fp32 image plane.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t z_plane_rsrc(const float* plane, size_t HW) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane), /*stride*/ 0, (int)(HW * sizeof(float)), 0x00020000);
+}
+
 // Sample coordinates of one group of steps for kRays rays: byte offset into the z plane (0 when the sample
 // is outside the image), the in-image flag and the sample's z.  kExact = false uses the shared-reciprocal
 // FMA chain for every lane and returns the smallest |den| seen, so that the caller can decide ONCE per
@@ -262,11 +267,11 @@ __device__ __forceinline__ float group_coords(const GiParams& p, v3 pos, float a
       const int ix = round_to_int(t.x);
       const int iy = round_to_int(t.y);
       inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
-      // The gather address is clamped into the image instead of predicated (an out-of-image sample is
-      // never used: inb is false).  W, H < 2^15 (checked by the C-ABI wrapper): 24-bit multiply, and the
-      // byte offset fits 32 bits so the load takes the scalar-base + 32-bit-offset form.
-      const unsigned cxi = min((unsigned)ix, (unsigned)(p.W - 1)), cyi = min((unsigned)iy, (unsigned)(p.H - 1));
-      off[k][g] = (__umul24(cyi, (unsigned)p.W) + cxi) << 2;
+      // The gather goes through a buffer descriptor of exactly the z plane: an out-of-image sample (never
+      // used: inb is false) yields some wrapped offset that the hardware range check either reads harmlessly
+      // or answers with 0 -- no clamp, no predication.  W, H < 2^15 (checked by the C-ABI wrapper), so the
+      // in-image offset is exact in the 24-bit multiply and fits 32 bits.
+      off[k][g] = (__umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix) << 2;
       spzv[k][g] = spz;
     }
   }
@@ -285,11 +290,10 @@ __device__ __forceinline__ float group_coords(const GiParams& p, v3 pos, float a
 //     scalar unit is not spent on exec-mask bookkeeping.
 template <bool kPow2, int kGroup, int kRays, bool kExact>
 __device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
-                                           const float* __restrict__ pos_z, bool mag_ok, int* hit) {
+                                           __amdgpu_buffer_rsrc_t pos_z, bool mag_ok, int* hit) {
   bool open[kRays];
 #pragma unroll
   for (int k = 0; k < kRays; k++) { open[k] = true; hit[k] = -1; }
-  const char* zbase = reinterpret_cast<const char*>(pos_z);
   float min_den = __builtin_inff();
   for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
     unsigned off[kRays][kGroup];
@@ -299,7 +303,8 @@ __device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, c
 #pragma unroll
     for (int g = 0; g < kGroup; g++)
 #pragma unroll
-      for (int k = 0; k < kRays; k++) zv[k][g] = *reinterpret_cast<const float*>(zbase + off[k][g]);
+      for (int k = 0; k < kRays; k++)
+        zv[k][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pos_z, (int)off[k][g], 0, 0));
     bool any_open = false;
 #pragma unroll
     for (int k = 0; k < kRays; k++) {
@@ -322,7 +327,7 @@ __device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, c
 // one carries neither the branches nor the registers of the rare one.
 template <bool kPow2, int kGroup, int kRays>
 __device__ __forceinline__ void march(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
-                                      const float* __restrict__ pos_z, bool mag_ok, int* hit) {
+                                      __amdgpu_buffer_rsrc_t pos_z, bool mag_ok, int* hit) {
   const bool bad = march_impl<kPow2, kGroup, kRays, false>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
   if (__builtin_expect(__any(bad), 0)) march_impl<kPow2, kGroup, kRays, true>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
 }
@@ -391,7 +396,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
     const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
     if (!tbn_never_hits(tbn)) {
       const v3 pos = {pos_map[pix_id], pos_map[HW + pix_id], pos_map[2 * HW + pix_id]};
-      const float* pos_z = pos_map + 2 * HW;
+      const __amdgpu_buffer_rsrc_t pos_z = z_plane_rsrc(pos_map + 2 * HW, HW);
       const float a = 1 + pos.z / 100;
       const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
       const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
@@ -448,7 +453,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
   const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
   v3 diffuse = {0, 0, 0};
   if (inside && p.start < p.step && !tbn_never_hits(tbn)) {
-    const float* pos_z = pos_map + 2 * HW;
+    const __amdgpu_buffer_rsrc_t pos_z = z_plane_rsrc(pos_map + 2 * HW, HW);
     const float a = 1 + pos.z / 100;
     const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
     const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
