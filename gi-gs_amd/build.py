@@ -15,8 +15,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libgigs_hip.so")
+OBJ = os.environ.get("GIGS_OBJ", os.path.join(HERE, "build"))
+LIB = os.environ.get("GIGS_LIB", os.path.join(HERE, "libgigs_hip.so"))
 SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "blend.hip", "gi.hip", "pbr.hip", "stage2.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [

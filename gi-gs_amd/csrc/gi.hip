@@ -363,8 +363,14 @@ __device__ __forceinline__ bool tbn_never_hits(const Tbn& m) {
   return (m.t.x != m.t.x) && (m.t.y != m.t.y) && (m.t.z != m.t.z);
 }
 
-constexpr int kGiGroup = 4;
-constexpr int kGiRays = 2;  // rays marched together per lane (independent instruction streams)
+#ifndef GIGS_GI_GROUP
+#define GIGS_GI_GROUP 4
+#endif
+#ifndef GIGS_GI_RAYS
+#define GIGS_GI_RAYS 2
+#endif
+constexpr int kGiGroup = GIGS_GI_GROUP;  // steps whose gathers are issued together
+constexpr int kGiRays = GIGS_GI_RAYS;    // rays marched together per lane (independent instruction streams)
 constexpr int kGiWaves = 4;
 constexpr int kGiTileLog2W = 3;
 

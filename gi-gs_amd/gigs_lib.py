@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgigs_hip.so")
+LIB_PATH = os.environ.get("GIGS_LIB", os.path.join(_HERE, "libgigs_hip.so"))  # GIGS_LIB: tuning builds
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
