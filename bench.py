@@ -78,12 +78,30 @@ def pmc_traffic(stage: str):
     names = {"ssao": "ssao_kernel<true>", "ssr": "ssr_kernel<true>", "blend_fwd": "blend_fwd_kernel",
              "blend_bwd": "blend_bwd_kernel", "shade_bwd": "shade_bwd_kernel", "shade_fwd": "shade_fwd_kernel",
              "preprocess_fwd": "preprocess_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel", "sort": "rocprim_sort"}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")), key=os.path.getmtime)
     if not files or stage not in names:
         return None
     try:
         k = json.load(open(files[-1])).get(names[stage], {})
         return int((2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def pmc_valu_busy(stage: str):
+    """Fraction of the kernel's cycles in which the VALU pipes were issuing, from the same committed PMC
+    summary: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles
+    summed over the 8 XCDs.  This -- not the HBM fraction -- is the roofline that binds the GI march."""
+    import glob
+    names = {"ssao": "ssao_kernel<true>", "ssr": "ssr_kernel<true>", "blend_fwd": "blend_fwd_kernel",
+             "blend_bwd": "blend_bwd_kernel"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")), key=os.path.getmtime)
+    if not files or stage not in names:
+        return None
+    try:
+        k = json.load(open(files[-1])).get(names[stage], {})
+        cycles = k["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+        return round(4.0 * k["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / (1024.0 * cycles), 3)
     except Exception:  # noqa: BLE001
         return None
 
@@ -287,7 +305,9 @@ def main():
             a = kernels[dom]["achieved_GBs"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(a / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
-                        "note": "dominant kernel by time; it is VALU/gather-bound, not HBM-bound (DESIGN.md)"}
+                        "valu_busy": pmc_valu_busy(dom),
+                        "note": "dominant kernel by time; it is bound by fp32 VALU issue (valu_busy = fraction of its "
+                                "cycles with the vector ALUs issuing, from the committed PMC pass), not by HBM (DESIGN.md)"}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(sc, cams[args.warmup % n_views], gi, args.sh_degree)

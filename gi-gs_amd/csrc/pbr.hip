@@ -818,7 +818,11 @@ shade_bwd_kernel(ShadeArgs A) {
   extern __shared__ __align__(16) float s_lds[];
   for (int i = threadIdx.x; i < A.lds_total; i += kShadeBwdBlock) s_lds[i] = 0.0f;
   __syncthreads();
-  const int pg = blockIdx.x * kShadeBwdBlock + threadIdx.x;
+  // persistent workgroups: each keeps its LDS accumulators across several 1024-pixel chunks, so the zero-fill
+  // and the flush (and the flush's global atomics) are paid once per workgroup, not once per chunk
+  const int n_chunks = (A.H * A.W + kShadeBwdBlock - 1) / kShadeBwdBlock;
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  const int pg = chunk * kShadeBwdBlock + threadIdx.x;
   const bool live = pg < A.H * A.W;
   const int p = live ? pg : 0;  // dead lanes shade pixel 0 and add nothing: the DPP scans need every lane
   ShadePix q;
@@ -911,6 +915,7 @@ shade_bwd_kernel(ShadeArgs A) {
       run_add3<false>(t1 ? t1 + 3 * (size_t)max(idx, 0) : nullptr, idx >= 0 ? (q.l1 << 24) | idx : -1, g_sp[0] * w, g_sp[1] * w, g_sp[2] * w);
     }
   }
+  }  // chunk loop
   if (A.lds_total > 0) {
     __syncthreads();
     if (A.lds_diffuse_off >= 0 && A.d_diffuse) {
@@ -1190,7 +1195,15 @@ int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs
     attr_set = true;
   }
   void* tok; gigs_internal_stage_begin(15, stream, &tok);
-  hipLaunchKernelGGL(gigs::shade_bwd_kernel, dim3((H * W + gigs::kShadeBwdBlock - 1) / gigs::kShadeBwdBlock),
+  const int n_chunks = (H * W + gigs::kShadeBwdBlock - 1) / gigs::kShadeBwdBlock;
+  static const int max_blocks = [] {  // one workgroup per CU (120 KB of LDS each); GIGS_SHADE_BWD_BLOCKS overrides
+    const char* e = getenv("GIGS_SHADE_BWD_BLOCKS");
+    if (e) return atoi(e);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+  }();
+  hipLaunchKernelGGL(gigs::shade_bwd_kernel, dim3(n_chunks < max_blocks ? n_chunks : max_blocks),
                      dim3(gigs::kShadeBwdBlock), (size_t)used * sizeof(float), (hipStream_t)stream, A);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
