@@ -277,9 +277,23 @@ def _SSR_BACKWARD(*_args):
         "Gaussian_SSR's backward is grad_albedo = grad_out * abd")
 
 
-def _lite_rasterize_gaussians(*_args):
-    # exported by the reference (R/ext.cpp:21) but called from nowhere in its Python
-    raise NotImplementedError("lite_rasterize_gaussians has no caller in the reference and is not built yet")
+def _lite_rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, cov3D_precomp, sh, campos,
+                              viewmatrix, projmatrix, scale_modifier, tan_fovx, tan_fovy, image_height, image_width,
+                              degree, prefiltered, argmax_depth):
+    """_C.lite_rasterize_gaussians: colour / opacity / depth only "for baking" (R/rasterize_points.cu:39-127,
+    liteRenderCUDA forward.cu:279-418) -> (rendered, out_color, out_opacity, radii, out_depth).  The lite kernel
+    composites exactly like the full one (same tests, same depth = view-space z), so this runs the full forward
+    with zero material attributes and returns the three planes; the reference never calls it from Python."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _need_gpu(means3D, "means3D")
+    P = int(means3D.size(0))
+    z = lambda c: torch.zeros((P, c), dtype=torch.float32, device=means3D.device)  # noqa: E731
+    res = _rasterize_gaussians(background, means3D, colors, opacity, z(3), z(3), z(1), z(1), scales, rotations,
+                               cov3D_precomp, sh, campos, viewmatrix, projmatrix, scale_modifier, tan_fovx, tan_fovy,
+                               image_height, image_width, degree, prefiltered, argmax_depth, False, False)
+    rendered, out_color, radii, out_opacity, out_depth = res[0], res[1], res[2], res[6], res[7]
+    return rendered, out_color, out_opacity, radii, out_depth
 
 
 _C = SimpleNamespace(

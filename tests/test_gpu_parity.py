@@ -234,6 +234,26 @@ def test_forward_quadrant_cull_is_exact(orc, monkeypatch):
         np.testing.assert_array_equal(hp[k].view(np.uint32), hp0[k].view(np.uint32), err_msg=k)
 
 
+def test_lite_rasterize_matches_full_forward(orc):
+    """_C.lite_rasterize_gaussians (colour / opacity / depth "for baking", never called by the reference's own
+    Python) returns the full operator's planes bit for bit, in both depth modes."""
+    dgr = _dgr()
+    sc, cam = small_scene(P=3000, sh_degree=1, W=144, H=96, scale_mu=0.05)
+    e = torch.Tensor([])
+    for argmax in (False, True):
+        st = settings(dgr, cam, sc["sh_degree"], bg=(0.2, 0.1, 0.3), argmax_depth=argmax)
+        full = hip_planes(hip_raw_forward(dgr, sc, cam, bg=(0.2, 0.1, 0.3), argmax_depth=argmax))
+        R, col, opa, radii, dep = dgr._C.lite_rasterize_gaussians(
+            st.bg, tt(sc["means3D"]), e, tt(sc["opacities"]), tt(sc["scales"]), tt(sc["rotations"]), e, tt(sc["shs"]),
+            st.campos, st.viewmatrix, st.projmatrix, 1.0, st.tanfovx, st.tanfovy, st.image_height, st.image_width,
+            st.sh_degree, False, argmax)
+        assert R > 0
+        np.testing.assert_array_equal(col.cpu().numpy(), full["color"])
+        np.testing.assert_array_equal(opa.cpu().numpy(), full["opacity"])
+        np.testing.assert_array_equal(dep.cpu().numpy(), full["depth"])
+        np.testing.assert_array_equal(radii.cpu().numpy(), full["radii"])
+
+
 def test_mark_visible(orc):
     dgr = _dgr()
     sc, cam = small_scene(P=5000, sh_degree=0)
