@@ -1,0 +1,159 @@
+"""GPU tests at BASELINE.json's full sizes (configs[1] 300k Gaussians / 800x800 / SH 2; configs[2] inference-only
+PBR + indirect; configs[3] 2 M Gaussians / SH 3), where the CPU oracle would take minutes: size-independent
+properties of the path instead of oracle values --
+
+  * binning: keys sorted, point_list consistent with keys, ranges partition [0, R) by tile, sum(tiles_touched) = R;
+  * compositing: opacity + final_T = 1 (the weights telescope), n_contrib within the tile's list, finite planes;
+  * exact self-consistency: the forward is deterministic bit for bit, the quadrant cull and the GI workgroup
+    shape do not change a bit;
+  * the backward is linear in the incoming gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from test_gpu_parity import DEV, _dgr, hip_planes, hip_raw_forward, scratch_views, settings, tt
+
+pytestmark = pytest.mark.gpu
+
+
+def _structure_checks(sv, hp, R, P, W, H):
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    keys = sv["keys"].astype(np.uint64)
+    assert np.all(keys[1:] >= keys[:-1]), "tile|depth keys are not sorted"
+    assert int(sv["tiles_touched"].astype(np.int64).sum()) == R
+    assert int(sv["point_offsets"][-1]) == R
+    # the sorted list is a permutation of the unsorted (key, value) pairs
+    order = np.lexsort((sv["vals_unsorted"], sv["keys_unsorted"]))
+    np.testing.assert_array_equal(sv["keys_unsorted"][order], keys)
+    assert np.array_equal(np.sort(sv["vals_unsorted"]), np.sort(sv["point_list"]))
+    # ranges: tile t owns exactly the instances whose key's high word is t
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    ranges = sv["ranges"].reshape(T, 2).astype(np.int64)
+    counts = np.bincount(tiles, minlength=T)
+    np.testing.assert_array_equal(ranges[:, 1] - ranges[:, 0], counts)
+    nz = counts > 0
+    np.testing.assert_array_equal(ranges[nz, 0], (np.cumsum(counts) - counts)[nz])
+    # per-pixel state
+    n_contrib = sv["n_contrib"].reshape(H, W).astype(np.int64)
+    tile_of_pixel = (np.arange(H)[:, None] // 16) * ((W + 15) // 16) + (np.arange(W)[None, :] // 16)
+    assert np.all(n_contrib <= counts[tile_of_pixel])
+    final_T = sv["final_T"].reshape(H, W)
+    assert np.all((final_T > 0) & (final_T <= 1))
+    np.testing.assert_allclose(hp["opacity"][0] + final_T, 1.0, atol=2e-5)
+    for k in ("color", "opacity", "depth", "normal", "pos", "albedo", "roughness", "metallic"):
+        assert np.isfinite(hp[k]).all(), k
+
+
+def test_c2_forward_structure_determinism_and_cull(monkeypatch):
+    dgr = _dgr()
+    P, W, H = 300_000, 800, 800
+    sc = scenes.surface_scene(P=P, sh_degree=2, seed=0)
+    cam = scenes.orbit_camera(5, 64, W, H, radius=3.5)
+    res = hip_raw_forward(dgr, sc, cam)
+    R = res[0]
+    assert R > 1_000_000
+    sv, hp = scratch_views(dgr, res, P, W, H), hip_planes(res)
+    _structure_checks(sv, hp, R, P, W, H)
+    # bit-for-bit determinism and cull-invariance of every plane and of the per-pixel state
+    res2 = hip_raw_forward(dgr, sc, cam)
+    monkeypatch.setenv("GIGS_BLEND_CULL", "0")
+    res3 = hip_raw_forward(dgr, sc, cam)
+    for other in (res2, res3):
+        sv2, hp2 = scratch_views(dgr, other, P, W, H), hip_planes(other)
+        for k in ("n_contrib", "final_T", "point_list"):
+            np.testing.assert_array_equal(sv[k].view(np.uint32), sv2[k].view(np.uint32), err_msg=k)
+        for k in hp:
+            np.testing.assert_array_equal(hp[k].view(np.uint32), hp2[k].view(np.uint32), err_msg=k)
+
+
+def test_c2_operator_gi_invariance_and_backward_linearity(monkeypatch):
+    """Full operator (rasterize + in-op filters + SSAO) and Gaussian_SSR at 800x800: occlusion in [0, 1], the
+    GI kernels give the same bits for another workgroup pixel rectangle, and the rasterizer backward is linear."""
+    dgr = _dgr()
+    P, W, H = 300_000, 800, 800
+    sc = scenes.surface_scene(P=P, sh_degree=2, seed=1)
+    cam = scenes.orbit_camera(9, 64, W, H, radius=3.5)
+    keys = ["means3D", "opacities", "normal", "albedo", "roughness", "metallic", "shs", "scales", "rotations"]
+
+    def run(grads):
+        g = {k: tt(sc[k], grad=True) for k in keys}
+        st = settings(dgr, cam, 2)
+        out = dgr.GaussianRasterizer(st)(means3D=g["means3D"], means2D=torch.zeros_like(g["means3D"], requires_grad=True),
+                                         opacities=g["opacities"], normal=g["normal"], shs=g["shs"], albedo=g["albedo"],
+                                         roughness=g["roughness"], metallic=g["metallic"], scales=g["scales"],
+                                         rotations=g["rotations"], derive_normal=True)
+        color, radii, opacity, depth, nfd, normal, occ, albedo, rough, metal, onv, depth_pos = out
+        if grads is not None:
+            loss = sum((t * w).sum() for t, w in zip((color, opacity, depth, normal, albedo, rough, metal), grads))
+            loss.backward()
+        return out, {k: (v.grad.clone() if v.grad is not None else None) for k, v in g.items()}
+
+    out, _ = run(None)
+    occ = out[6]
+    assert float(occ.min()) >= 0.0 and float(occ.max()) <= 1.0 and 0.05 < float(occ.mean()) < 1.0
+    monkeypatch.setenv("GIGS_GI_TILE_LOG2W", "5")
+    out2, _ = run(None)
+    monkeypatch.delenv("GIGS_GI_TILE_LOG2W")
+    assert torch.equal(occ, out2[6])
+    ssr = dgr.Gaussian_SSR(cam["tanfovx"], cam["tanfovy"], W, H, 0.8, 0.01, 0.05, 0.0625, 16, 8)
+    rgb = torch.rand(3, H, W, device=DEV)
+    F0 = torch.full((3, H, W), 0.04, device=DEV)
+    onv = torch.nan_to_num(out[10])
+    irr, abd = ssr(onv, out[11], rgb, out[7].detach(), out[8].detach(), out[9].detach(), F0)
+    assert torch.isfinite(irr).all() and float(irr.min()) >= 0.0
+    monkeypatch.setenv("GIGS_GI_TILE_LOG2W", "4")
+    irr2, _ = ssr(onv, out[11], rgb, out[7].detach(), out[8].detach(), out[9].detach(), F0)
+    assert torch.equal(irr, irr2)
+    # linearity of the backward: bwd(2 g1 - 3 g2) = 2 bwd(g1) - 3 bwd(g2) up to atomic-order rounding
+    torch.manual_seed(0)
+    shapes = [(3, H, W), (1, H, W), (1, H, W), (3, H, W), (3, H, W), (1, H, W), (1, H, W)]
+    g1 = [torch.randn(s, device=DEV) for s in shapes]
+    g2 = [torch.randn(s, device=DEV) for s in shapes]
+    _, d1 = run(g1)
+    _, d2 = run(g2)
+    _, d3 = run([2.0 * a - 3.0 * b for a, b in zip(g1, g2)])
+    for k in keys:
+        want = 2.0 * d1[k] - 3.0 * d2[k]
+        scale = float(want.abs().max()) + 1e-20
+        assert float((d3[k] - want).abs().max()) / scale < 2e-4, k
+
+
+def test_c3_inference_planes():
+    """configs[2]: inference-only rendering -- roughness carries the transmittance (forward.cu:618-619)."""
+    dgr = _dgr()
+    P, W, H = 300_000, 800, 800
+    sc = scenes.surface_scene(P=P, sh_degree=2, seed=2)
+    cam = scenes.orbit_camera(3, 64, W, H, radius=3.5)
+    a, b = hip_raw_forward(dgr, sc, cam), hip_raw_forward(dgr, sc, cam, inference=True)
+    sv = scratch_views(dgr, a, P, W, H)
+    ha, hb = hip_planes(a), hip_planes(b)
+    np.testing.assert_array_equal(hb["roughness"][0], ha["roughness"][0] + sv["final_T"].reshape(H, W))
+    for k in ("color", "opacity", "depth", "albedo", "metallic"):
+        np.testing.assert_array_equal(ha[k], hb[k])
+
+
+def test_c4_two_million_gaussians_sh3():
+    """configs[3] scale: 2 M Gaussians, SH degree 3, forward + backward on one GPU; structural checks only."""
+    dgr = _dgr()
+    P, W, H = 2_000_000, 800, 800
+    sc = scenes.surface_scene(P=P, sh_degree=3, seed=3, scale_mu=0.004)
+    cam = scenes.orbit_camera(1, 64, W, H, radius=3.5)
+    res = hip_raw_forward(dgr, sc, cam)
+    R = res[0]
+    assert R > 2_000_000
+    _structure_checks(scratch_views(dgr, res, P, W, H), hip_planes(res), R, P, W, H)
+    keys = ["means3D", "opacities", "normal", "albedo", "roughness", "metallic", "shs", "scales", "rotations"]
+    g = {k: tt(sc[k], grad=True) for k in keys}
+    st = settings(dgr, cam, 3)
+    out = dgr.GaussianRasterizer(st)(means3D=g["means3D"], means2D=torch.zeros_like(g["means3D"], requires_grad=True),
+                                     opacities=g["opacities"], normal=g["normal"], shs=g["shs"], albedo=g["albedo"],
+                                     roughness=g["roughness"], metallic=g["metallic"], scales=g["scales"],
+                                     rotations=g["rotations"], derive_normal=True)
+    (out[0].mean() + out[7].mean() + out[3].mean()).backward()
+    vis = out[1] > 0
+    for k in keys:
+        assert torch.isfinite(g[k].grad).all(), k
+        assert float(g[k].grad[~vis].abs().sum()) == 0.0, k  # culled Gaussians receive exact zeros
+    assert float(g["shs"].grad.abs().sum()) > 0 and float(g["albedo"].grad.abs().sum()) > 0
