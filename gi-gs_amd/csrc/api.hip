@@ -313,6 +313,7 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
     StageScope sc(kRanges, s);
     HIP_TRY(hipMemsetAsync(img.ranges, 0, T * sizeof(uint2), s));
     gigs::launch_tile_ranges(num_rendered, bin, img.ranges, s);
+    gigs::launch_tile_order((int)T, img.ranges, img.tile_order, s);
   }
   STAGE_CHECK("identifyTileRanges");
   {

@@ -28,7 +28,7 @@
 
 namespace gigs {
 
-constexpr int kBatch = 256;
+constexpr int kLongTile = 2048;  // lists longer than this run at raised wave priority
 
 // ---- DPP helpers ---------------------------------------------------------------------------
 template <int kCtrl, int kRowMask = 0xf, int kBankMask = 0xf>
@@ -95,7 +95,8 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ brec,
                  const float* __restrict__ viewmatrix, const float* __restrict__ bg_color,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, BlendOut o,
-                 int argmax_depth, int inference, uint8_t* __restrict__ hit_mask, int cull) {
+                 int argmax_depth, int inference, uint8_t* __restrict__ hit_mask, int cull,
+                 const uint32_t* __restrict__ tile_order) {
   // Each wave walks the tile's list on its own (no workgroup barrier anywhere): the time of a tile is the
   // time of its busiest quadrant, not the sum over batches of the slowest quadrant of each batch, and a wave
   // whose 64 pixels are saturated leaves at once.  The list is consumed in chunks of 64 instances, one per
@@ -103,7 +104,7 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   // so the dependent index -> record gathers of the next chunk are in flight while this one is blended.
   __shared__ float4 s_rec[4][GIGS_BREC_F4 * 64];  // per wave, [k][slot]: 4 x 5 KB
 
-  const unsigned tile = blockIdx.x;
+  const unsigned tile = tile_order[blockIdx.x];  // longest lists first (binning.hip::tile_order_kernel)
   const unsigned ty = tile / gx, tx = tile - ty * gx;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const unsigned px = tx * GIGS_BLOCK_X + (wave & 1) * 8 + (lane & 7);
@@ -115,6 +116,8 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
 
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
+  // the kernel ends when its longest tile does: waves of long tiles get the issue priority on their SIMD
+  if (n > kLongTile) __builtin_amdgcn_s_setprio(3);
   float4* sw = s_rec[wave];
   uint8_t* hit = hit_mask + 4 * (size_t)range.x + wave;  // this quadrant's byte of instance i: hit[4 * i]
 
@@ -245,7 +248,7 @@ void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& 
   const int cull = !(e && e[0] == '0');
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(a.gx * a.gy), dim3(GIGS_TILE), 0, s, a.W, a.H, a.gx,
                      im.ranges, b.point_list, g.brec, a.viewmatrix, a.background, im.n_contrib,
-                     im.final_T, o, a.argmax_depth, a.inference, b.hit_mask, cull);
+                     im.final_T, o, a.argmax_depth, a.inference, b.hit_mask, cull, im.tile_order);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -258,7 +261,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ brec,
                  const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
                  const uint32_t* __restrict__ n_contrib, BlendGradIn gi, float* __restrict__ grec,
-                 const uint8_t* __restrict__ hit_mask) {
+                 const uint8_t* __restrict__ hit_mask, const uint32_t* __restrict__ tile_order) {
   // Wave-autonomous like the forward: each wave walks the tile's list back to front in chunks of 64 instances
   // (lane l of chunk c <-> instance n-1-(64c+l)), fetching only the instances its quadrant blended (the
   // forward's hit byte), two-deep pipelined, no workgroup barrier.  The 19 per-Gaussian sums of a wave are
@@ -267,7 +270,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   __shared__ float4 s_rec[4][3 * 64];            // per wave, [k][slot], k = 0..2 (mean2D, conic/opacity, rgb)
   __shared__ __align__(16) float s_sum[4][GIGS_GREC];  // per wave: the reduced sums of the current instance
 
-  const unsigned tile = blockIdx.x;
+  const unsigned tile = tile_order[blockIdx.x];  // longest lists first (binning.hip::tile_order_kernel)
   const unsigned ty = tile / gx, tx = tile - ty * gx;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const unsigned px = tx * GIGS_BLOCK_X + (wave & 1) * 8 + (lane & 7);
@@ -279,6 +282,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
 
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
+  if (n > kLongTile) __builtin_amdgcn_s_setprio(3);
   float4* sw = s_rec[wave];
   float* ssum = s_sum[wave];
   const uint8_t* hit = hit_mask + 4 * (size_t)range.x + wave;
@@ -442,7 +446,7 @@ void launch_blend_bwd(const BwdArgs& a, const GeomState& g, const BinningState& 
                  a.dL_dpix_albedo, a.dL_dpix_roughness, a.dL_dpix_metallic};
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.gx * a.gy), dim3(GIGS_TILE), 0, s, a.W, a.H, a.gx,
                      im.ranges, b.point_list, g.brec, a.background, im.final_T,
-                     im.n_contrib, gi, g.grec, b.hit_mask);
+                     im.n_contrib, gi, g.grec, b.hit_mask, im.tile_order);
 }
 
 }  // namespace gigs

@@ -174,11 +174,13 @@ struct ImageState {
   float* final_T;
   uint32_t* n_contrib;
   uint2* ranges;
+  uint32_t* tile_order;  // workgroup b of the blend kernels handles tile tile_order[b]: longest lists first
   static ImageState fromChunk(char*& chunk, size_t N, size_t T) {
     ImageState s;
     carve(chunk, s.final_T, N);
     carve(chunk, s.n_contrib, N);
     carve(chunk, s.ranges, T);
+    carve(chunk, s.tile_order, T);
     return s;
   }
 };
@@ -232,6 +234,7 @@ void launch_duplicate(int P, const int* radii, unsigned gx, unsigned gy, const G
                       const BinningState& b, hipStream_t s);
 hipError_t sort_pairs(const BinningState& b, int R, int end_bit, hipStream_t s);
 void launch_tile_ranges(int R, const BinningState& b, uint2* ranges, hipStream_t s);
+void launch_tile_order(int T, const uint2* ranges, uint32_t* tile_order, hipStream_t s);
 void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& b,
                       const ImageState& im, float* out_color, float* out_opacity,
                       float* out_depth, float* out_normal, float* out_normal_view, float* out_pos,
