@@ -73,6 +73,48 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class OutputPool:
+    """Optional reuse of the operator's output planes across calls (gigs-hip extension, off by default).
+
+    A training loop that replays the rest of its iteration from a hipGraph wants the rasterizer's planes at
+    the same addresses every step (the graph then reads them in place instead of copying them into its static
+    inputs).  Inside `with pool:` every output plane of this package is taken from the pool -- so tensors
+    returned by an earlier call under the same pool are overwritten by the next one."""
+
+    def __init__(self):
+        self.buffers, self.counts = {}, {}
+
+    def __enter__(self):
+        global _pool
+        self.counts = {}
+        self._prev, _pool = _pool, self
+        return self
+
+    def __exit__(self, *exc):
+        global _pool
+        _pool = self._prev
+        return False
+
+    def get(self, tag, shape, dtype, device):
+        k = self.counts.get(tag, 0)
+        self.counts[tag] = k + 1
+        key = (tag, k, tuple(shape), dtype, str(device))
+        t = self.buffers.get(key)
+        if t is None:
+            t = self.buffers[key] = torch.empty(tuple(shape), dtype=dtype, device=device)
+        return t
+
+
+_pool: Optional[OutputPool] = None
+
+
+def _new(tag: str, shape, device, dtype=torch.float32) -> torch.Tensor:
+    """Uninitialised output tensor (every element is written by the kernel that receives it)."""
+    if _pool is not None:
+        return _pool.get(tag, shape, dtype, device)
+    return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
 def _need_gpu(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(
@@ -124,7 +166,7 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
     # the reference zero-fills every output (rasterize_points.cu:170-179); the kernels overwrite every
     # pixel / every Gaussian when P > 0, so one uninitialised slab is carved instead of 10 fill launches
     if P != 0:
-        slab = torch.empty((20, H, W), **fopts)
+        slab = _new("gbuffer", (20, H, W), dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
     else:
         slab = torch.zeros((20, H, W), **fopts)
@@ -225,8 +267,8 @@ def _mark_visible(means3D, viewmatrix, projmatrix):
 def _depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depthMap):
     _need_gpu(depthMap, "depthMap")
     dev = depthMap.device
-    normalMap = torch.empty((3, height, width), dtype=torch.float32, device=dev)  # every pixel is written
-    depth_pos = torch.empty((3, height, width), dtype=torch.float32, device=dev)
+    normalMap = _new("normal_from_depth", (3, height, width), dev)  # every pixel is written
+    depth_pos = _new("depth_pos", (3, height, width), dev)
     v, k0 = _fptr(viewmatrix, "viewmatrix")
     d, k1 = _fptr(depthMap, "depthMap")
     with torch.cuda.device(dev):
@@ -239,7 +281,7 @@ def _depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depthMap):
 def _SSAO(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, out_normal, out_pos):
     _need_gpu(out_normal, "out_normal")
     dev = out_normal.device
-    occlusion = torch.empty((1, height, width), dtype=torch.float32, device=dev)  # every pixel is written
+    occlusion = _new("occlusion", (1, height, width), dev)  # every pixel is written
     n, k0 = _fptr(out_normal, "out_normal")
     ps, k1 = _fptr(out_pos, "out_pos")
     with torch.cuda.device(dev):
@@ -316,7 +358,7 @@ class _Median3x3(torch.autograd.Function):
     def forward(ctx, x):  # x: [C, H, W]
         _need_gpu(x, "input")
         xc = x.contiguous().float()
-        out = torch.empty_like(xc)
+        out = _new("median3x3", xc.shape, xc.device)
         Cn, H, W = xc.shape
         with torch.cuda.device(xc.device):
             gigs_lib.check(_lib.gigs_median3x3(Cn, H, W, xc.data_ptr(), out.data_ptr(), _stream()), "median3x3")
@@ -352,7 +394,7 @@ def _bilateral_blur(input: torch.Tensor, kernel_size=(3, 3), sigma_color=1.0, si
     _need_gpu(input, "input")
     B, Cn, H, W = input.shape
     x = input.detach().contiguous().float()
-    out = torch.empty_like(x)
+    out = _new("bilateral3x3", x.shape, x.device)
     with torch.cuda.device(x.device):
         for b in range(B):
             gigs_lib.check(_lib.gigs_bilateral3x3(Cn, H, W, float(sigma_color), float(sigma_space[1]),

@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, Gaussian_SSR,
-                                         filters)
+                                         OutputPool, filters)
 
 
 def linear_to_srgb(linear: torch.Tensor) -> torch.Tensor:  # train.py:54-68
@@ -196,6 +196,8 @@ class Stage2Step:
         self.fused, self.light, self.brdf_lut = fused, light, brdf_lut
         self.flags = dict(metallic=metallic, indirect=indirect, gamma=gamma, tone=tone)
         self.back = self.mips = self.side = None
+        # fused + graphs: the rasterizer's planes live at fixed addresses, the graph reads them in place
+        self.pool = OutputPool() if (fused and graphs and os.environ.get("GIGS_OUTPUT_POOL", "1") == "1") else None
         self.front = Stage2Front(light, brdf_lut, metallic=metallic, indirect=indirect, tone=tone, gamma=gamma)
         self.loss_fn = stage2_loss
         self.graphs = graphs
@@ -213,8 +215,13 @@ class Stage2Step:
         background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
         if self.fused:
             lights = self._fused_begin()
+        if self.pool is not None:
+            with self.pool:
+                out = rasterize(cam, g, self.sh_degree, background, self.gi)
+        else:
+            out = rasterize(cam, g, self.sh_degree, background, self.gi)
         ((_, radii, _, _, normal_map_from_depth, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map,
-          out_normal_view, depth_pos), screenspace_points, st) = rasterize(cam, g, self.sh_degree, background, self.gi)
+          out_normal_view, depth_pos), screenspace_points, st) = out
         H, W = cam["image_height"], cam["image_width"]
         gi = self.gi
         if self.fused:
@@ -275,7 +282,10 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
                    **self.flags)
         self.back = Stage2FusedBack(self.brdf_lut, cfg)
         if self.graphs:
-            sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
+            # pooled rasterizer planes (fixed addresses) become the graph's static inputs themselves: no staging copies
+            pooled = set(t.untyped_storage().data_ptr() for t in self.pool.buffers.values()) if self.pool else set()
+            sample = tuple(a.detach().requires_grad_(a.requires_grad) if a.untyped_storage().data_ptr() in pooled
+                           else a.detach().clone().requires_grad_(a.requires_grad) for a in args)
             self.back = graphed(self.back, sample)
     loss, render_rgb, render_direct, IRR = self.back(*args)
     loss.backward()
