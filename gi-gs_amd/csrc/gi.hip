@@ -237,18 +237,22 @@ __device__ __forceinline__ float group_coords(const GiParams& p, v3 pos, float a
   float min_den = __builtin_inff();
 #pragma unroll
   for (int g = 0; g < kGroup; g++) {
-    const float fj = (float)(j0 + g);
+    // pos + sampleVec * j * (1 + z/100) * (1 + z/100) * radius / step, left to right (forward.cu:693).  For a
+    // power-of-two step the final division is an exact scaling, and an exact scaling commutes with every
+    // rounding of the chain as long as no intermediate falls into the subnormal range: the fast path folds it
+    // into j (j / step is exact) and saves three multiplies per sample; `sv_scale_ok` (checked per ray by the
+    // caller) rules the subnormal case out, otherwise the exact path below runs.
+    const float fj = (kPow2 && !kExact) ? (float)(j0 + g) * p.inv_step : (float)(j0 + g);
     const bool in_range = (j0 + g) < p.step;
 #pragma unroll
     for (int k = 0; k < kRays; k++) {
-      // pos + sampleVec * j * (1 + z/100) * (1 + z/100) * radius / step, left to right (forward.cu:693)
       f32x2 m = f32x2{sv[k].x, sv[k].y} * fj;
       float mz = sv[k].z * fj;
       m = m * a; mz = mz * a;
       m = m * a; mz = mz * a;
       m = m * p.radius; mz = mz * p.radius;
       if (kPow2) {
-        m = m * p.inv_step; mz = mz * p.inv_step;
+        if (kExact) { m = m * p.inv_step; mz = mz * p.inv_step; }
       } else {
         const float fs = (float)p.step;
         m = f32x2{m.x / fs, m.y / fs}; mz = mz / fs;
@@ -327,8 +331,19 @@ __device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, c
 // one carries neither the branches nor the registers of the rare one.
 template <bool kPow2, int kGroup, int kRays>
 __device__ __forceinline__ void march(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
-                                      __amdgpu_buffer_rsrc_t pos_z, bool mag_ok, int* hit) {
-  const bool bad = march_impl<kPow2, kGroup, kRays, false>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
+                                      __amdgpu_buffer_rsrc_t pos_z, bool mag_ok, unsigned sv_min_bits, int* hit) {
+  bool bad = march_impl<kPow2, kGroup, kRays, false>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
+  if (kPow2) {
+    // folding 1/step into j is exact unless a product of the chain is subnormal: every non-zero component of the
+    // sample vectors must stay above sv_min (= 2^-120 / the smallest cumulative factor of the chain; a zero
+    // component gives exact zeros either way).  As unsigned integers: (|bits| - 1) >= (sv_min_bits - 1).
+    unsigned lowest = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < kRays; k++)
+      lowest = min(lowest, min(min((__float_as_uint(sv[k].x) & 0x7fffffffu) - 1u, (__float_as_uint(sv[k].y) & 0x7fffffffu) - 1u),
+                               (__float_as_uint(sv[k].z) & 0x7fffffffu) - 1u));
+    bad = bad || lowest < sv_min_bits - 1u;
+  }
   if (__builtin_expect(__any(bad), 0)) march_impl<kPow2, kGroup, kRays, true>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
 }
 
@@ -353,6 +368,17 @@ __device__ __forceinline__ v3 tbn_apply(const Tbn& m, float x, float y, float z)
 __device__ __forceinline__ bool gi_mag_ok(v3 pos, float a, float radius) {
   const float bound = fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fabsf(pos.z)) + 2.0f * fabsf(a * a * radius) + 1.0f;
   return bound < 0x1p59f;  // false for NaN / inf
+}
+
+// Smallest non-zero |sample-vector component| for which folding 1/step into j is exact (see group_coords): the
+// chain multiplies by j/step >= 1/step, a, a, radius; its smallest cumulative factor must keep the product
+// above 2^-120.  Returned as fp32 bits (positive floats order like unsigned integers); NaN / zero factors give
+// +inf bits, i.e. "never exact" -> the exact path.
+__device__ __forceinline__ unsigned gi_sv_min_bits(float a, float radius, float inv_step) {
+  const float aa = fabsf(a), a2 = aa * aa;
+  const float lo = fminf(fminf(1.0f, aa), fminf(a2, a2 * fabsf(radius))) * inv_step;
+  const float sv_min = 0x1p-120f / lo;  // lo == 0 or NaN -> inf / NaN
+  return (sv_min == sv_min) ? __float_as_uint(sv_min) : 0x7f800000u;
 }
 
 // Every sample direction contains t * ts.x, so a tangent that is NaN in all three components
@@ -408,6 +434,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
       const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
       const int r0 = wave * chunk, r1 = min(p.nrays, r0 + chunk);
       const bool mag_ok = gi_mag_ok(pos, a, p.radius);
+      const unsigned sv_min_bits = gi_sv_min_bits(a, p.radius, p.inv_step);
       int r = r0;
       for (; r + kGiRays <= r1; r += kGiRays) {
         v3 sv[kGiRays];
@@ -419,7 +446,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
           w[k] = rays[2 * (r + k) + 1].y;
           sv[k] = tbn_apply(tbn, ra.x, ra.y, ra.z);
         }
-        march<kPow2, kGiGroup, kGiRays>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
+        march<kPow2, kGiGroup, kGiRays>(p, pos, a, sv, cx, cy, pos_z, mag_ok, sv_min_bits, hit);
 #pragma unroll
         for (int k = 0; k < kGiRays; k++) occ += hit[k] >= 0 ? w[k] : 0.0f;  // x + 0 is exact: ray order kept
       }
@@ -427,7 +454,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
         const float4 ra = rays[2 * r];
         const v3 sv = tbn_apply(tbn, ra.x, ra.y, ra.z);
         int hit;
-        march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, &hit);
+        march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, sv_min_bits, &hit);
         occ += hit >= 0 ? rays[2 * r + 1].y : 0.0f;
       }
     }
@@ -465,6 +492,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
     const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
     const int r0 = wave * chunk, r1 = min(p.nrays, r0 + chunk);
     const bool mag_ok = gi_mag_ok(pos, a, p.radius);
+      const unsigned sv_min_bits = gi_sv_min_bits(a, p.radius, p.inv_step);
     auto add_hit = [&](int q, float cos_t, float sin_t) {
       if (q >= 0) {
         // rgb * cosf(theta) * sinf(theta), left to right (forward.cu:824-826)
@@ -485,7 +513,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
         st[k] = rays[2 * (r + k) + 1].x;
         sv[k] = tbn_apply(tbn, ra.x, ra.y, ra.z);
       }
-      march<kPow2, kGiGroup, kGiRays>(p, pos, a, sv, cx, cy, pos_z, mag_ok, hit);
+      march<kPow2, kGiGroup, kGiRays>(p, pos, a, sv, cx, cy, pos_z, mag_ok, sv_min_bits, hit);
       bool any_hit = false;
 #pragma unroll
       for (int k = 0; k < kGiRays; k++) any_hit = any_hit || hit[k] >= 0;
@@ -498,7 +526,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
       const float4 ra = rays[2 * r];
       const v3 sv = tbn_apply(tbn, ra.x, ra.y, ra.z);
       int hit;
-      march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, &hit);
+      march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, sv_min_bits, &hit);
       add_hit(hit, ra.w, rays[2 * r + 1].x);
     }
   }
