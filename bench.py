@@ -291,14 +291,35 @@ def main():
         N, T = H * W, ((W + 15) // 16) * ((H + 15) // 16)
         ab = algorithmic_bytes(P, V, R, N, M, T)
         kernels = {}
-        for name, (ms, n) in prof.stages.items():
-            avg = ms / n
-            rec = {"launches_per_step": n / args.steps, "avg_ms": round(avg, 4), "ms_per_step": round(ms / args.steps, 4)}
-            if name in ab:
-                rec["alg_bytes_per_launch"] = int(ab[name])
-                rec["achieved_GBs"] = round(ab[name] / (avg * 1e-3) / 1e9, 2)
-            kernels[name] = rec
-        with_bytes = [k for k in kernels if "achieved_GBs" in kernels[k]]
+
+        def add_stages(stages, steps, source):
+            for name, (ms, n) in stages.items():
+                if name in kernels or n == 0:
+                    continue
+                avg = ms / n
+                rec = {"launches_per_step": n / steps, "avg_ms": round(avg, 4), "ms_per_step": round(ms / steps, 4),
+                       "timed": source}
+                if name in ab:
+                    rec["alg_bytes_per_launch"] = int(ab[name])
+                    rec["achieved_GBs"] = round(ab[name] / (avg * 1e-3) / 1e9, 2)
+                kernels[name] = rec
+
+        add_stages(prof.stages, args.steps, "live")  # hipEvents over the timed region
+        if shade == "hip" and args.graphs == "on" and world == 1:
+            # stages replayed from a hipGraph carry no events: time them on a few extra eager steps of the same
+            # workload OUTSIDE the timed region (marked "eager-extra"; the live entries above are not touched)
+            eager = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=False, fused=(args.fused == "on"))
+            extra = 4
+            for i in range(2):
+                eager(cams_t[i % n_views], g, gt_image, view_dirs[i % n_views])
+            torch.cuda.synchronize()
+            with gigs_lib.profile() as prof2:
+                for i in range(extra):
+                    eager(cams_t[(2 + i) % n_views], g, gt_image, view_dirs[(2 + i) % n_views])
+                torch.cuda.synchronize()
+            add_stages(prof2.stages, extra, "eager-extra")
+        # the roofline entry is taken from stages timed live over the timed region
+        with_bytes = [k for k in kernels if "achieved_GBs" in kernels[k] and kernels[k]["timed"] == "live"]
         dom = max(with_bytes, key=lambda k: kernels[k]["ms_per_step"]) if with_bytes else None
         roofline = None
         if dom is not None and "achieved_GBs" in kernels[dom]:
