@@ -282,6 +282,66 @@ __device__ __forceinline__ float group_coords(const GiParams& p, v3 pos, float a
   return min_den;
 }
 
+// The same for exactly two rays, with every z-lane scalar of the pair (sample z, denominator, reciprocal
+// refinement, the two depth-test bounds) held as one fp32 pair: the kernel is bound by VALU issue and a
+// v_pk_* instruction (~4.7 cycles for two elements) is cheaper than two scalar ones that carry an SGPR / literal
+// operand or a VOP3 encoding (~4 cycles each; only VGPR-only VOP2 forms reach ~2.5: tools/microbench/pk_forms.hip).  Same IEEE operations per element, same results.  hi2 / lo2 receive spz + bias and
+// spz - thick of the two rays (ssr.h hit test operands).
+template <bool kPow2, int kGroup, bool kExact>
+__device__ __forceinline__ float group_coords2(const GiParams& p, v3 pos, float a, const v3* sv, float cx, float cy,
+                                               bool mag_ok, int j0, unsigned (*off)[kGroup], bool (*inb)[kGroup],
+                                               f32x2* hi2, f32x2* lo2) {
+  const f32x2 posxy = {pos.x, pos.y}, fxy = {p.fx, p.fy}, cxy = {cx, cy};
+  const f32x2 posz2 = {pos.z, pos.z}, svz = {sv[0].z, sv[1].z};
+  const f32x2 sxy[2] = {f32x2{sv[0].x, sv[0].y}, f32x2{sv[1].x, sv[1].y}};
+  float min_den = __builtin_inff();
+#pragma unroll
+  for (int g = 0; g < kGroup; g++) {
+    const float fj = (kPow2 && !kExact) ? (float)(j0 + g) * p.inv_step : (float)(j0 + g);  // see group_coords
+    const bool in_range = (j0 + g) < p.step;
+    f32x2 m[2] = {sxy[0] * fj, sxy[1] * fj};
+    f32x2 mz = svz * fj;
+    m[0] = m[0] * a; m[1] = m[1] * a; mz = mz * a;
+    m[0] = m[0] * a; m[1] = m[1] * a; mz = mz * a;
+    m[0] = m[0] * p.radius; m[1] = m[1] * p.radius; mz = mz * p.radius;
+    if (kPow2) {
+      if (kExact) { m[0] = m[0] * p.inv_step; m[1] = m[1] * p.inv_step; mz = mz * p.inv_step; }
+    } else {
+      const float fs = (float)p.step;
+      m[0] = f32x2{m[0].x / fs, m[0].y / fs}; m[1] = f32x2{m[1].x / fs, m[1].y / fs}; mz = f32x2{mz.x / fs, mz.y / fs};
+    }
+    const f32x2 spz = posz2 + mz;
+    const f32x2 den = spz + 0.0000001f;  // get_coord (ssr.h:120-135)
+    // shared-reciprocal division (div2_fast) with the reciprocal refinement of both rays packed
+    const f32x2 r0 = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const f32x2 e0 = __builtin_elementwise_fma(-den, r0, f32x2{1.0f, 1.0f});
+    const f32x2 r1 = __builtin_elementwise_fma(e0, r0, r0);
+    if (!kExact) min_den = fminf(fminf(fabsf(den.x), fabsf(den.y)), min_den);  // NaN dens are not recorded (see group_coords)
+    hi2[g] = spz + p.bias;
+    lo2[g] = spz - p.thick;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const f32x2 sp = posxy + m[k];
+      const float d = k == 0 ? den.x : den.y, r = k == 0 ? r1.x : r1.y;
+      const f32x2 nd = {-d, -d}, rr = {r, r};
+      const f32x2 q0 = sp * rr;
+      const f32x2 e1 = __builtin_elementwise_fma(nd, q0, sp);
+      const f32x2 q1 = __builtin_elementwise_fma(e1, rr, q0);
+      const f32x2 e2 = __builtin_elementwise_fma(nd, q1, sp);
+      f32x2 qv = __builtin_elementwise_fma(e2, rr, q1);
+      if (kExact) {
+        if (!(mag_ok && fabsf(d) > 0x1p-60f)) qv = f32x2{sp.x / d, sp.y / d};
+      }
+      const f32x2 t = qv * fxy + cxy;
+      const int ix = round_to_int(t.x);
+      const int iy = round_to_int(t.y);
+      inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+      off[k][g] = (__umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix) << 2;  // see group_coords
+    }
+  }
+  return min_den;
+}
+
 // Marches kRays rays of one pixel together; hit[k] = pixel index of ray k's hit or -1.
 // The reference walks j = start..step-1 per ray and stops at the first sample that leaves the image
 // or hits (forward.cu:691-714).  ~98 % of the rays of a real frame run all their steps, so:
@@ -301,9 +361,14 @@ __device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, c
   float min_den = __builtin_inff();
   for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
     unsigned off[kRays][kGroup];
-    float spzv[kRays][kGroup], zv[kRays][kGroup];
+    float zv[kRays][kGroup];
     bool inb[kRays][kGroup];
-    min_den = fminf(min_den, group_coords<kPow2, kGroup, kRays, kExact>(p, pos, a, sv, cx, cy, mag_ok, j0, off, inb, spzv));
+    f32x2 hi2[kGroup], lo2[kGroup];           // kRays == 2: depth-test bounds of the pair
+    float spzv[kRays == 2 ? 1 : kRays][kGroup];  // otherwise: the sample z
+    if constexpr (kRays == 2)
+      min_den = fminf(min_den, group_coords2<kPow2, kGroup, kExact>(p, pos, a, sv, cx, cy, mag_ok, j0, off, inb, hi2, lo2));
+    else
+      min_den = fminf(min_den, group_coords<kPow2, kGroup, kRays, kExact>(p, pos, a, sv, cx, cy, mag_ok, j0, off, inb, spzv));
 #pragma unroll
     for (int g = 0; g < kGroup; g++)
 #pragma unroll
@@ -314,7 +379,15 @@ __device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, c
     for (int k = 0; k < kRays; k++) {
 #pragma unroll
       for (int g = 0; g < kGroup; g++) {
-        const bool h = inb[k][g] && (zv[k][g] <= spzv[k][g] + p.bias) && (zv[k][g] >= spzv[k][g] - p.thick);
+        float hi, lo;
+        if constexpr (kRays == 2) {
+          hi = k == 0 ? hi2[g].x : hi2[g].y;
+          lo = k == 0 ? lo2[g].x : lo2[g].y;
+        } else {
+          hi = spzv[k][g] + p.bias;
+          lo = spzv[k][g] - p.thick;
+        }
+        const bool h = inb[k][g] && (zv[k][g] <= hi) && (zv[k][g] >= lo);
         hit[k] = (open[k] && h) ? (int)(off[k][g] >> 2) : hit[k];
         open[k] = open[k] && inb[k][g] && !h;
       }
@@ -412,8 +485,17 @@ __device__ __forceinline__ bool gi_pixel(const GiParams& p, int& x, int& y, int&
   return x < p.W && y < p.H;
 }
 
+#ifndef GIGS_GI_WAVES
+#define GIGS_GI_WAVES 0
+#endif
+#if GIGS_GI_WAVES > 0
+#define GIGS_GI_OCC __attribute__((amdgpu_waves_per_eu(GIGS_GI_WAVES, GIGS_GI_WAVES)))
+#else
+#define GIGS_GI_OCC
+#endif
+
 template <bool kPow2>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) GIGS_GI_OCC
 ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             const float* __restrict__ nrm, const float* __restrict__ pos_map,
             float* __restrict__ occlusion) {
@@ -471,7 +553,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
 }
 
 template <bool kPow2>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) GIGS_GI_OCC
 ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict__ nrm,
            const float* __restrict__ pos_map, const float* __restrict__ rgb,
            const float* __restrict__ albedo_map, const float* __restrict__ metallic_map,
