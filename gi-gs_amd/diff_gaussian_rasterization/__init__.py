@@ -106,6 +106,25 @@ class OutputPool:
 
 
 _pool: Optional[OutputPool] = None
+_after_blend = None
+
+
+class after_blend:
+    """`with after_blend(fn):` -- GaussianRasterizer.forward calls fn() once the alpha-blend kernel has been
+    queued and before the in-op filters and SSAO are (gigs-hip extension, off by default)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _after_blend
+        self._prev, _after_blend = _after_blend, self.fn
+        return self
+
+    def __exit__(self, *exc):
+        global _after_blend
+        _after_blend = self._prev
+        return False
 
 
 def _new(tag: str, shape, device, dtype=torch.float32) -> torch.Tensor:
@@ -515,6 +534,10 @@ class GaussianRasterizer(nn.Module):
          out_normal_view, _) = _RasterizeGaussians.apply(
             means3D, means2D, opacities, normal, albedo, roughness, metallic, shs, colors_precomp, scales,
             rotations, cov3D_precomp, raster_settings)
+        if _after_blend is not None:
+            # gigs-hip extension: the blend kernel is queued, the VALU-bound SSAO march is next -- the point at
+            # which a caller can start independent memory-bound work on another stream (see after_blend)
+            _after_blend()
 
         focal_x = raster_settings.image_width / (2.0 * raster_settings.tanfovx)
         focal_y = raster_settings.image_height / (2.0 * raster_settings.tanfovy)

@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, Gaussian_SSR,
-                                         OutputPool, filters)
+                                         OutputPool, after_blend, filters)
 
 
 def linear_to_srgb(linear: torch.Tensor) -> torch.Tensor:  # train.py:54-68
@@ -195,7 +195,7 @@ class Stage2Step:
         self.gi, self.sh_degree, self.metallic = gi, sh_degree, metallic
         self.fused, self.light, self.brdf_lut = fused, light, brdf_lut
         self.flags = dict(metallic=metallic, indirect=indirect, gamma=gamma, tone=tone)
-        self.back = self.mips = self.side = None
+        self.back = self.mips = self.side = self.step_begin = None
         # fused + graphs: the rasterizer's planes live at fixed addresses, the graph reads them in place
         self.pool = OutputPool() if (fused and graphs and os.environ.get("GIGS_OUTPUT_POOL", "1") == "1") else None
         self.front = Stage2Front(light, brdf_lut, metallic=metallic, indirect=indirect, tone=tone, gamma=gamma)
@@ -214,12 +214,17 @@ class Stage2Step:
         dev = g["means3D"].device
         background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
         if self.fused:
-            lights = self._fused_begin()
-        if self.pool is not None:
-            with self.pool:
+            if self.step_begin is None:
+                self.step_begin = torch.cuda.Event()
+            self.step_begin.record()
+        lights = []
+        hook = after_blend((lambda: lights.extend(self._fused_begin())) if self.fused else None)
+        with hook:
+            if self.pool is not None:
+                with self.pool:
+                    out = rasterize(cam, g, self.sh_degree, background, self.gi)
+            else:
                 out = rasterize(cam, g, self.sh_degree, background, self.gi)
-        else:
-            out = rasterize(cam, g, self.sh_degree, background, self.gi)
         ((_, radii, _, _, normal_map_from_depth, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map,
           out_normal_view, depth_pos), screenspace_points, st) = out
         H, W = cam["image_height"], cam["image_width"]
@@ -247,9 +252,10 @@ class Stage2Step:
 
 
 def _fused_begin(self):
-    """Starts light.build_mips() on a side stream before the rasterizer is launched: the GGX pre-filter is
-    independent of the G-buffer and overlaps the latency-bound binning / blend kernels (launching it after the
-    rasterizer's host call instead measured the same).  autograd runs a node's backward on the stream of its forward, so the light's
+    """Starts light.build_mips() on a side stream, called from inside the rasterizer's forward as soon as its
+    kernels up to the blend are queued (diff_gaussian_rasterization.after_blend; the host call returns after
+    the binning read-back, while the GPU is still sorting): the GGX pre-filter is independent of the G-buffer
+    and overlaps the latency-bound sort / blend kernels.  autograd runs a node's backward on the stream of its forward, so the light's
     backward likewise overlaps the rasterizer's backward."""
     from stage2_fused import LightMips
     main = torch.cuda.current_stream()
@@ -261,7 +267,10 @@ def _fused_begin(self):
             with torch.no_grad():
                 self.mips(self.dummy)  # builds the cached filter tables outside the capture
             self.mips = graphed(self.mips, (self.dummy,))
-    self.side.wait_stream(main)  # light.base may have been updated on the main stream
+    # light.base may have been updated on the main stream before this step: wait for the point where the step
+    # began, NOT for the rasterizer kernels queued since (waiting for the blend kernel, so that the filter runs
+    # next to the SSAO march only, measured 4 % slower: the march is VALU-bound and loses wave slots to it)
+    self.side.wait_event(self.step_begin)
     with torch.cuda.stream(self.side):
         return self.mips(self.dummy)
 
