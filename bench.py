@@ -202,10 +202,22 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # GIGS_BENCH_FORCE_DIST=1: run the distributed code path (process group, gradient all-reduce, barriers) with a
+    # single rank -- a one-GPU rehearsal of everything but the inter-GPU traffic
+    use_dist = world > 1 or os.environ.get("GIGS_BENCH_FORCE_DIST", "0") == "1"
     dist = None
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+
+    def init_dist():
+        # Called AFTER the first (hipGraph-capturing) step: RCCL's proxy thread issues HIP calls of its own, and a
+        # HIP call from another thread while a stream is capturing in the default (global) mode fails the capture.
+        if not use_dist:
+            return
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -248,16 +260,20 @@ def main():
             out = stepper(cam, g, gt_image, view_dirs[vi])
         else:
             out = stub_step(cam, g, args.sh_degree, gi, gt_image)
-        if world > 1:
+        if use_dist and dist.is_initialized():
             # one flat bucket: xGMI is point-to-point, a single large all-reduce keeps every link busy
             dp.allreduce_gradients(flat_params)
         return out
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_dist:
+        one_step(0)  # captures the hipGraphs (untimed, before the process group exists)
+        torch.cuda.synchronize()
+        init_dist()
     for i in range(args.warmup):
         one_step(i)
     barrier()
@@ -268,7 +284,7 @@ def main():
         barrier()
         t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -344,7 +360,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
