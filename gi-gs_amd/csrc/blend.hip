@@ -28,6 +28,8 @@
 
 namespace gigs {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kLongTile = 2048;  // lists longer than this run at raised wave priority
 
 // ---- DPP helpers ---------------------------------------------------------------------------
@@ -123,8 +125,11 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
 
   float T = 1.0f;
   uint32_t last_contributor = 0;
-  float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, A0 = 0, A1 = 0, A2 = 0;
-  float Rr = 0, Mm = 0, O = 0, P0 = 0, P1 = 0, P2 = 0;  // P2 doubles as D (depth == pos_view.z)
+  // Accumulators paired the way the record words are laid out, so that every `acc += word * weight` (a multiply
+  // and an add: the library is built without FMA contraction) is one v_pk_mul_f32 + one v_pk_add_f32 for two
+  // planes -- same IEEE operations per element, half the instructions on the walk's serial path.
+  f32x2 C01 = {0, 0}, C2P0 = {0, 0}, N01 = {0, 0}, N2P1 = {0, 0}, A01 = {0, 0}, A2P2 = {0, 0}, RM = {0, 0};
+  float O = 0;  // P2 (pos_view.z) doubles as the depth accumulator
   float max_weight = 0.0f, e0 = 0, e1 = 0, e2 = 0;
 
   // pixel-centre box of this wave's quadrant
@@ -185,12 +190,11 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
         const float4 r2 = sw[2 * 64 + bit];  // rgb, pos.x
         const float4 r3 = sw[3 * 64 + bit];  // normal, pos.y
         const float4 r4 = sw[4 * 64 + bit];  // albedo, pos.z
-        C0 += r2.x * weight; C1 += r2.y * weight; C2 += r2.z * weight;
-        A0 += r4.x * weight; A1 += r4.y * weight; A2 += r4.z * weight;
-        N0 += r3.x * weight; N1 += r3.y * weight; N2 += r3.z * weight;
-        Rr += r0.z * weight;
-        Mm += r0.w * weight;
-        P0 += r2.w * weight; P1 += r3.w * weight; P2 += r4.w * weight;
+        const f32x2 w2 = {weight, weight};
+        C01 += f32x2{r2.x, r2.y} * w2; C2P0 += f32x2{r2.z, r2.w} * w2;
+        N01 += f32x2{r3.x, r3.y} * w2; N2P1 += f32x2{r3.z, r3.w} * w2;
+        A01 += f32x2{r4.x, r4.y} * w2; A2P2 += f32x2{r4.z, r4.w} * w2;
+        RM += f32x2{r0.z, r0.w} * w2;
         O += weight;
         if (argmax_depth && weight > max_weight) {  // only the argmax_depth outputs read e0..e2
           e0 = r2.w; e1 = r3.w; e2 = r4.w;
@@ -207,6 +211,8 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   // instances of chunks that were never fetched (every pixel of the quadrant saturated) blend nowhere here
   for (int i = base + lane; i < n; i += 64) hit[4 * (size_t)i] = 0;
 
+  const float C0 = C01.x, C1 = C01.y, C2 = C2P0.x, P0 = C2P0.y, N0 = N01.x, N1 = N01.y, N2 = N2P1.x, P1 = N2P1.y;
+  const float A0 = A01.x, A1 = A01.y, A2 = A2P2.x, P2 = A2P2.y, Rr = RM.x, Mm = RM.y;
   if (inside) {
     const size_t HW = (size_t)H * W;
     final_T[pix_id] = T;

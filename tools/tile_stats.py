@@ -35,3 +35,31 @@ for vi in (0, 3):
     ideal = (300.0 * T + ln.sum()) / 1024
     print("  makespan in-order %.0f  longest-first %.0f  ideal %.0f  (max single %.0f)" % (
         sched(range(T)), sched(np.argsort(-ln)), ideal, 300 + ln.max()))
+
+# contribution density of the longest tiles (per quadrant), from the forward's hit bytes
+for vi in (0,):
+    off_b = lib.gigs_binning_offset(R, 3)
+    # hit_mask follows the sort space in the binning chunk; locate it through its size: 4R bytes after point_list etc.
+    # (diagnostic only: recompute by brute force instead) -> use n_contrib as a proxy for per-pixel depth of the walk
+    ncon = img[lib.gigs_image_offset(800, 800, 1):lib.gigs_image_offset(800, 800, 1) + 4 * 640000].cpu().numpy().view(np.uint32).reshape(800, 800)
+    order = np.argsort(-ln)[:5]
+    for t in order:
+        ty, tx = divmod(int(t), 50)
+        blk = ncon[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]
+        q = [blk[:8, :8].max(), blk[:8, 8:].max(), blk[8:, :8].max(), blk[8:, 8:].max()]
+        print("  tile", t, "len", ln[t], "last contributor per quadrant (max over pixels)", q, "mean", int(blk.mean()))
+
+# walk length per (tile, quadrant): a quadrant stops early only when all its 64 pixels are saturated
+fT = img[lib.gigs_image_offset(800, 800, 0):lib.gigs_image_offset(800, 800, 0) + 4 * 640000].cpu().numpy().view(np.float32).reshape(800, 800)
+walk = []
+for t in range(T):
+    ty, tx = divmod(t, 50)
+    for qy in (0, 1):
+        for qx in (0, 1):
+            sl = (slice(ty * 16 + qy * 8, ty * 16 + qy * 8 + 8), slice(tx * 16 + qx * 8, tx * 16 + qx * 8 + 8))
+            # a saturated pixel stopped at a Gaussian after its last contributor: T * (1 - alpha) < 1e-4
+            sat = (fT[sl] < 0.02).all()
+            walk.append(min(ln[t], int(ncon[sl].max()) + 64) if sat else ln[t])
+walk = np.array(walk)
+print("walked instances per quadrant: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d ; sum %d (vs 4R = %d)" % (
+    walk.mean(), np.median(walk), np.percentile(walk, 90), np.percentile(walk, 99), walk.max(), walk.sum(), 4 * ln.sum()))
