@@ -49,17 +49,16 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
-// Conservative test "no pixel centre of the 8x8 quadrant can pass `alpha >= 1/255`" for one Gaussian.
-// (u0, v0) = mean2D - first pixel centre of the quadrant, so d = mean - pix ranges over
-// [u0-7, u0] x [v0-7, v0]; the exponent -power = Q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy is convex when the
+// Conservative test "no pixel centre of a box of pixels can pass `alpha >= 1/255`" for one Gaussian.
+// d = mean2D - pix ranges over [ua, ub] x [va, vb] (the box is the bounding box of the quadrant's pixels that are
+// still blending, see the forward kernel); the exponent -power = Q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy is convex when the
 // conic is positive definite, and its minimum over the box is 0 (centre inside) or lies on one of the four
 // edges.  alpha >= 1/255 needs Q <= log(255 * opacity); the comparison carries a slack far above the fp32
 // error of both this bound and the kernel's own evaluation of `power`, so a culled Gaussian is one that
 // the reference's per-pixel tests (forward.cu:533-541) would have skipped for every pixel of the quadrant.
-__device__ __forceinline__ bool quadrant_never_blends(float u0, float v0, float A, float B, float C, float op) {
+__device__ __forceinline__ bool box_never_blends(float ua, float ub, float va, float vb, float A, float B, float C, float op) {
   if (op < 1.0f / 255.0f) return true;  // alpha <= opacity * exp(power <= 0)
   if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f)) return false;
-  const float ua = u0 - 7.0f, ub = u0, va = v0 - 7.0f, vb = v0;
   if (ua <= 0.0f && ub >= 0.0f && va <= 0.0f && vb >= 0.0f) return false;
   const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
   auto f = [&](float u, float v) { return 0.5f * (A * u * u + C * v * v) + B * u * v; };
@@ -164,8 +163,18 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
 
     // instance-parallel cull: lane l tests instance base+l against the quadrant, the wave then walks only
     // the surviving bits (in list order, so the blend order is unchanged)
-    unsigned long long m =
-        __ballot(valid && !(cull && quadrant_never_blends(q0.x - qx0, q0.y - qy0, q1.x, q1.y, q1.z, q1.w)));
+    // The box is the bounding box of the pixels of the quadrant that are still blending (not saturated, inside the
+    // image): a quadrant on a silhouette keeps walking for its few open pixels only, and the Gaussians that cover
+    // just its saturated part fall to the cull instead of being evaluated.  Scalar bit arithmetic on one ballot.
+    const unsigned long long open_px = __ballot(!done);  // bit = lane = 8 * row + column; non-zero here
+    unsigned long long fold = open_px | (open_px >> 32);
+    fold |= fold >> 16;
+    fold |= fold >> 8;
+    const unsigned cols = (unsigned)fold & 0xffu;
+    const float bx0 = qx0 + (float)__builtin_ctz(cols), bx1 = qx0 + (float)(31 - __builtin_clz(cols));
+    const float by0 = qy0 + (float)(__builtin_ctzll(open_px) >> 3), by1 = qy0 + (float)((63 - __builtin_clzll(open_px)) >> 3);
+    unsigned long long m = __ballot(
+        valid && !(cull && box_never_blends(q0.x - bx1, q0.x - bx0, q0.y - by1, q0.y - by0, q1.x, q1.y, q1.z, q1.w)));
     unsigned long long hits = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
