@@ -1181,10 +1181,15 @@ int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs
   A.lds_diffuse_off = -1;
   for (int i = 0; i < 8; i++) A.lds_spec_off[i] = -1;
   const int n_dd = 6 * diffuse_res * diffuse_res * 3;
-  if (d_diffuse && n_dd <= gigs::kShadeLdsBudget) { A.lds_diffuse_off = 0; used = n_dd; }
+  static const int lds_budget = [] {  // GIGS_SHADE_LDS_FLOATS: tuning knob (smaller budget -> more workgroups per CU)
+    const char* e = getenv("GIGS_SHADE_LDS_FLOATS");
+    const int v = e ? atoi(e) : gigs::kShadeLdsBudget;
+    return v < 0 ? 0 : (v > gigs::kShadeLdsBudget ? gigs::kShadeLdsBudget : v);
+  }();
+  if (d_diffuse && n_dd <= lds_budget) { A.lds_diffuse_off = 0; used = n_dd; }
   for (int i = n_levels - 1; i >= 0; i--) {
     const int n = 6 * spec_res[i] * spec_res[i] * 3;
-    if (A.d_spec[i] && used + n <= gigs::kShadeLdsBudget) { A.lds_spec_off[i] = used; used += n; }
+    if (A.d_spec[i] && used + n <= lds_budget) { A.lds_spec_off[i] = used; used += n; }
   }
   A.lds_total = used;
   static bool attr_set = false;
