@@ -100,34 +100,31 @@ tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__
 // Launch order of the blend workgroups.  A blend kernel lasts as long as its longest tile list (lists are very
 // skewed: median ~200, maximum ~6000 instances at 800x800), so the long tiles must start first instead of
 // wherever raster order puts them.  rank(t) = number of tiles with a longer list (ties by index): an O(T^2)
-// count is cheapest at T = 2500 tiles (one 6 us kernel); above kMaxOrderedTiles the order is the identity.
+// count is cheapest at T = 2500 tiles (one wave per tile, a few microseconds); above kMaxOrderedTiles the order
+// is the identity.
 constexpr int kMaxOrderedTiles = 16384;
 __global__ void __launch_bounds__(256)
 tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order, int identity) {
-  __shared__ uint32_t s_len[256];
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  // one wave per tile: its 64 lanes stride over all tiles and count, by ballot, those that rank before it
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= T) return;
   if (identity) {
-    if (t < T) order[t] = (uint32_t)t;
+    if (lane == 0) order[t] = (uint32_t)t;
     return;
   }
-  const uint32_t mine = t < T ? ranges[t].y - ranges[t].x : 0u;
+  const uint32_t mine = ranges[t].y - ranges[t].x;
   uint32_t rank = 0;
-  for (int base = 0; base < T; base += 256) {
-    const int u = base + threadIdx.x;
-    __syncthreads();
-    s_len[threadIdx.x] = u < T ? ranges[u].y - ranges[u].x : 0u;
-    __syncthreads();
-    const int lim = min(256, T - base);
-    for (int j = 0; j < lim; j++) {
-      const uint32_t other = s_len[j];
-      rank += (other > mine || (other == mine && base + j < t)) ? 1u : 0u;
-    }
+  for (int base = 0; base < T; base += 64) {
+    const int u = base + lane;
+    const uint32_t other = u < T ? ranges[u].y - ranges[u].x : 0u;
+    const bool before = u < T && (other > mine || (other == mine && u < t));
+    rank += (uint32_t)__popcll(__ballot(before));
   }
-  if (t < T) order[rank] = (uint32_t)t;
+  if (lane == 0) order[rank] = (uint32_t)t;
 }
 
 void launch_tile_order(int T, const uint2* ranges, uint32_t* tile_order, hipStream_t s) {
-  hipLaunchKernelGGL(tile_order_kernel, dim3((T + 255) / 256), dim3(256), 0, s, T, ranges, tile_order,
+  hipLaunchKernelGGL(tile_order_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, tile_order,
                      T > kMaxOrderedTiles ? 1 : 0);
 }
 
