@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -94,6 +95,9 @@ const char* kStageNames[kNumStages] = {
   "preprocess_bwd", "depth_to_normal", "ssao", "ssr", "median3x3", "bilateral3x3",
   "median3x3_bwd", "shade_fwd", "shade_bwd", "cubemap_fwd", "cubemap_bwd", "gbuffer_post",
   "stage2_loss_fwd", "stage2_loss_bwd"};
+
+// optional event recorded on the forward's stream right before the blend kernel is launched (gigs_set_blend_begin_event)
+std::atomic<void*> g_blend_begin_event{nullptr};
 
 struct ProfRec { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -191,6 +195,8 @@ long long gigs_image_offset(int width, int height, int which) {
   if (which < 0 || which >= 3) return -1;
   return (long long)((const char*)ptrs[which] - base);
 }
+
+void gigs_set_blend_begin_event(void* hip_event) { g_blend_begin_event.store(hip_event); }
 
 void gigs_profile_begin(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -316,6 +322,7 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
     gigs::launch_tile_order((int)T, img.ranges, img.tile_order, s);
   }
   STAGE_CHECK("identifyTileRanges");
+  if (void* ev = g_blend_begin_event.load()) HIP_TRY(hipEventRecord((hipEvent_t)ev, s));
   {
     StageScope sc(kBlendFwd, s);
     gigs::launch_blend_fwd(a, geom, bin, img, out_color, out_opacity, out_depth, out_normal,

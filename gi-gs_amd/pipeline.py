@@ -195,7 +195,7 @@ class Stage2Step:
         self.gi, self.sh_degree, self.metallic = gi, sh_degree, metallic
         self.fused, self.light, self.brdf_lut = fused, light, brdf_lut
         self.flags = dict(metallic=metallic, indirect=indirect, gamma=gamma, tone=tone)
-        self.back = self.mips = self.side = self.step_begin = None
+        self.back = self.mips = self.side = self.step_begin = self.blend_begin = None
         # fused + graphs: the rasterizer's planes live at fixed addresses, the graph reads them in place
         self.pool = OutputPool() if (fused and graphs and os.environ.get("GIGS_OUTPUT_POOL", "1") == "1") else None
         self.front = Stage2Front(light, brdf_lut, metallic=metallic, indirect=indirect, tone=tone, gamma=gamma)
@@ -215,16 +215,24 @@ class Stage2Step:
         background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
         if self.fused:
             if self.step_begin is None:
-                self.step_begin = torch.cuda.Event()
+                import gigs_lib
+                self.step_begin, self.blend_begin = torch.cuda.Event(), torch.cuda.Event()
+                self.blend_begin.record()  # creates the underlying hipEvent; the library re-records it in the forward
+                self._set_blend_event = gigs_lib.lib().gigs_set_blend_begin_event
             self.step_begin.record()
+            self._set_blend_event(self.blend_begin.cuda_event)  # only for this forward: cleared again below
         lights = []
         hook = after_blend((lambda: lights.extend(self._fused_begin())) if self.fused else None)
-        with hook:
-            if self.pool is not None:
-                with self.pool:
+        try:
+            with hook:
+                if self.pool is not None:
+                    with self.pool:
+                        out = rasterize(cam, g, self.sh_degree, background, self.gi)
+                else:
                     out = rasterize(cam, g, self.sh_degree, background, self.gi)
-            else:
-                out = rasterize(cam, g, self.sh_degree, background, self.gi)
+        finally:
+            if self.fused:
+                self._set_blend_event(None)
         ((_, radii, _, _, normal_map_from_depth, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map,
           out_normal_view, depth_pos), screenspace_points, st) = out
         H, W = cam["image_height"], cam["image_width"]
@@ -267,10 +275,14 @@ def _fused_begin(self):
             with torch.no_grad():
                 self.mips(self.dummy)  # builds the cached filter tables outside the capture
             self.mips = graphed(self.mips, (self.dummy,))
-    # light.base may have been updated on the main stream before this step: wait for the point where the step
-    # began, NOT for the rasterizer kernels queued since (waiting for the blend kernel, so that the filter runs
-    # next to the SSAO march only, measured 4 % slower: the march is VALU-bound and loses wave slots to it)
-    self.side.wait_event(self.step_begin)
+    # Start when the blend kernel starts (an event the library records right before launching it): that kernel is
+    # a few long serial walks with most CUs idle.  Measured alternatives: starting at once (next to the sort passes,
+    # which then take 0.3-0.5 instead of 0.22 ms) and starting after the blend kernel (next to the VALU-bound SSAO
+    # march only: 4 % slower overall).  GIGS_LIGHT_START=step selects the former.
+    if os.environ.get("GIGS_LIGHT_START", "blend") == "step":
+        self.side.wait_event(self.step_begin)
+    else:
+        self.side.wait_event(self.blend_begin)
     with torch.cuda.stream(self.side):
         return self.mips(self.dummy)
 

@@ -262,6 +262,12 @@ long long gigs_image_offset(int width, int height, int which);
 int gigs_selftest_div2(int n, const float* nx, const float* ny, const float* d, float* out_fast,
                        float* out_ref, int* out_round, void* stream);
 
+/* Optional scheduling hook: a hipEvent_t (caller-owned, NULL = none) that gigs_forward records on its stream right
+ * before it launches the alpha-blend kernel, so that a caller can start independent work on another stream next to
+ * that kernel (it is latency-bound and leaves most CUs idle) rather than next to the bandwidth-bound binning kernels.
+ * Process-wide; set it before the forward that should record it. */
+void gigs_set_blend_begin_event(void* hip_event);
+
 /* In-library stage timing for bench.py.  Between gigs_profile_begin() and gigs_profile_end()
  * every kernel stage launched by this library records a hipEvent pair on its own stream (no
  * synchronisation is added).  gigs_profile_end() waits for the recorded events, writes the
