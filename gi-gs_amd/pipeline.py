@@ -268,6 +268,10 @@ def _fused_begin(self):
     from stage2_fused import LightMips
     main = torch.cuda.current_stream()
     if self.mips is None:
+        # light.base's AccumulateGrad lives on the stream the parameter was created on, its gradient is produced on
+        # the side stream: intended here (autograd inserts the event wait), so the advisory warning is switched off
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.side = torch.cuda.Stream()
         self.mips = LightMips(self.light)
         self.dummy = torch.zeros(1, device=self.light.base.device)
