@@ -181,8 +181,8 @@ long long gigs_binning_offset(int R, int which) {
   char* base = nullptr;
   char* p = base;
   gigs::BinningState b = gigs::BinningState::fromChunk(p, (size_t)R, 0);
-  const void* ptrs[] = {b.keys_unsorted, b.values_unsorted, b.keys, b.point_list};
-  if (which < 0 || which >= 4) return -1;
+  const void* ptrs[] = {b.keys_unsorted, b.values_unsorted, b.keys, b.point_list, b.hit_mask};
+  if (which < 0 || which >= 5) return -1;
   return (long long)((const char*)ptrs[which] - base);
 }
 long long gigs_image_offset(int width, int height, int which) {

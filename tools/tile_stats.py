@@ -63,3 +63,14 @@ for t in range(T):
 walk = np.array(walk)
 print("walked instances per quadrant: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d ; sum %d (vs 4R = %d)" % (
     walk.mean(), np.median(walk), np.percentile(walk, 90), np.percentile(walk, 99), walk.max(), walk.sum(), 4 * ln.sum()))
+
+# backward work per (tile, quadrant): instances the forward recorded as blended there
+hoff = lib.gigs_binning_offset(R, 4)
+hm = binning[hoff:hoff + 4 * R].cpu().numpy().reshape(R, 4)
+hits = []
+for t in range(T):
+    seg = hm[ranges[t, 0]:ranges[t, 1]]
+    hits.extend(seg.sum(0).tolist() if len(seg) else [0, 0, 0, 0])
+hits = np.array(hits)
+print("blended instances per quadrant: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d ; sum %d" % (
+    hits.mean(), np.median(hits), np.percentile(hits, 90), np.percentile(hits, 99), hits.max(), hits.sum()))
