@@ -42,12 +42,15 @@ __device__ __forceinline__ float dpp_mov0(float v) {
 // v_add_f32_dpp (source lane permuted by the DPP modifier, lanes without a source add 0, masked rows keep their
 // value); they are written as instructions because the compiler turns the builtin form into v_mov_b32_dpp +
 // v_add_f32 pairs -- twice the work on the walk's serial path -- and the N chains are interleaved so that the two
-// wait states a DPP read needs after a VALU write of the same register are filled with useful instructions.
+// wait states a DPP read needs after a VALU write of the same register are filled with useful instructions (the
+// leading s_nop covers a value produced by the instruction right before the block: the compiler's hazard
+// recogniser does not look into inline assembly).
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float* v);
 template <>
 __device__ __forceinline__ void wave_sum_n<1>(float* v) {
-  asm("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "s_nop 1\n\t"
@@ -63,7 +66,8 @@ __device__ __forceinline__ void wave_sum_n<1>(float* v) {
 }
 template <>
 __device__ __forceinline__ void wave_sum_n<3>(float* v) {
-  asm("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -85,7 +89,8 @@ __device__ __forceinline__ void wave_sum_n<3>(float* v) {
 }
 template <>
 __device__ __forceinline__ void wave_sum_n<5>(float* v) {
-  asm("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -119,7 +124,8 @@ __device__ __forceinline__ void wave_sum_n<5>(float* v) {
 }
 template <>
 __device__ __forceinline__ void wave_sum_n<10>(float* v) {
-  asm("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -490,6 +496,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
     for (int k = 0; k < 3; k++) rec[k] = src[k];
   }
 
+  if (lane < GIGS_GREC) ssum[lane] = 0.0f;
   for (int base = 0; base < n; base += 64) {
     unsigned long long m = __ballot(h_cur);
     const uint32_t my_id = id_cur;
@@ -520,18 +527,42 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
       const float alpha = fminf(0.99f, r1.w * G);
       const bool act = inside && (contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 
-      float v[GIGS_GREC];
-#pragma unroll
-      for (int k = 0; k < GIGS_GREC; k++) v[k] = 0.0f;
+      // Per gradient group (wave-uniform switches): the 64 per-pixel terms, their wave sum, and lane 63's store of
+      // the sums into the group's slots of the 80-byte LDS row (slots of groups that never run stay zero).  A pixel
+      // that does not blend this Gaussian contributes dchannel_dcolor = 0, i.e. exact zeros (finite gradients).
+      float dchannel_dcolor = 0.0f, one_minus_alpha = 1.0f;
       if (act) {
-        T = T / (1.f - alpha);
-        const float dchannel_dcolor = alpha * T;
-        v[10] = dchannel_dcolor * dn0; v[11] = dchannel_dcolor * dn1; v[12] = dchannel_dcolor * dn2;
-        v[13] = dchannel_dcolor * da0; v[14] = dchannel_dcolor * da1; v[15] = dchannel_dcolor * da2;
-        v[16] = dchannel_dcolor * drg;
-        v[17] = dchannel_dcolor * dmt;
-        v[18] = dchannel_dcolor * ddp;
-        if (any_geo) {  // wave-uniform: the dL_dalpha chain (and its running colour / opacity state) feeds v[0..9] only
+        one_minus_alpha = 1.f - alpha;
+        T = T / one_minus_alpha;
+        dchannel_dcolor = alpha * T;
+      }
+      if (any_mat) {
+        float m[5] = {dchannel_dcolor * da0, dchannel_dcolor * da1, dchannel_dcolor * da2, dchannel_dcolor * drg,
+                      dchannel_dcolor * dmt};
+        wave_sum_n<5>(m);
+        if (lane == 63) {
+#pragma unroll
+          for (int k = 0; k < 5; k++) ssum[13 + k] = m[k];
+        }
+      }
+      if (any_nrm) {
+        float m[3] = {dchannel_dcolor * dn0, dchannel_dcolor * dn1, dchannel_dcolor * dn2};
+        wave_sum_n<3>(m);
+        if (lane == 63) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) ssum[10 + k] = m[k];
+        }
+      }
+      if (any_dep) {
+        float m = dchannel_dcolor * ddp;
+        wave_sum_n<1>(&m);
+        if (lane == 63) ssum[18] = m;
+      }
+      if (any_geo) {  // the dL_dalpha chain (and its running colour / opacity state) feeds sums 0..9 only
+        float v[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k] = 0.0f;
+        if (act) {
           const float4 r2 = sw[2 * 64 + bit];
           float dL_dalpha = 0.0f;
           ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = r2.x;
@@ -545,7 +576,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
           dL_dalpha += (1.0f - accum_opacity) * dop;
           dL_dalpha *= T;
           last_alpha = alpha;
-          dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+          dL_dalpha += (-T_final / one_minus_alpha) * bg_dot_dpixel;
           const float dL_dG = r1.w * dL_dalpha;
           const float gdx = G * dx, gdy = G * dy;
           const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
@@ -558,18 +589,13 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
           v[5] = -0.5f * gdy * dy * dL_dG;
           v[6] = G * dL_dalpha;
         }
-      }
-      if (any_geo) wave_sum_n<10>(v);
-      if (any_nrm) wave_sum_n<3>(v + 10);
-      if (any_mat) wave_sum_n<5>(v + 13);
-      if (any_dep) wave_sum_n<1>(v + 18);
-      // lane 63 holds the sums of the groups that ran (exact zeros elsewhere): 80 bytes to LDS, then lane k
-      // adds sum k to float k of the Gaussian's gradient record
-      if (lane == 63) {
-        float4* d4 = reinterpret_cast<float4*>(ssum);
+        wave_sum_n<10>(v);
+        if (lane == 63) {
 #pragma unroll
-        for (int k = 0; k < GIGS_GREC / 4; k++) d4[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+          for (int k = 0; k < 10; k++) ssum[k] = v[k];
+        }
       }
+      // lane k then adds sum k to float k of the Gaussian's gradient record
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, bit);
