@@ -479,7 +479,7 @@ constexpr int kGiTileLog2W = 3;
 // combined through LDS in the fixed order ((w0 + w1) + w2) + w3.
 __device__ __forceinline__ bool gi_pixel(const GiParams& p, int& x, int& y, int& wave) {
   const int lane = threadIdx.x & 63;
-  wave = threadIdx.x >> 6;
+  wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform: the ray table is then read with s_load
   x = (blockIdx.x << p.tile_log2w) + (lane & ((1 << p.tile_log2w) - 1));
   y = blockIdx.y * (64 >> p.tile_log2w) + (lane >> p.tile_log2w);
   return x < p.W && y < p.H;
