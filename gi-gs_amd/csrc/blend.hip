@@ -43,13 +43,14 @@ __device__ __forceinline__ float dpp_mov0(float v) {
 // value); they are written as instructions because the compiler turns the builtin form into v_mov_b32_dpp +
 // v_add_f32 pairs -- twice the work on the walk's serial path -- and the N chains are interleaved so that the two
 // wait states a DPP read needs after a VALU write of the same register are filled with useful instructions (the
-// leading s_nop covers a value produced by the instruction right before the block: the compiler's hazard
-// recogniser does not look into inline assembly).
+// leading s_nop 4 covers what may sit right before the block -- a VALU write of an operand needs 2 wait states
+// before a DPP read, a VALU write of EXEC (v_cmpx) 5: the compiler's hazard recogniser does not look into inline
+// assembly).
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float* v);
 template <>
 __device__ __forceinline__ void wave_sum_n<1>(float* v) {
-  asm("s_nop 1\n\t"
+  asm("s_nop 4\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -66,7 +67,7 @@ __device__ __forceinline__ void wave_sum_n<1>(float* v) {
 }
 template <>
 __device__ __forceinline__ void wave_sum_n<3>(float* v) {
-  asm("s_nop 1\n\t"
+  asm("s_nop 4\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -89,7 +90,7 @@ __device__ __forceinline__ void wave_sum_n<3>(float* v) {
 }
 template <>
 __device__ __forceinline__ void wave_sum_n<5>(float* v) {
-  asm("s_nop 1\n\t"
+  asm("s_nop 4\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -124,7 +125,7 @@ __device__ __forceinline__ void wave_sum_n<5>(float* v) {
 }
 template <>
 __device__ __forceinline__ void wave_sum_n<10>(float* v) {
-  asm("s_nop 1\n\t"
+  asm("s_nop 4\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
