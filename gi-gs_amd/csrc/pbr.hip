@@ -902,6 +902,9 @@ shade_bwd_kernel(ShadeArgs A) {
     float* t1 = A.lds_spec_off[q.l1] >= 0 ? s_lds + A.lds_spec_off[q.l1] : A.d_spec[q.l1];
     if (!A.d_spec[q.l0]) t0 = nullptr;
     if (!A.d_spec[q.l1]) t1 = nullptr;
+    // diagnostic (GIGS_ABLATE bit 2 / 3): drop the adds that go to LDS-resident / to global levels
+    if (((A.ablate & 4) && A.lds_spec_off[q.l0] >= 0) || ((A.ablate & 8) && A.lds_spec_off[q.l0] < 0)) t0 = nullptr;
+    if (((A.ablate & 4) && A.lds_spec_off[q.l1] >= 0) || ((A.ablate & 8) && A.lds_spec_off[q.l1] < 0)) t1 = nullptr;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int idx = (live && q.has0 && t0) ? q.t0.idx[k] : -1;
