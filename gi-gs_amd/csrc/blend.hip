@@ -30,6 +30,11 @@ namespace gigs {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Lane mask of a predicate.  HIP's ballot64(int) goes through a 0/1 VGPR and a compare (v_cndmask + v_cmp_ne per
+// call); the builtin takes the predicate's own mask -- it matters in the walk, where every instruction of the one
+// wave that holds up the kernel counts.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 constexpr int kLongTile = 2048;  // lists longer than this run at raised wave priority
 
 // ---- DPP helpers ---------------------------------------------------------------------------
@@ -256,7 +261,8 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   const unsigned py = ty * GIGS_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < (unsigned)W && py < (unsigned)H;
   const size_t pix_id = (size_t)W * py + px;
-  const float pixfx = (float)px, pixfy = (float)py;
+  float pixfx = (float)px, pixfy = (float)py;
+  asm volatile("" : "+v"(pixfx), "+v"(pixfy));  // not to be rematerialised (2 v_cvt per survivor) inside the walk
   bool done = !inside;
 
   const uint2 range = ranges[tile];
@@ -290,7 +296,7 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   uint32_t id_next = (64 + lane < n) ? point_list[range.x + 64 + lane] : 0u;
 
   int base = 0;
-  bool wave_done = __ballot(!done) == 0ull;
+  bool wave_done = ballot64(!done) == 0ull;
   for (; base < n && !wave_done; base += 64) {
     const bool valid = base + lane < n;
     // this chunk: stage the records for the broadcast reads of the walk, keep mean/conic/opacity for the cull
@@ -310,14 +316,14 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
     // The box is the bounding box of the pixels of the quadrant that are still blending (not saturated, inside the
     // image): a quadrant on a silhouette keeps walking for its few open pixels only, and the Gaussians that cover
     // just its saturated part fall to the cull instead of being evaluated.  Scalar bit arithmetic on one ballot.
-    const unsigned long long open_px = __ballot(!done);  // bit = lane = 8 * row + column; non-zero here
+    const unsigned long long open_px = ballot64(!done);  // bit = lane = 8 * row + column; non-zero here
     unsigned long long fold = open_px | (open_px >> 32);
     fold |= fold >> 16;
     fold |= fold >> 8;
     const unsigned cols = (unsigned)fold & 0xffu;
     const float bx0 = qx0 + (float)__builtin_ctz(cols), bx1 = qx0 + (float)(31 - __builtin_clz(cols));
     const float by0 = qy0 + (float)(__builtin_ctzll(open_px) >> 3), by1 = qy0 + (float)((63 - __builtin_clzll(open_px)) >> 3);
-    unsigned long long m = __ballot(
+    unsigned long long m = ballot64(
         valid && !(cull && box_never_blends(q0.x - bx1, q0.x - bx0, q0.y - by1, q0.y - by0, q1.x, q1.y, q1.z, q1.w)));
     unsigned long long hits = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -337,7 +343,7 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
       const bool stop = cand && test_T < 0.0001f;
       const bool contrib = cand && !stop;
       if (stop) done = true;
-      if (__ballot(contrib) != 0ull) hits |= 1ull << bit;
+      if (ballot64(contrib) != 0ull) hits |= 1ull << bit;
       if (contrib) {
         const float weight = alpha * T;
         const float4 r2 = sw[2 * 64 + bit];  // rgb, pos.x
@@ -349,15 +355,19 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
         A01 += f32x2{r4.x, r4.y} * w2; A2P2 += f32x2{r4.z, r4.w} * w2;
         RM += f32x2{r0.z, r0.w} * w2;
         O += weight;
-        if (argmax_depth && weight > max_weight) {  // only the argmax_depth outputs read e0..e2
-          e0 = r2.w; e1 = r3.w; e2 = r4.w;
-          max_weight = weight;
+        if (argmax_depth) {  // wave-uniform: only the argmax_depth outputs read e0..e2
+          if (weight > max_weight) {
+            e0 = r2.w; e1 = r3.w; e2 = r4.w;
+            max_weight = weight;
+          }
         }
         T = test_T;
         last_contributor = (uint32_t)(base + bit + 1);
       }
-      if (__ballot(stop) != 0ull && __ballot(!done) == 0ull) { wave_done = true; break; }
     }
+    // "every pixel of the quadrant saturated" is looked at once per chunk, not per survivor: two ballots less on the
+    // serial path of the long walks, at most one chunk of cheap non-blending evaluations more for the others
+    wave_done = ballot64(!done) == 0ull;
     __builtin_amdgcn_wave_barrier();  // the walk's LDS reads precede the next chunk's staging stores
     if (valid) hit[4 * (size_t)(base + lane)] = (uint8_t)((hits >> lane) & 1ull);
   }
