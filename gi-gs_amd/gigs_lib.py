@@ -76,6 +76,7 @@ SIGNATURES = {
     "gigs_binning_offset": (C.c_longlong, [_i, _i]),
     "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),
     "gigs_selftest_div2": (_i, [_i, _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_selftest_round": (_i, [_f, C.c_void_p]),
     "gigs_set_blend_begin_event": (None, [C.c_void_p]),
     "gigs_profile_begin": (None, []),
     "gigs_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),

@@ -262,6 +262,10 @@ long long gigs_image_offset(int width, int height, int which);
  * out_round[2i] = the add-and-truncate rounding of nx[i], out_round[2i+1] = (int)roundf(nx[i]). */
 int gigs_selftest_div2(int n, const float* nx, const float* ny, const float* d, float* out_fast,
                        float* out_ref, int* out_round, void* stream);
+/* Exhaustive self-test of the march's pixel rounding: *mismatches (device u64) receives the number of fp32 bit
+ * patterns t (all 2^32 are tried) for which floor(t + (0.5 - 2^-25)) and (int)roundf(t) would select a different
+ * pixel or decide "inside the image" differently for some image side < 2^15.  Expected: 0. */
+int gigs_selftest_round(unsigned long long* mismatches, void* stream);
 
 /* Optional scheduling hook: a hipEvent_t (caller-owned, NULL = none) that gigs_forward records on its stream right
  * before it launches the alpha-blend kernel, so that a caller can start independent work on another stream next to

@@ -493,3 +493,15 @@ def test_fast_div2_and_rounding_are_bit_exact():
     assert np.all((a == b) | both_nan), f"{int(((a != b) & ~both_nan).sum())} quotients differ"
     r = ornd.cpu().numpy().reshape(-1, 2)
     np.testing.assert_array_equal(r[:, 0], r[:, 1])
+
+
+def test_pixel_rounding_is_exact_for_every_float():
+    """gi.hip rounds projected coordinates with floor(t + (0.5 - 2^-25)) instead of (int)roundf(t); the device sweeps
+    all 2^32 floats and counts those where the two would pick a different pixel or a different inside/outside
+    decision for an image side below 2^15."""
+    import gigs_lib
+    lib = gigs_lib.lib()
+    bad = torch.ones(1, dtype=torch.int64, device=DEV)
+    assert lib.gigs_selftest_round(bad.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
