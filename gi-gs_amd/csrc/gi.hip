@@ -228,9 +228,30 @@ __device__ __forceinline__ int round_to_int(float t) { return f2i(t + copysignf(
 // Checked over ALL 2^32 floats on the device: gigs_selftest_round.
 __device__ __forceinline__ int round_pix(float t) { return f2i(floorf(t + 0.49999997f)); }
 
-// Buffer descriptor (raw, byte offsets, hardware range check) of one fp32 image plane.
+// Buffer descriptor of one fp32 image plane with a 4-byte stride: an `idxen` load takes the pixel index itself (the
+// hardware scales it) and range-checks it against the pixel count, an `offen` load with a byte offset works too.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t z_plane_rsrc(const float* plane, size_t HW) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane), /*stride*/ 0, (int)(HW * sizeof(float)), 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane), /*stride*/ 4, (int)HW, 0x00020000);
+}
+
+// N indexed gathers in flight, then one wait.  Inline assembly because clang has no builtin for the indexed (struct)
+// buffer load; the destinations are not tracked by the compiler's wait-count insertion, hence the explicit s_waitcnt
+// that every result passes through before it is used.
+__device__ __forceinline__ float gather_idx_issue(unsigned i, __amdgpu_buffer_rsrc_t rsrc) {
+  float z;
+  asm volatile("buffer_load_dword %0, %1, %2, 0 idxen" : "=&v"(z) : "v"(i), "s"(rsrc));
+  return z;
+}
+template <int N>
+__device__ __forceinline__ void gather_idx(float* z, const unsigned* i, __amdgpu_buffer_rsrc_t rsrc) {
+  static_assert(N == 4 || N == 8, "group sizes of the march");
+#pragma unroll
+  for (int k = 0; k < N; k++) z[k] = gather_idx_issue(i[k], rsrc);
+  if constexpr (N == 8)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]));
+  else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
 }
 
 // Sample coordinates of one group of steps for kRays rays: byte offset into the z plane (0 when the sample
@@ -282,8 +303,8 @@ __device__ __forceinline__ float group_coords(const GiParams& p, v3 pos, float a
       // The gather goes through a buffer descriptor of exactly the z plane: an out-of-image sample (never
       // used: inb is false) yields some wrapped offset that the hardware range check either reads harmlessly
       // or answers with 0 -- no clamp, no predication.  W, H < 2^15 (checked by the C-ABI wrapper), so the
-      // in-image offset is exact in the 24-bit multiply and fits 32 bits.
-      off[k][g] = (__umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix) << 2;
+      // in-image pixel index is exact in the 24-bit multiply.
+      off[k][g] = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;
       spzv[k][g] = spz;
     }
   }
@@ -344,7 +365,7 @@ __device__ __forceinline__ float group_coords2(const GiParams& p, v3 pos, float 
       const int ix = round_pix(t.x);
       const int iy = round_pix(t.y);
       inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
-      off[k][g] = (__umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix) << 2;  // see group_coords
+      off[k][g] = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;  // see group_coords
     }
   }
   return min_den;
@@ -377,11 +398,20 @@ __device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, c
       min_den = fminf(min_den, group_coords2<kPow2, kGroup, kExact>(p, pos, a, sv, cx, cy, mag_ok, j0, off, inb, hi2, lo2));
     else
       min_den = fminf(min_den, group_coords<kPow2, kGroup, kRays, kExact>(p, pos, a, sv, cx, cy, mag_ok, j0, off, inb, spzv));
+    {
+      constexpr int kN = kRays * kGroup;
+      unsigned in[kN];
+      float zn[kN];
 #pragma unroll
-    for (int g = 0; g < kGroup; g++)
+      for (int g = 0; g < kGroup; g++)
 #pragma unroll
-      for (int k = 0; k < kRays; k++)
-        zv[k][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pos_z, (int)off[k][g], 0, 0));
+        for (int k = 0; k < kRays; k++) in[g * kRays + k] = off[k][g];
+      gather_idx<kN>(zn, in, pos_z);
+#pragma unroll
+      for (int g = 0; g < kGroup; g++)
+#pragma unroll
+        for (int k = 0; k < kRays; k++) zv[k][g] = zn[g * kRays + k];
+    }
     bool any_open = false;
 #pragma unroll
     for (int k = 0; k < kRays; k++) {
@@ -396,7 +426,7 @@ __device__ __forceinline__ bool march_impl(const GiParams& p, v3 pos, float a, c
           lo = spzv[k][g] - p.thick;
         }
         const bool h = inb[k][g] && (zv[k][g] <= hi) && (zv[k][g] >= lo);
-        hit[k] = (open[k] && h) ? (int)(off[k][g] >> 2) : hit[k];
+        hit[k] = (open[k] && h) ? (int)off[k][g] : hit[k];
         open[k] = open[k] && inb[k][g] && !h;
       }
       any_open = any_open || open[k];
