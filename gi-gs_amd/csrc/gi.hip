@@ -172,6 +172,10 @@ struct GiParams {
   float inv_step;  // exact 1/step when step is a power of two
   int nrays;
   int tile_log2w;  // the 64 pixels of a workgroup form a (1 << tile_log2w) x (64 >> tile_log2w) rectangle
+  // j / step for j = start .. start + 63 (exact for a power-of-two step): the fast path reads its per-step factor from
+  // here with a scalar load instead of converting and multiplying on the vector ALU for every group (marches of more
+  // than kFjTable - kGiGroup steps take the general path)
+  float fjt[64];
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -227,6 +231,8 @@ __device__ __forceinline__ int round_to_int(float t) { return f2i(t + copysignf(
 // are both outside otherwise.  v_floor_f32 (VOP1) replaces v_bfi_b32 (VOP3: ~1.5 cycles more per coordinate).
 // Checked over ALL 2^32 floats on the device: gigs_selftest_round.
 __device__ __forceinline__ int round_pix(float t) { return f2i(floorf(t + 0.49999997f)); }
+// the same for a coordinate pair whose +(0.5 - 2^-25) is done as one packed add
+__device__ __forceinline__ int floor_pix(float t_plus_half) { return f2i(floorf(t_plus_half)); }
 
 // Buffer descriptor of one fp32 image plane with a 4-byte stride: an `idxen` load takes the pixel index itself (the
 // hardware scales it) and range-checks it against the pixel count, an `offen` load with a byte offset works too.
@@ -271,7 +277,7 @@ __device__ __forceinline__ float group_coords(const GiParams& p, v3 pos, float a
     // rounding of the chain as long as no intermediate falls into the subnormal range: the fast path folds it
     // into j (j / step is exact) and saves three multiplies per sample; `sv_scale_ok` (checked per ray by the
     // caller) rules the subnormal case out, otherwise the exact path below runs.
-    const float fj = (kPow2 && !kExact) ? (float)(j0 + g) * p.inv_step : (float)(j0 + g);
+    const float fj = (kPow2 && !kExact) ? p.fjt[j0 - p.start + g] : (float)(j0 + g);
     const bool in_range = (j0 + g) < p.step;
 #pragma unroll
     for (int k = 0; k < kRays; k++) {
@@ -296,9 +302,9 @@ __device__ __forceinline__ float group_coords(const GiParams& p, v3 pos, float a
       } else {
         min_den = fminf(min_den, fabsf(den));  // a NaN den is not recorded: both paths then give NaN -> pixel (0, 0)
       }
-      const f32x2 t = qv * fxy + cxy;
-      const int ix = round_pix(t.x);
-      const int iy = round_pix(t.y);
+      const f32x2 t = (qv * fxy + cxy) + 0.49999997f;  // round_pix's addend, packed
+      const int ix = floor_pix(t.x);
+      const int iy = floor_pix(t.y);
       inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
       // The gather goes through a buffer descriptor of exactly the z plane: an out-of-image sample (never
       // used: inb is false) yields some wrapped offset that the hardware range check either reads harmlessly
@@ -326,7 +332,7 @@ __device__ __forceinline__ float group_coords2(const GiParams& p, v3 pos, float 
   float min_den = __builtin_inff();
 #pragma unroll
   for (int g = 0; g < kGroup; g++) {
-    const float fj = (kPow2 && !kExact) ? (float)(j0 + g) * p.inv_step : (float)(j0 + g);  // see group_coords
+    const float fj = (kPow2 && !kExact) ? p.fjt[j0 - p.start + g] : (float)(j0 + g);  // see group_coords
     const bool in_range = (j0 + g) < p.step;
     f32x2 m[2] = {sxy[0] * fj, sxy[1] * fj};
     f32x2 mz = svz * fj;
@@ -361,9 +367,9 @@ __device__ __forceinline__ float group_coords2(const GiParams& p, v3 pos, float 
       if (kExact) {
         if (!(mag_ok && fabsf(d) > 0x1p-60f)) qv = f32x2{sp.x / d, sp.y / d};
       }
-      const f32x2 t = qv * fxy + cxy;
-      const int ix = round_pix(t.x);
-      const int iy = round_pix(t.y);
+      const f32x2 t = (qv * fxy + cxy) + 0.49999997f;  // round_pix's addend, packed
+      const int ix = floor_pix(t.x);
+      const int iy = floor_pix(t.y);
       inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
       off[k][g] = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;  // see group_coords
     }
@@ -698,6 +704,8 @@ static GiParams make_params(int W, int H, float fx, float fy, float radius, floa
   p.step = step; p.start = start; p.nrays = nrays;
   pow2 = step > 0 && (step & (step - 1)) == 0 && step <= (1 << 20);
   p.inv_step = pow2 ? 1.0f / (float)step : 0.0f;
+  if (step - start > 64 - kGiGroup) pow2 = false;  // a partial last group may index kGiGroup - 1 entries past step - 1
+  for (int k = 0; k < 64; k++) p.fjt[k] = (float)(start + k) * p.inv_step;
   // GIGS_GI_TILE_LOG2W: tuning knob for the pixel rectangle of a workgroup (3 = 8x8 ... 6 = 64x1)
   const char* e = getenv("GIGS_GI_TILE_LOG2W");
   p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
