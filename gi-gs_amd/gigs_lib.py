@@ -72,6 +72,14 @@ SIGNATURES = {
     "gigs_gbuffer_post": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_loss_scratch_floats": (C.c_size_t, [_i, _i, _i]),
+    "gigs_l1_ssim_fwd": (_i, [_i, _i, _i, _f, _f, C.c_float, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_l1_ssim_bwd": (_i, [_i, _i, _i, _f, _f, C.c_float, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_tv_loss_fwd": (_i, [_i, _i, _i, _i, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_tv_loss_bwd": (_i, [_i, _i, _i, _i, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_masked_l1_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_masked_l1_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_adam_step": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, C.c_void_p]),
     "gigs_geom_offset": (C.c_longlong, [_i, _i]),
     "gigs_binning_offset": (C.c_longlong, [_i, _i]),
     "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),
@@ -89,6 +97,12 @@ class ShadeExt(C.Structure):
                 ("out_F0", C.c_void_p), ("out_linear", C.c_void_p), ("out_roughness", C.c_void_p),
                 ("g_albedo_mul_a", C.c_void_p), ("g_albedo_mul_b", C.c_void_p),
                 ("g_roughness_add", C.c_void_p), ("g_metallic_add", C.c_void_p)]
+
+
+class AdamGroup(C.Structure):
+    """gigs_adam_group of include/gigs_hip.h."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_longlong), ("lr", C.c_double), ("step", C.c_int)]
 
 
 _lib = None

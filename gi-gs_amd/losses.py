@@ -1,0 +1,187 @@
+"""The training loop's image losses on libgigs_hip.
+
+Same names, arguments and results as the reference's helpers, each one HIP pass forward and one backward
+instead of a chain of torch ops:
+
+    l1_loss(network_output, gt)                          utils/loss_utils.py:19-20
+    ssim(img1, img2, window_size=11, size_average=True)  utils/loss_utils.py:55-98
+    l1_ssim_loss(image, gt, lambda_dssim)                train.py:318-320  (1-l)*L1 + l*(1-ssim), one kernel
+    get_tv_loss(gt_image, prediction, pad=1, step=1)     train.py:83-113
+    get_masked_tv_loss(mask, gt_image, prediction)       train.py:116-142
+    masked_l1_loss(a, b, mask)                           train.py:327  F.l1_loss(a[:, mask], b[:, mask])
+    stage1_loss(...)                                     train.py:318-331, the whole stage-1 objective
+
+Images are [C,H,W] fp32 on the GPU.  There is no CPU path: without libgigs_hip.so importing this module fails,
+and CPU tensors raise.
+"""
+from __future__ import annotations
+
+import torch
+
+import gigs_lib
+
+_lib = gigs_lib.lib()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chw(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: needs CUDA/HIP tensors, gigs-hip has no CPU path")
+    if t.dim() != 3:
+        raise ValueError(f"{what}: expected [C,H,W], got {tuple(t.shape)}")
+    return t.contiguous().float()
+
+
+def _scratch(C: int, H: int, W: int, dev) -> torch.Tensor:
+    return torch.empty(int(_lib.gigs_loss_scratch_floats(C, H, W)), dtype=torch.float32, device=dev)
+
+
+class _L1Ssim(torch.autograd.Function):
+    """(image, gt, lambda) -> [loss, mean|image-gt|, mean ssim]; gradient to image through loss only."""
+
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        image, gt = _chw(image, "l1_ssim"), _chw(gt, "l1_ssim")
+        if image.shape != gt.shape:
+            raise ValueError("l1_ssim: image and gt differ in shape")
+        C, H, W = image.shape
+        need = bool(ctx.needs_input_grad[0])
+        d = torch.empty((3, C, H, W), dtype=torch.float32, device=image.device) if need else None
+        out = torch.empty(3, dtype=torch.float32, device=image.device)
+        with torch.cuda.device(image.device):
+            gigs_lib.check(_lib.gigs_l1_ssim_fwd(C, H, W, _p(image), _p(gt), float(lambda_dssim),
+                                                 _p(d[0]) if need else None, _p(d[1]) if need else None,
+                                                 _p(d[2]) if need else None, _p(_scratch(C, H, W, image.device)),
+                                                 _p(out), _stream()), "l1_ssim_fwd")
+        ctx.lam = float(lambda_dssim)
+        ctx.save_for_backward(image, gt, d if need else torch.empty(0, device=image.device))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        image, gt, d = ctx.saved_tensors
+        C, H, W = image.shape
+        g_image = torch.empty_like(image)
+        # only out[0] (the loss) carries gradient here; out[1:] are reporting values
+        g = g_out[0:1].contiguous().float()
+        with torch.cuda.device(image.device):
+            gigs_lib.check(_lib.gigs_l1_ssim_bwd(C, H, W, _p(image), _p(gt), ctx.lam, _p(d[0]), _p(d[1]), _p(d[2]),
+                                                 _p(g), _p(g_image), _stream()), "l1_ssim_bwd")
+        return g_image, None, None
+
+
+def l1_ssim_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
+    """train.py:320: (1 - lambda) * l1 + lambda * (1 - ssim(image, gt)), one fused pass."""
+    return _L1Ssim.apply(image, gt, lambda_dssim)[0]
+
+
+def l1_loss(network_output: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """utils/loss_utils.py:19-20."""
+    return _L1Ssim.apply(network_output, gt, 0.0)[0]
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True) -> torch.Tensor:
+    """utils/loss_utils.py:55-98 for one [C,H,W] image, window 11 and the scalar mean (what train.py uses)."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("ssim: only window_size=11, size_average=True (the reference's only use)")
+    # loss = 1 - ssim at lambda = 1
+    return 1.0 - _L1Ssim.apply(img1, img2, 1.0)[0]
+
+
+class _Tv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt, prediction, mask_f, step):
+        gt, prediction = _chw(gt, "tv_loss"), _chw(prediction, "tv_loss")
+        C, H, W = prediction.shape
+        if gt.shape != (3, H, W):
+            raise ValueError("tv_loss: gt_image must be [3,H,W] matching prediction")
+        if mask_f is not None:
+            mask_f = mask_f.reshape(H, W).contiguous().float()
+        loss = torch.empty(1, dtype=torch.float32, device=gt.device)
+        with torch.cuda.device(gt.device):
+            gigs_lib.check(_lib.gigs_tv_loss_fwd(C, H, W, int(step), _p(gt), _p(prediction), _p(mask_f),
+                                                 _p(_scratch(C, H, W, gt.device)), _p(loss), _stream()), "tv_loss_fwd")
+        ctx.step = int(step)
+        ctx.has_mask = mask_f is not None
+        ctx.save_for_backward(gt, prediction, mask_f if mask_f is not None else torch.empty(0, device=gt.device))
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        gt, prediction, mask_f = ctx.saved_tensors
+        C, H, W = prediction.shape
+        g_pred = torch.empty_like(prediction)
+        g = g_loss.reshape(1).contiguous().float()
+        with torch.cuda.device(gt.device):
+            gigs_lib.check(_lib.gigs_tv_loss_bwd(C, H, W, ctx.step, _p(gt), _p(prediction),
+                                                 _p(mask_f) if ctx.has_mask else None, _p(g), _p(g_pred), _stream()),
+                           "tv_loss_bwd")
+        return None, g_pred, None, None
+
+
+def get_tv_loss(gt_image: torch.Tensor, prediction: torch.Tensor, pad: int = 1, step: int = 1) -> torch.Tensor:
+    """train.py:83-113 (pad > 1 average-pools both inputs first, as there)."""
+    if pad > 1:
+        gt_image = torch.nn.functional.avg_pool2d(gt_image, pad, pad)
+        prediction = torch.nn.functional.avg_pool2d(prediction, pad, pad)
+    return _Tv.apply(gt_image, prediction, None, step)
+
+
+def get_masked_tv_loss(mask: torch.Tensor, gt_image: torch.Tensor, prediction: torch.Tensor,
+                       erosion: bool = False) -> torch.Tensor:
+    """train.py:116-142; `erosion` (a 7x7 kornia morphology pass the reference never enables) is not provided."""
+    if erosion:
+        raise NotImplementedError("get_masked_tv_loss: erosion=True is unused by the reference and not implemented")
+    return _Tv.apply(gt_image, prediction, mask.float(), 1)
+
+
+class _MaskedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, mask):
+        a, b = _chw(a, "masked_l1"), _chw(b, "masked_l1")
+        C, H, W = a.shape
+        if b.shape != a.shape or mask.numel() != H * W:
+            raise ValueError("masked_l1: shapes differ")
+        mask_u8 = mask.reshape(H, W).contiguous().to(torch.uint8)
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            gigs_lib.check(_lib.gigs_masked_l1_fwd(C, H, W, _p(a), _p(b), _p(mask_u8), _p(_scratch(C, H, W, a.device)),
+                                                   _p(out), _stream()), "masked_l1_fwd")
+        ctx.save_for_backward(a, b, mask_u8, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        a, b, mask_u8, out = ctx.saved_tensors
+        C, H, W = a.shape
+        g_a = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        g_b = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if g_a is None and g_b is None:
+            return None, None, None
+        g = g_loss.reshape(1).contiguous().float()
+        with torch.cuda.device(a.device):
+            gigs_lib.check(_lib.gigs_masked_l1_bwd(C, H, W, _p(a), _p(b), _p(mask_u8), _p(out), _p(g), _p(g_a), _p(g_b),
+                                                   _stream()), "masked_l1_bwd")
+        return g_a, g_b, None
+
+
+def masked_l1_loss(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """train.py:327: F.l1_loss(a[:, mask], b[:, mask]) with a boolean [H,W] mask (NaN for an empty mask, as torch)."""
+    return _MaskedL1.apply(a, b, mask)
+
+
+def stage1_loss(image, gt_image, normal_map, normal_map_from_depth, normal_from_depth_mask, lambda_dssim=0.2,
+                normal_loss_weight=1.0, normal_tv_weight=1.0):
+    """The stage-1 objective of train.py:318-331 -> (loss, Ll1, normal_loss)."""
+    out = _L1Ssim.apply(image, gt_image, lambda_dssim)
+    normal_loss = masked_l1_loss(normal_map, normal_map_from_depth, normal_from_depth_mask)
+    loss = out[0] + normal_loss_weight * normal_loss
+    loss = loss + get_tv_loss(gt_image, normal_map, pad=1, step=1) * normal_tv_weight
+    return loss, out[1].detach(), normal_loss

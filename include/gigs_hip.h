@@ -246,6 +246,46 @@ int gigs_stage2_loss_bwd(int height, int width, const float* render_direct, cons
                          float* d_render_direct, float* d_irr_linear, float* d_roughness, float* d_metallic,
                          void* stream);
 
+/* Training-loop glue (gigs-hip extension): the image losses of train.py and the Adam step, one
+ * pass each.  Planes are [C,H,W] fp32; `scratch` holds at least gigs_loss_scratch_floats(C,H,W) floats (per-workgroup
+ * partial sums, added in a fixed order -> reproducible losses); g_loss is a device scalar (NULL = 1).
+ * gigs_l1_ssim_fwd = train.py:318-320 with utils/loss_utils.py:19-20, 55-98:
+ *   out3 = {(1-lambda)*mean|image-gt| + lambda*(1-mean(ssim_map)), mean|image-gt|, mean(ssim_map)}; window 11,
+ *   sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2.  d_mu1/d_e11/d_e12 [C,H,W] (all or none) receive the
+ *   per-pixel derivatives of ssim_map that gigs_l1_ssim_bwd spreads back through the window into g_image.
+ * gigs_tv_loss_fwd/bwd = get_tv_loss(gt, prediction, pad=1, step) (train.py:83-113) or, with mask_f [H,W] != NULL,
+ *   get_masked_tv_loss without erosion (train.py:116-142); gt is [3,H,W], prediction [C,H,W]; gradient to prediction.
+ * gigs_masked_l1_fwd/bwd = F.l1_loss(a[:, mask], b[:, mask]) (train.py:327), mask u8 [H,W];
+ *   loss_count = {loss, number of mask pixels}; g_a / g_b may each be NULL (g_b = -g_a).
+ * gigs_adam_step = torch.optim.Adam(eps=..., betas=...) without weight decay / amsgrad, as the reference configures it
+ *   (scene/gaussian_model.py:325-346), for all parameter groups in one launch per 16 groups; `step` is the 1-based
+ *   update count of the group's state, `lr` its current learning rate; zero_grad != 0 also clears the gradients. */
+typedef struct gigs_adam_group {
+  float* param;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  long long n;
+  double lr;
+  int step;
+} gigs_adam_group;
+size_t gigs_loss_scratch_floats(int channels, int height, int width);
+int gigs_l1_ssim_fwd(int channels, int height, int width, const float* image, const float* gt, float lambda_dssim,
+                     float* d_mu1, float* d_e11, float* d_e12, float* scratch, float* out3, void* stream);
+int gigs_l1_ssim_bwd(int channels, int height, int width, const float* image, const float* gt, float lambda_dssim,
+                     const float* d_mu1, const float* d_e11, const float* d_e12, const float* g_loss, float* g_image,
+                     void* stream);
+int gigs_tv_loss_fwd(int channels, int height, int width, int step, const float* gt, const float* prediction,
+                     const float* mask_f, float* scratch, float* loss, void* stream);
+int gigs_tv_loss_bwd(int channels, int height, int width, int step, const float* gt, const float* prediction,
+                     const float* mask_f, const float* g_loss, float* g_prediction, void* stream);
+int gigs_masked_l1_fwd(int channels, int height, int width, const float* a, const float* b, const uint8_t* mask,
+                       float* scratch, float* loss_count, void* stream);
+int gigs_masked_l1_bwd(int channels, int height, int width, const float* a, const float* b, const uint8_t* mask,
+                       const float* loss_count, const float* g_loss, float* g_a, float* g_b, void* stream);
+int gigs_adam_step(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
+                   void* stream);
+
 /* Test/diagnostic views into the opaque scratch buffers (byte offsets from the buffer
  * start, or -1).  `which`: geometry 0 depths f32[P], 1 pos_view f32[3P], 2 means2D f32[2P],
  * 3 cov3D f32[6P], 4 conic_opacity f32[4P], 5 rgb f32[3P], 6 clamped u8[3P],
