@@ -611,6 +611,44 @@ cubemap_mip_bwd_kernel(int r, const float* __restrict__ dout, float* __restrict_
   din[3 * (size_t)i] = v.x; din[3 * (size_t)i + 1] = v.y; din[3 * (size_t)i + 2] = v.z;
 }
 
+// dr.texture(cubemap[None], dirs[None], filter_mode="linear", boundary_mode="cube") for a list of directions
+// (train.py:409-417 envmap TV, render.py:80 / relight.py:108 envmap export): out is [n,3], or [3,n] planes if planar.
+__global__ void __launch_bounds__(256)
+cube_texture_fwd_kernel(int res, const float* __restrict__ tex, int n, const float* __restrict__ dirs,
+                        float* __restrict__ out, int planar) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Taps t;
+  v3 v = {0, 0, 0};
+  if (cube_taps(res, dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2], t)) v = cube_sample(tex, t);
+  if (planar) {
+    out[i] = v.x; out[(size_t)n + i] = v.y; out[2 * (size_t)n + i] = v.z;
+  } else {
+    out[3 * (size_t)i] = v.x; out[3 * (size_t)i + 1] = v.y; out[3 * (size_t)i + 2] = v.z;
+  }
+}
+
+// scatters g_out through the same taps; accumulates into d_tex (caller zeroes)
+__global__ void __launch_bounds__(256)
+cube_texture_bwd_kernel(int res, int n, const float* __restrict__ dirs, const float* __restrict__ g_out,
+                        float* __restrict__ d_tex, int planar) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Taps t;
+  if (!cube_taps(res, dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2], t)) return;
+  const float g0 = planar ? g_out[i] : g_out[3 * (size_t)i];
+  const float g1 = planar ? g_out[(size_t)n + i] : g_out[3 * (size_t)i + 1];
+  const float g2 = planar ? g_out[2 * (size_t)n + i] : g_out[3 * (size_t)i + 2];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (t.idx[k] >= 0 && t.w[k] != 0.0f) {
+      float* p = d_tex + 3 * (size_t)t.idx[k];
+      atomicAdd(p, g0 * t.w[k]);
+      atomicAdd(p + 1, g1 * t.w[k]);
+      atomicAdd(p + 2, g2 * t.w[k]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // shade
 // ------------------------------------------------------------------------------------------
@@ -1071,6 +1109,32 @@ int gigs_cubemap_mip_bwd(int res_out, const float* dout, float* din, void* strea
   const int res = 2 * res_out;
   void* tok; gigs_internal_stage_begin(17, stream, &tok);
   hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_cube_texture_fwd(int res, const float* cubemap, int n, const float* dirs, float* out, int planar,
+                          void* stream) {
+  if (res <= 0 || n < 0 || !cubemap || (n > 0 && (!dirs || !out)))
+    return gigs_internal_fail(GIGS_ERR_INVALID, "cube_texture_fwd: bad argument");
+  if (n == 0) return 0;
+  void* tok; gigs_internal_stage_begin(16, stream, &tok);
+  hipLaunchKernelGGL(gigs::cube_texture_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, res,
+                     cubemap, n, dirs, out, planar);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_cube_texture_bwd(int res, int n, const float* dirs, const float* g_out, float* d_cubemap, int planar,
+                          void* stream) {
+  if (res <= 0 || n < 0 || !d_cubemap || (n > 0 && (!dirs || !g_out)))
+    return gigs_internal_fail(GIGS_ERR_INVALID, "cube_texture_bwd: bad argument");
+  if (n == 0) return 0;
+  void* tok; gigs_internal_stage_begin(17, stream, &tok);
+  hipLaunchKernelGGL(gigs::cube_texture_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, res, n,
+                     dirs, g_out, d_cubemap, planar);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;

@@ -209,8 +209,11 @@ l1_ssim_bwd_kernel(int H, int W, const float* __restrict__ img, const float* __r
 // weight of the (p, p+s) pair along one axis: exp(-mean_c |gt(p+s) - gt(p)|) [* mask(p+s) * mask(p)]
 __device__ __forceinline__ float tv_weight(const float* __restrict__ gt, const float* __restrict__ mask, size_t HW,
                                            size_t p, size_t q) {
-  const float d = fabsf(gt[q] - gt[p]) + fabsf(gt[HW + q] - gt[HW + p]) + fabsf(gt[2 * HW + q] - gt[2 * HW + p]);
-  float w = expf(-(d / 3.0f));
+  float w = 1.0f;  // no guide image: the plain TV of train.py:419-421
+  if (gt) {
+    const float d = fabsf(gt[q] - gt[p]) + fabsf(gt[HW + q] - gt[HW + p]) + fabsf(gt[2 * HW + q] - gt[2 * HW + p]);
+    w = expf(-(d / 3.0f));
+  }
   if (mask) w *= mask[q] * mask[p];
   return w;
 }
@@ -478,7 +481,7 @@ int gigs_l1_ssim_bwd(int channels, int height, int width, const float* image, co
 
 int gigs_tv_loss_fwd(int channels, int height, int width, int step, const float* gt, const float* prediction,
                      const float* mask_f, float* scratch, float* loss, void* stream) {
-  if (channels <= 0 || height <= 0 || width <= 0 || step < 1 || step >= height || step >= width || !gt ||
+  if (channels <= 0 || height <= 0 || width <= 0 || step < 1 || step >= height || step >= width ||
       !prediction || !scratch || !loss)
     return gigs_internal_fail(GIGS_ERR_INVALID, "tv_loss_fwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
@@ -494,7 +497,7 @@ int gigs_tv_loss_fwd(int channels, int height, int width, int step, const float*
 
 int gigs_tv_loss_bwd(int channels, int height, int width, int step, const float* gt, const float* prediction,
                      const float* mask_f, const float* g_loss, float* g_prediction, void* stream) {
-  if (channels <= 0 || height <= 0 || width <= 0 || step < 1 || step >= height || step >= width || !gt ||
+  if (channels <= 0 || height <= 0 || width <= 0 || step < 1 || step >= height || step >= width ||
       !prediction || !g_prediction)
     return gigs_internal_fail(GIGS_ERR_INVALID, "tv_loss_bwd: bad argument");
   hipStream_t s = (hipStream_t)stream;

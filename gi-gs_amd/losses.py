@@ -10,6 +10,7 @@ instead of a chain of torch ops:
     get_masked_tv_loss(mask, gt_image, prediction)       train.py:116-142
     masked_l1_loss(a, b, mask)                           train.py:327  F.l1_loss(a[:, mask], b[:, mask])
     stage1_loss(...)                                     train.py:318-331, the whole stage-1 objective
+    get_envmap_dirs(res), env_tv_loss(base, dirs)        train.py:145-157, :405-424
 
 Images are [C,H,W] fp32 on the GPU.  There is no CPU path: without libgigs_hip.so importing this module fails,
 and CPU tensors raise.
@@ -98,19 +99,22 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
 class _Tv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gt, prediction, mask_f, step):
-        gt, prediction = _chw(gt, "tv_loss"), _chw(prediction, "tv_loss")
+        prediction = _chw(prediction, "tv_loss")
+        gt = None if gt is None else _chw(gt, "tv_loss")
         C, H, W = prediction.shape
-        if gt.shape != (3, H, W):
+        if gt is not None and gt.shape != (3, H, W):
             raise ValueError("tv_loss: gt_image must be [3,H,W] matching prediction")
         if mask_f is not None:
             mask_f = mask_f.reshape(H, W).contiguous().float()
-        loss = torch.empty(1, dtype=torch.float32, device=gt.device)
-        with torch.cuda.device(gt.device):
+        dev = prediction.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
             gigs_lib.check(_lib.gigs_tv_loss_fwd(C, H, W, int(step), _p(gt), _p(prediction), _p(mask_f),
-                                                 _p(_scratch(C, H, W, gt.device)), _p(loss), _stream()), "tv_loss_fwd")
+                                                 _p(_scratch(C, H, W, dev)), _p(loss), _stream()), "tv_loss_fwd")
         ctx.step = int(step)
-        ctx.has_mask = mask_f is not None
-        ctx.save_for_backward(gt, prediction, mask_f if mask_f is not None else torch.empty(0, device=gt.device))
+        ctx.has_mask, ctx.has_gt = mask_f is not None, gt is not None
+        none = torch.empty(0, device=dev)
+        ctx.save_for_backward(gt if gt is not None else none, prediction, mask_f if mask_f is not None else none)
         return loss[0]
 
     @staticmethod
@@ -119,8 +123,8 @@ class _Tv(torch.autograd.Function):
         C, H, W = prediction.shape
         g_pred = torch.empty_like(prediction)
         g = g_loss.reshape(1).contiguous().float()
-        with torch.cuda.device(gt.device):
-            gigs_lib.check(_lib.gigs_tv_loss_bwd(C, H, W, ctx.step, _p(gt), _p(prediction),
+        with torch.cuda.device(prediction.device):
+            gigs_lib.check(_lib.gigs_tv_loss_bwd(C, H, W, ctx.step, _p(gt) if ctx.has_gt else None, _p(prediction),
                                                  _p(mask_f) if ctx.has_mask else None, _p(g), _p(g_pred), _stream()),
                            "tv_loss_bwd")
         return None, g_pred, None, None
@@ -185,3 +189,22 @@ def stage1_loss(image, gt_image, normal_map, normal_map_from_depth, normal_from_
     loss = out[0] + normal_loss_weight * normal_loss
     loss = loss + get_tv_loss(gt_image, normal_map, pad=1, step=1) * normal_tv_weight
     return loss, out[1].detach(), normal_loss
+
+
+def get_envmap_dirs(res=(512, 1024), device="cuda") -> torch.Tensor:
+    """train.py:145-157: directions of an equirectangular [H,W] panorama."""
+    import math
+    gy, gx = torch.meshgrid(torch.linspace(0.0 + 1.0 / res[0], 1.0 - 1.0 / res[0], res[0], device=device),
+                            torch.linspace(-1.0 + 1.0 / res[1], 1.0 - 1.0 / res[1], res[1], device=device),
+                            indexing="ij")
+    sintheta, costheta = torch.sin(gy * math.pi), torch.cos(gy * math.pi)
+    sinphi, cosphi = torch.sin(gx * math.pi), torch.cos(gx * math.pi)
+    return torch.stack((sintheta * sinphi, costheta, -sintheta * cosphi), dim=-1)  # [H, W, 3]
+
+
+def env_tv_loss(cubemap_base: torch.Tensor, envmap_dirs: torch.Tensor) -> torch.Tensor:
+    """train.py:405-424: TV smoothness of the panorama sampled from the light's base cubemap,
+    mean((E[1:]-E[:-1])^2) + mean((E[:,1:]-E[:,:-1])^2); two kernels forward (lookup into planes, TV), two back."""
+    from pbr.texture import cube_texture
+    env = cube_texture(cubemap_base, envmap_dirs, planar=True)  # [3, H, W]
+    return _Tv.apply(None, env, None, 1)

@@ -246,6 +246,16 @@ int gigs_stage2_loss_bwd(int height, int width, const float* render_direct, cons
                          float* d_render_direct, float* d_irr_linear, float* d_roughness, float* d_metallic,
                          void* stream);
 
+/* dr.texture(cubemap[None], dirs[None], filter_mode="linear", boundary_mode="cube") (train.py:409-417, render.py:80,
+ * relight.py:108) for n directions [n,3], sampled as the shade kernel samples light.diffuse (face by largest |axis|,
+ * bilinear taps, taps beyond an edge come from the neighbouring face, the missing corner tap is dropped; the rule
+ * documented at gigs_shade_fwd): out is [n,3], or three planes [3,n] if planar.
+ * The backward accumulates into d_cubemap [6,res,res,3] (caller zeroes); directions get no gradient. */
+int gigs_cube_texture_fwd(int res, const float* cubemap, int n, const float* dirs, float* out, int planar,
+                          void* stream);
+int gigs_cube_texture_bwd(int res, int n, const float* dirs, const float* g_out, float* d_cubemap, int planar,
+                          void* stream);
+
 /* Training-loop glue (gigs-hip extension): the image losses of train.py and the Adam step, one
  * pass each.  Planes are [C,H,W] fp32; `scratch` holds at least gigs_loss_scratch_floats(C,H,W) floats (per-workgroup
  * partial sums, added in a fixed order -> reproducible losses); g_loss is a device scalar (NULL = 1).
@@ -254,7 +264,8 @@ int gigs_stage2_loss_bwd(int height, int width, const float* render_direct, cons
  *   sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2.  d_mu1/d_e11/d_e12 [C,H,W] (all or none) receive the
  *   per-pixel derivatives of ssim_map that gigs_l1_ssim_bwd spreads back through the window into g_image.
  * gigs_tv_loss_fwd/bwd = get_tv_loss(gt, prediction, pad=1, step) (train.py:83-113) or, with mask_f [H,W] != NULL,
- *   get_masked_tv_loss without erosion (train.py:116-142); gt is [3,H,W], prediction [C,H,W]; gradient to prediction.
+ *   get_masked_tv_loss without erosion (train.py:116-142); gt is [3,H,W] (NULL = no guide image, all pair weights 1:
+ *   the plain TV of train.py:419-421), prediction [C,H,W]; gradient to prediction.
  * gigs_masked_l1_fwd/bwd = F.l1_loss(a[:, mask], b[:, mask]) (train.py:327), mask u8 [H,W];
  *   loss_count = {loss, number of mask pixels}; g_a / g_b may each be NULL (g_b = -g_a).
  * gigs_adam_step = torch.optim.Adam(eps=..., betas=...) without weight decay / amsgrad, as the reference configures it

@@ -91,3 +91,19 @@ def adam_ref(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-15):
     bc2 = 1.0 - beta2 ** step
     denom = v.sqrt() / math.sqrt(bc2) + eps
     return p - (lr / bc1) * (m / denom), m, v
+
+
+def envmap_dirs_ref(res=(512, 1024)):
+    """train.py:145-157."""
+    gy, gx = torch.meshgrid(torch.linspace(0.0 + 1.0 / res[0], 1.0 - 1.0 / res[0], res[0]),
+                            torch.linspace(-1.0 + 1.0 / res[1], 1.0 - 1.0 / res[1], res[1]), indexing="ij")
+    st, ct = torch.sin(gy * math.pi), torch.cos(gy * math.pi)
+    sp, cp = torch.sin(gx * math.pi), torch.cos(gx * math.pi)
+    return torch.stack((st * sp, ct, -st * cp), dim=-1)
+
+
+def env_tv_ref(base, dirs):
+    """train.py:405-424 with the cube lookup of oracle/torch_pbr_ref.py (nvdiffrast: parity unpinned)."""
+    from oracle import torch_pbr_ref as pr
+    env = pr.cube_sample(base.to(pr.DT), dirs.to(pr.DT))  # [H, W, 3]
+    return ((env[1:] - env[:-1]) ** 2).mean() + ((env[:, 1:] - env[:, :-1]) ** 2).mean()

@@ -208,3 +208,44 @@ def test_fused_adam_state_survives_densification_style_edits():
         o.step()
     a, b = opt.param_groups[0]["params"][0].detach().cpu(), ref.param_groups[0]["params"][0].detach()
     assert a.shape == (107, 3) and (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
+
+
+def test_cube_texture_matches_restated_lookup():
+    from oracle import torch_pbr_ref as pr
+    from pbr.texture import cube_texture
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    base = torch.rand(6, 16, 16, 3, generator=g)
+    d = torch.randn(4000, 3, generator=g)
+    d[:64] = torch.tensor([1.0, 1.0, 1.0]) * torch.sign(torch.randn(64, 3, generator=g))  # cube corners
+    d[64:128, 2] = d[64:128, 0].abs()  # face edges
+    br = base.to(pr.DT).requires_grad_(True)
+    want = pr.cube_sample(br, d.to(pr.DT))
+    w = torch.randn(4000, 3, generator=g)
+    (want * w.to(pr.DT)).sum().backward()
+    b = base.to(dev).requires_grad_(True)
+    got = cube_texture(b, d.to(dev))
+    (got * w.to(dev)).sum().backward()
+    assert (got.detach().cpu().double() - want.detach()).abs().max().item() < 2e-6
+    assert (b.grad.cpu().double() - br.grad).abs().max().item() < 1e-4 * br.grad.abs().max().item()
+    planes = cube_texture(base.to(dev), d.to(dev).reshape(40, 100, 3), planar=True)
+    assert planes.shape == (3, 40, 100) and torch.equal(planes.permute(1, 2, 0).reshape(4000, 3), got.detach())
+
+
+def test_env_tv_loss_matches_restatement():
+    import losses
+    from oracle import train_glue_ref as ref
+    dev = _dev()
+    g = torch.Generator().manual_seed(22)
+    base = (0.5 + 0.25 * torch.randn(6, 32, 32, 3, generator=g)).abs()
+    dirs = ref.envmap_dirs_ref((64, 128))
+    got_dirs = losses.get_envmap_dirs((64, 128), device=dev)
+    assert (got_dirs.cpu() - dirs).abs().max().item() < 1e-6
+    br = base.double().requires_grad_(True)
+    want = ref.env_tv_ref(br, dirs)
+    want.backward()
+    b = base.to(dev).requires_grad_(True)
+    got = losses.env_tv_loss(b, dirs.to(dev))
+    got.backward()
+    assert abs(got.item() - want.item()) <= 2e-5 * abs(want.item())
+    assert (b.grad.cpu().double() - br.grad).abs().max().item() <= 1e-4 * br.grad.abs().max().item()
