@@ -210,7 +210,10 @@ class Stage2Step:
         self.loss_fn = graphed(self.loss_fn, clone(loss_args))
         self._captured = True
 
-    def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], gt_image: torch.Tensor, view_dirs: torch.Tensor):
+    def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], gt_image: torch.Tensor, view_dirs: torch.Tensor,
+                 extra_loss=None):
+        """extra_loss(normal_map, albedo_map, roughness_map, metallic_map) -> scalar added to the loss before
+        backward (the BRDF / envmap regularisers of train.py:387-420; see gi-gs_amd/losses.py)."""
         dev = g["means3D"].device
         background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
         if self.fused:
@@ -239,7 +242,8 @@ class Stage2Step:
         gi = self.gi
         if self.fused:
             return self._fused_step(cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view,
-                                    albedo_map, roughness_map, metallic_map, occlusion_map, depth_pos, lights)
+                                    albedo_map, roughness_map, metallic_map, occlusion_map, depth_pos, lights,
+                                    extra_loss)
         front_args = (normal_map_from_depth, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
                       occlusion_map.detach(), st.viewmatrix, view_dirs)
         if self.graphs and not self._captured:
@@ -254,6 +258,8 @@ class Stage2Step:
                            gi["step"], gi["start"])
         (IRR, _) = ssr(onv, depth_pos.detach(), linear_rgb, albedo_map, roughness_f, metallic_f, F0)
         loss, render_rgb = self.loss_fn(render_direct, IRR, gt_image, normal_mask_f, roughness_f, metallic_f)
+        if extra_loss is not None:
+            loss = loss + extra_loss(normal_map, albedo_map, roughness_map, metallic_map)
         loss.backward()
         return dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct.detach(),
                     IRR=IRR.detach(), viewspace_points=screenspace_points, radii=radii)
@@ -292,7 +298,7 @@ def _fused_begin(self):
 
 
 def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view, albedo_map,
-                roughness_map, metallic_map, occlusion_map, depth_pos, lights):
+                roughness_map, metallic_map, occlusion_map, depth_pos, lights, extra_loss=None):
     """fused=True: everything after the rasterizer is stage2_fused._Stage2Fused (7 kernels instead of ~250)."""
     from stage2_fused import Stage2FusedBack
     H, W = cam["image_height"], cam["image_width"]
@@ -313,6 +319,8 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
                            else a.detach().clone().requires_grad_(a.requires_grad) for a in args)
             self.back = graphed(self.back, sample)
     loss, render_rgb, render_direct, IRR = self.back(*args)
+    if extra_loss is not None:
+        loss = loss + extra_loss(normal_map, albedo_map, roughness_map, metallic_map)
     loss.backward()
     return dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct, IRR=IRR,
                 viewspace_points=screenspace_points, radii=radii)
