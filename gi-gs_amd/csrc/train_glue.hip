@@ -407,6 +407,64 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
   }
 }
 
+// ---- densification bookkeeping ----------------------------------------------------------
+// train.py:494-498 + GaussianModel.add_densification_stats (scene/gaussian_model.py:933-945) for the Gaussians with
+// radii > 0, one pass instead of ~20 masked torch ops per iteration:
+//   max_radii2D = max(max_radii2D, radii);  accum += |(gx, gy)|;  accum_abs += |gx| + |gy|;
+//   accum_abs_max = max(accum_abs_max, |gx| + |gy|);  denom += 1
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(int P, const float* __restrict__ grad2d, const int* __restrict__ radii, float* __restrict__ accum,
+                     float* __restrict__ accum_abs, float* __restrict__ accum_abs_max, float* __restrict__ denom,
+                     float* __restrict__ max_radii2D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const int r = radii[i];
+  if (r <= 0) return;
+  const float gx = grad2d[3 * (size_t)i], gy = grad2d[3 * (size_t)i + 1];
+  const float a = fabsf(gx) + fabsf(gy);
+  max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+  accum[i] += sqrtf(gx * gx + gy * gy);
+  accum_abs[i] += a;
+  accum_abs_max[i] = fmaxf(accum_abs_max[i], a);
+  denom[i] += 1.0f;
+}
+
+// Row gather over many tensors at once: dst_t[r, :] = zero_row[r] && t.zero_new ? 0 : src_t[src_index[r], :].
+// One launch rebuilds every parameter and optimizer-state tensor after a densify / prune decision
+// (the reference: ~30 boolean-mask index ops and cats, scene/gaussian_model.py:595-706).
+constexpr int kGatherMaxTensors = 32;
+constexpr int kGatherChunk = 1024;
+struct GatherTable {
+  const float* src[kGatherMaxTensors];
+  float* dst[kGatherMaxTensors];
+  int row_floats[kGatherMaxTensors];
+  int zero_new[kGatherMaxTensors];
+  unsigned first_chunk[kGatherMaxTensors + 1];
+  int count;
+};
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(GatherTable T, long long n_rows, const int* __restrict__ src_index,
+                   const uint8_t* __restrict__ zero_row) {
+  int t = 0;
+  while (t + 1 < T.count && blockIdx.x >= T.first_chunk[t + 1]) t++;
+  const int rf = T.row_floats[t];
+  const long long total = n_rows * rf;
+  const long long base = (long long)(blockIdx.x - T.first_chunk[t]) * kGatherChunk;
+  const float* __restrict__ src = T.src[t];
+  float* __restrict__ dst = T.dst[t];
+  const bool zn = T.zero_new[t] != 0 && zero_row != nullptr;
+#pragma unroll
+  for (int k = 0; k < kGatherChunk / 256; k++) {
+    const long long e = base + k * 256 + threadIdx.x;
+    if (e >= total) break;
+    const long long r = e / rf;
+    const int c = (int)(e - r * rf);
+    float v = 0.0f;
+    if (!(zn && zero_row[r])) v = src[(long long)src_index[r] * rf + c];
+    dst[e] = v;
+  }
+}
+
 static SsimWindow make_window() {
   // loss_utils.py:42-46: exp() in double per tap, stored as fp32, divided by the fp32 sum (sigma 1.5)
   SsimWindow w;
@@ -583,6 +641,64 @@ int gigs_adam_step(int n_groups, const gigs_adam_group* groups, double beta1, do
   }
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "adam_step: launch failed");
+  return 0;
+}
+
+int gigs_densify_stats(int P, const float* viewspace_grad, const int* radii, float* xyz_gradient_accum,
+                       float* xyz_gradient_accum_abs, float* xyz_gradient_accum_abs_max, float* denom,
+                       float* max_radii2D, void* stream) {
+  if (P < 0 || (P > 0 && (!viewspace_grad || !radii || !xyz_gradient_accum || !xyz_gradient_accum_abs ||
+                          !xyz_gradient_accum_abs_max || !denom || !max_radii2D)))
+    return gigs_internal_fail(GIGS_ERR_INVALID, "densify_stats: bad argument");
+  if (P == 0) return 0;
+  void* tok; gigs_internal_stage_begin(27, stream, &tok);
+  hipLaunchKernelGGL(gigs::densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P,
+                     viewspace_grad, radii, xyz_gradient_accum, xyz_gradient_accum_abs, xyz_gradient_accum_abs_max,
+                     denom, max_radii2D);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "densify_stats: launch failed");
+  return 0;
+}
+
+int gigs_gather_rows(int n_tensors, const gigs_gather_tensor* tensors, long long n_rows_out, long long n_rows_in,
+                     const int* src_index, const uint8_t* zero_row, void* stream) {
+  if (n_tensors < 0 || n_rows_out < 0 || n_rows_in < 0 || (n_tensors > 0 && !tensors) || (n_rows_out > 0 && !src_index))
+    return gigs_internal_fail(GIGS_ERR_INVALID, "gather_rows: bad argument");
+  if (n_rows_out == 0 || n_tensors == 0) return 0;
+  void* tok; gigs_internal_stage_begin(28, stream, &tok);
+  int done = 0;
+  while (done < n_tensors) {
+    gigs::GatherTable T;
+    memset(&T, 0, sizeof(T));
+    unsigned chunks = 0;
+    int k = 0;
+    for (; done < n_tensors && k < gigs::kGatherMaxTensors; done++) {
+      const gigs_gather_tensor& g = tensors[done];
+      if (g.row_floats <= 0 || !g.dst || (n_rows_in > 0 && !g.src)) {
+        gigs_internal_stage_end(tok);
+        return gigs_internal_fail(GIGS_ERR_INVALID, "gather_rows: bad tensor");
+      }
+      const unsigned long long c =
+          (unsigned long long)((n_rows_out * g.row_floats + gigs::kGatherChunk - 1) / gigs::kGatherChunk);
+      if (chunks + c > 0x7fffffffull) {
+        if (k == 0) {
+          gigs_internal_stage_end(tok);
+          return gigs_internal_fail(GIGS_ERR_INVALID, "gather_rows: tensor too large");
+        }
+        break;
+      }
+      T.src[k] = g.src; T.dst[k] = g.dst; T.row_floats[k] = g.row_floats; T.zero_new[k] = g.zero_new;
+      T.first_chunk[k] = chunks;
+      chunks += (unsigned)c;
+      k++;
+    }
+    T.count = k;
+    T.first_chunk[k] = chunks;
+    hipLaunchKernelGGL(gigs::gather_rows_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, T, n_rows_out,
+                       src_index, zero_row);
+  }
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "gather_rows: launch failed");
   return 0;
 }
 

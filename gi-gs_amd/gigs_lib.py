@@ -82,6 +82,8 @@ SIGNATURES = {
     "gigs_masked_l1_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_masked_l1_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_adam_step": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, C.c_void_p]),
+    "gigs_densify_stats": (_i, [_i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_gather_rows": (_i, [_i, C.c_void_p, C.c_longlong, C.c_longlong, _f, _f, C.c_void_p]),
     "gigs_geom_offset": (C.c_longlong, [_i, _i]),
     "gigs_binning_offset": (C.c_longlong, [_i, _i]),
     "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),
@@ -105,6 +107,11 @@ class AdamGroup(C.Structure):
     """gigs_adam_group of include/gigs_hip.h."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_longlong), ("lr", C.c_double), ("step", C.c_int)]
+
+
+class GatherTensor(C.Structure):
+    """gigs_gather_tensor of include/gigs_hip.h."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_floats", C.c_int), ("zero_new", C.c_int)]
 
 
 _lib = None

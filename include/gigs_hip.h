@@ -297,6 +297,27 @@ int gigs_masked_l1_bwd(int channels, int height, int width, const float* a, cons
 int gigs_adam_step(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
                    void* stream);
 
+/* Densification bookkeeping (gigs-hip extension).
+ * gigs_densify_stats = train.py:494-498 + GaussianModel.add_densification_stats (scene/gaussian_model.py:933-945) in one
+ *   pass over the P Gaussians, for those with radii > 0: max_radii2D = max(., radii); xyz_gradient_accum += |(gx,gy)|;
+ *   xyz_gradient_accum_abs += |gx|+|gy|; xyz_gradient_accum_abs_max = max(., |gx|+|gy|); denom += 1.
+ *   viewspace_grad is means2D.grad [P,3]; the five statistics are fp32 [P].
+ * gigs_gather_rows rebuilds any number of row-major fp32 tensors after a densify / prune decision in one launch
+ *   (replaces the per-tensor boolean-mask indexing and torch.cat of scene/gaussian_model.py:595-706):
+ *   dst_t[r, :] = (zero_row && zero_row[r] && t.zero_new) ? 0 : src_t[src_index[r], :] for r < n_rows_out;
+ *   src_index values must lie in [0, n_rows_in) (checked by the host side, not by the kernel). */
+typedef struct gigs_gather_tensor {
+  const float* src;
+  float* dst;
+  int row_floats; /* floats per row */
+  int zero_new;   /* 1: rows flagged in zero_row become zero (optimizer moments of new Gaussians) */
+} gigs_gather_tensor;
+int gigs_densify_stats(int P, const float* viewspace_grad, const int* radii, float* xyz_gradient_accum,
+                       float* xyz_gradient_accum_abs, float* xyz_gradient_accum_abs_max, float* denom,
+                       float* max_radii2D, void* stream);
+int gigs_gather_rows(int n_tensors, const gigs_gather_tensor* tensors, long long n_rows_out, long long n_rows_in,
+                     const int* src_index, const uint8_t* zero_row, void* stream);
+
 /* Test/diagnostic views into the opaque scratch buffers (byte offsets from the buffer
  * start, or -1).  `which`: geometry 0 depths f32[P], 1 pos_view f32[3P], 2 means2D f32[2P],
  * 3 cov3D f32[6P], 4 conic_opacity f32[4P], 5 rgb f32[3P], 6 clamped u8[3P],
