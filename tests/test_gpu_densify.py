@@ -151,3 +151,38 @@ def test_prune_points_and_reset_opacity():
     assert torch.allclose(o.detach().cpu(), m2["params"]["opacity"], rtol=1e-6, atol=1e-6)
     assert float(opt.state[o]["exp_avg"].abs().sum()) == 0.0 and float(opt.state[o]["exp_avg_sq"].abs().sum()) == 0.0
     assert float(torch.sigmoid(o.detach()).max()) <= 0.01 + 1e-6
+
+
+def test_checkpoint_resumes_into_fused_adam(tmp_path):
+    """chkpntN.pth written from a torch.optim.Adam run (the reference's optimizer) continues under FusedAdam."""
+    import os
+    import types
+    import optim
+    import scene_io
+    dev = _dev()
+    model, g = _model(257, 3)
+    p = {n: torch.nn.Parameter(model["params"][n].clone()) for n in NAMES}
+    ref_opt = torch.optim.Adam([{"params": [p[n]], "lr": 1e-3 * (i + 1), "name": n} for i, n in enumerate(NAMES)], lr=0.0,
+                               eps=1e-15)
+    grads = [{n: torch.randn(p[n].shape, generator=g) for n in NAMES} for _ in range(3)]
+    for k in range(2):
+        for n in NAMES:
+            p[n].grad = grads[k][n].clone()
+        ref_opt.step()
+    stats = types.SimpleNamespace(max_radii2D=torch.zeros(257), xyz_gradient_accum=torch.zeros(257, 1),
+                                  xyz_gradient_accum_abs=torch.zeros(257, 1), xyz_gradient_accum_abs_max=torch.zeros(257, 1),
+                                  denom=torch.zeros(257, 1))
+    path = os.path.join(tmp_path, "chkpnt2.pth")
+    scene_io.save_checkpoint(path, scene_io.capture(2, p, stats, ref_opt, 1.0), {}, {}, 2)
+    _, params, _, opt_dict, _ = scene_io.restore(scene_io.load_checkpoint(path)["gaussians"])
+    q = {n: torch.nn.Parameter(params[n].to(dev)) for n in NAMES}
+    opt = optim.FusedAdam([{"params": [q[n]], "lr": 0.0, "name": n} for n in NAMES], lr=0.0, eps=1e-15)
+    opt.load_state_dict(opt_dict)
+    for n in NAMES:
+        p[n].grad = grads[2][n].clone()
+        q[n].grad = grads[2][n].clone().to(dev)
+    ref_opt.step()
+    opt.step()
+    for n in NAMES:
+        assert int(opt.state[q[n]]["step"]) == 3
+        assert (q[n].detach().cpu() - p[n].detach()).abs().max().item() <= 2e-6 * p[n].detach().abs().max().item(), n
