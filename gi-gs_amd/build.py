@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.environ.get("GIGS_OBJ", os.path.join(HERE, "build"))
 LIB = os.environ.get("GIGS_LIB", os.path.join(HERE, "libgigs_hip.so"))
-SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "blend.hip", "gi.hip", "pbr.hip", "stage2.hip", "train_glue.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "blend.hip", "gi.hip", "pbr.hip", "stage2.hip", "train_glue.hip", "knn.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",

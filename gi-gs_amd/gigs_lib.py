@@ -84,6 +84,8 @@ SIGNATURES = {
     "gigs_adam_step": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, C.c_void_p]),
     "gigs_densify_stats": (_i, [_i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_gather_rows": (_i, [_i, C.c_void_p, C.c_longlong, C.c_longlong, _f, _f, C.c_void_p]),
+    "gigs_dist2_scratch_bytes": (C.c_size_t, [_i]),
+    "gigs_dist2": (_i, [_i, _f, _f, _f, C.c_size_t, C.c_void_p]),
     "gigs_geom_offset": (C.c_longlong, [_i, _i]),
     "gigs_binning_offset": (C.c_longlong, [_i, _i]),
     "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),

@@ -318,6 +318,13 @@ int gigs_densify_stats(int P, const float* viewspace_grad, const int* radii, flo
 int gigs_gather_rows(int n_tensors, const gigs_gather_tensor* tensors, long long n_rows_out, long long n_rows_in,
                      const int* src_index, const uint8_t* zero_row, void* stream);
 
+/* simple-knn's distCUDA2 (submodules/simple-knn/simple_knn.cu:165-224, ext.cpp / spatial.cu):
+ * mean_dists[i] = mean of the squared distances from points[i] to its three nearest other points (by index: duplicates
+ * count, at distance 0); with fewer than four points the reference's FLT_MAX placeholders stay in the sum (> 1e38 or +inf).  points [P,3] fp32.
+ * scratch: gigs_dist2_scratch_bytes(P) bytes of device memory.  No host read-back; everything is queued on `stream`. */
+size_t gigs_dist2_scratch_bytes(int P);
+int gigs_dist2(int P, const float* points, float* mean_dists, void* scratch, size_t scratch_bytes, void* stream);
+
 /* Test/diagnostic views into the opaque scratch buffers (byte offsets from the buffer
  * start, or -1).  `which`: geometry 0 depths f32[P], 1 pos_view f32[3P], 2 means2D f32[2P],
  * 3 cov3D f32[6P], 4 conic_opacity f32[4P], 5 rgb f32[3P], 6 clamped u8[3P],
