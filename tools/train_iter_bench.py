@@ -13,6 +13,7 @@ logging are outside all three.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -131,7 +132,51 @@ def main():
         dt = (time.perf_counter() - t0) / a.steps
         return {"ms_per_iteration": round(dt * 1e3, 3), "iterations_per_s": round(1.0 / dt, 1)}
 
+    def run_stage1(hip):
+        """train.py:318-331 + :517-518: render -> L1 + D-SSIM + masked normal L1 + normal TV -> backward -> Adam."""
+        r = raw_params()
+        Opt = optim.FusedAdam if hip else torch.optim.Adam
+        opt = Opt([{"params": [r[k]], "lr": lrs[k], "name": k} for k in lrs], lr=0.0, eps=1e-15)
+        bg = torch.zeros(3, device=dev)
+        taps = torch.tensor([math.exp(-((i - 5) ** 2) / 4.5) for i in range(11)])
+        taps = taps / taps.sum()
+        win = torch.outer(taps, taps)[None, None].expand(3, 1, 11, 11).contiguous().to(dev)
+
+        def torch_ssim(x, y):
+            blur = lambda t: F.conv2d(t[None], win, padding=5, groups=3)[0]  # noqa: E731
+            mx, my = blur(x), blur(y)
+            vx, vy, cxy = blur(x * x) - mx * mx, blur(y * y) - my * my, blur(x * y) - mx * my
+            return (((2 * mx * my + 1e-4) * (2 * cxy + 9e-4)) / ((mx * mx + my * my + 1e-4) * (vx + vy + 9e-4))).mean()
+
+        def it(i):
+            res = pipeline.render(cams_t[i % n_views], activate(r), a.sh_degree, bg, gi)
+            image, nm, nfd, mask = res["render"], res["normal_map"], res["normal_map_from_depth"], res["normal_from_depth_mask"]
+            if hip:
+                loss, _, _ = losses.stage1_loss(image, gt_image, nm, nfd, mask, 0.2)
+            else:
+                loss = 0.8 * (image - gt_image).abs().mean() + 0.2 * (1.0 - torch_ssim(image, gt_image))
+                loss = loss + F.l1_loss(nm[:, mask], nfd[:, mask])
+                wh = torch.exp(-(gt_image[:, 1:, :] - gt_image[:, :-1, :]).abs().mean(dim=0, keepdim=True))
+                ww = torch.exp(-(gt_image[:, :, 1:] - gt_image[:, :, :-1]).abs().mean(dim=0, keepdim=True))
+                loss = loss + (torch.pow(nm[:, 1:, :] - nm[:, :-1, :], 2) * wh).mean() + (
+                    torch.pow(nm[:, :, 1:] - nm[:, :, :-1], 2) * ww).mean()
+            loss.backward()
+            opt.step()
+            for p in r.values():
+                p.grad = None
+        for i in range(a.warmup):
+            it(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            it(a.warmup + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        return {"ms_per_iteration": round(dt * 1e3, 3), "iterations_per_s": round(1.0 / dt, 1)}
+
     out = {"workload": f"C2 P={a.gaussians} {a.res}x{a.res} sh{a.sh_degree} start=8", "steps": a.steps}
+    out["stage1_full_iteration_hip_glue"] = run_stage1(True)
+    out["stage1_full_iteration_torch_glue"] = run_stage1(False)
     out["metric_step_no_optimizer"] = run("metric")
     out["full_iteration_hip_glue"] = run("hip")
     out["full_iteration_torch_glue"] = run("torch")
