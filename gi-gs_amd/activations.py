@@ -1,0 +1,69 @@
+"""The parameter getters of the reference's GaussianModel (scene/gaussian_model.py:48-58, 178-263) as one kernel
+forward and one backward (gigs_activate_fwd / _bwd) instead of eight getters' worth of torch ops per iteration.
+
+    g = activate(raw)     raw: {"xyz", "f_dc", "f_rest", "opacity", "normal", "albedo", "roughness", "metallic",
+                                "scaling", "rotation"} (the optimizer's tensors)
+                          g:   {"means3D", "shs", "opacities", "normal", "albedo", "roughness", "metallic", "scales",
+                                "rotations"} (what GaussianRasterizer takes, gaussian_renderer/__init__.py:66-155)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict
+
+import torch
+
+import gigs_lib
+
+_lib = gigs_lib.lib()
+
+RAW = ("f_dc", "f_rest", "opacity", "normal", "albedo", "roughness", "metallic", "scaling", "rotation")
+OUT = ("shs", "opacities", "normal", "albedo", "roughness", "metallic", "scales", "rotations")
+_OUT_OF = dict(opacities="opacity", normal="normal", albedo="albedo", roughness="roughness", metallic="metallic",
+               scales="scaling", rotations="rotation")
+
+
+class _Activate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *raw):
+        if not raw[0].is_cuda:
+            raise RuntimeError("activate needs CUDA/HIP tensors: gigs-hip has no CPU path")
+        raw = tuple(t.contiguous().float() for t in raw)
+        r = dict(zip(RAW, raw))
+        P = int(r["f_dc"].shape[0])
+        K = 1 + int(r["f_rest"].shape[1])
+        if r["f_dc"].shape != (P, 1, 3) or r["f_rest"].shape != (P, K - 1, 3) or r["rotation"].shape != (P, 4):
+            raise ValueError("activate: unexpected parameter shapes")
+        dev = raw[0].device
+        out = {"shs": torch.empty((P, K, 3), dtype=torch.float32, device=dev)}
+        for o, src in _OUT_OF.items():
+            out[o] = torch.empty_like(r[src])
+        a = gigs_lib.ActivationRaw(*[r[n].data_ptr() for n in RAW])
+        b = gigs_lib.ActivationOut(*[out[n].data_ptr() for n in OUT])
+        with torch.cuda.device(dev):
+            gigs_lib.check(_lib.gigs_activate_fwd(P, K, C.addressof(a), C.addressof(b),
+                                                  torch.cuda.current_stream().cuda_stream), "activate_fwd")
+        ctx.save_for_backward(*raw)
+        ctx.P, ctx.K = P, K
+        return tuple(out[n] for n in OUT)
+
+    @staticmethod
+    def backward(ctx, *g_out):
+        raw = ctx.saved_tensors
+        dev = raw[0].device
+        g = [None if t is None else t.contiguous().float() for t in g_out]
+        d = [torch.empty_like(t) for t in raw]
+        a = gigs_lib.ActivationRaw(*[t.data_ptr() for t in raw])
+        b = gigs_lib.ActivationOut(*[None if t is None else t.data_ptr() for t in g])
+        c = gigs_lib.ActivationRaw(*[t.data_ptr() for t in d])
+        with torch.cuda.device(dev):
+            gigs_lib.check(_lib.gigs_activate_bwd(ctx.P, ctx.K, C.addressof(a), C.addressof(b), C.addressof(c),
+                                                  torch.cuda.current_stream().cuda_stream), "activate_bwd")
+        return tuple(d)
+
+
+def activate(raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    out = _Activate.apply(*[raw[n] for n in RAW])
+    g = dict(zip(OUT, out))
+    g["means3D"] = raw["xyz"]
+    return g

@@ -89,14 +89,14 @@ enum Stage {
   kPreprocess = 0, kScan, kDuplicate, kSort, kRanges, kBlendFwd, kBlendBwd, kPreprocessBwd,
   kDepthToNormal, kSsao, kSsr, kMedian, kBilateral, kMedianBwd, kShadeFwd, kShadeBwd,
   kCubemapFwd, kCubemapBwd, kGbufferPost, kLossFwd, kLossBwd, kL1SsimFwd, kL1SsimBwd, kTvFwd, kTvBwd,
-  kMaskedL1, kAdam, kDensifyStats, kGatherRows, kDist2, kNumStages
+  kMaskedL1, kAdam, kDensifyStats, kGatherRows, kDist2, kActivateFwd, kActivateBwd, kNumStages
 };
 const char* kStageNames[kNumStages] = {
   "preprocess_fwd", "scan", "duplicate", "sort", "tile_ranges", "blend_fwd", "blend_bwd",
   "preprocess_bwd", "depth_to_normal", "ssao", "ssr", "median3x3", "bilateral3x3",
   "median3x3_bwd", "shade_fwd", "shade_bwd", "cubemap_fwd", "cubemap_bwd", "gbuffer_post",
   "stage2_loss_fwd", "stage2_loss_bwd", "l1_ssim_fwd", "l1_ssim_bwd", "tv_loss_fwd", "tv_loss_bwd", "masked_l1",
-  "adam_step", "densify_stats", "gather_rows", "dist2"};
+  "adam_step", "densify_stats", "gather_rows", "dist2", "activate_fwd", "activate_bwd"};
 
 // optional event recorded on the forward's stream right before the blend kernel is launched (gigs_set_blend_begin_event)
 std::atomic<void*> g_blend_begin_event{nullptr};

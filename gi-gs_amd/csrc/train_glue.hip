@@ -407,6 +407,99 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
   }
 }
 
+// ---- parameter activations (scene/gaussian_model.py:48-58, 178-263) ------------------------------------------
+// get_features = cat(f_dc, f_rest), get_opacity / albedo / roughness / metallic = sigmoid, get_scaling = exp,
+// get_rotation / get_normal = F.normalize(dim=-1, eps=1e-12): eight getters, ~10 torch kernels forward and ~20 backward
+// per iteration; here one pass each way.  Lane i handles SH float i of the concatenation and, for i < P, the sixteen
+// small attributes of Gaussian i.
+struct ActPtrs {
+  const float *f_dc, *f_rest, *opacity, *normal, *albedo, *roughness, *metallic, *scaling, *rotation;  // raw
+  float *shs, *o_opacity, *o_normal, *o_albedo, *o_roughness, *o_metallic, *o_scales, *o_rotations;    // fwd outputs
+  const float *g_shs, *g_opacity, *g_normal, *g_albedo, *g_roughness, *g_metallic, *g_scales, *g_rotations;  // bwd inputs
+  float *d_f_dc, *d_f_rest, *d_opacity, *d_normal, *d_albedo, *d_roughness, *d_metallic, *d_scaling, *d_rotation;
+};
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int N>
+__device__ __forceinline__ void normalize_fwd(const float* __restrict__ v, float* __restrict__ o) {
+  float n2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < N; k++) n2 += v[k] * v[k];
+  const float d = fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+  for (int k = 0; k < N; k++) o[k] = v[k] / d;
+}
+// d/dv of v / max(|v|, eps): below eps the denominator is the constant eps
+template <int N>
+__device__ __forceinline__ void normalize_bwd(const float* __restrict__ v, const float* __restrict__ g,
+                                              float* __restrict__ d) {
+  float n2 = 0.0f, vg = 0.0f;
+#pragma unroll
+  for (int k = 0; k < N; k++) { n2 += v[k] * v[k]; vg += v[k] * g[k]; }
+  const float n = sqrtf(n2);
+  if (n > 1e-12f) {
+    const float s = vg / (n2 * n);
+#pragma unroll
+    for (int k = 0; k < N; k++) d[k] = g[k] / n - v[k] * s;
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; k++) d[k] = g[k] / 1e-12f;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+activate_fwd_kernel(int P, int K, ActPtrs A) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int row_f = 3 * K;
+  if (i < (long long)P * row_f) {
+    const long long r = i / row_f;
+    const int c = (int)(i - r * row_f);
+    A.shs[i] = c < 3 ? A.f_dc[3 * r + c] : A.f_rest[r * (row_f - 3) + (c - 3)];
+  }
+  if (i >= P) return;
+  A.o_opacity[i] = sigmoidf(A.opacity[i]);
+  A.o_roughness[i] = sigmoidf(A.roughness[i]);
+  A.o_metallic[i] = sigmoidf(A.metallic[i]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    A.o_albedo[3 * i + k] = sigmoidf(A.albedo[3 * i + k]);
+    A.o_scales[3 * i + k] = expf(A.scaling[3 * i + k]);
+  }
+  normalize_fwd<3>(A.normal + 3 * i, A.o_normal + 3 * i);
+  normalize_fwd<4>(A.rotation + 4 * i, A.o_rotations + 4 * i);
+}
+
+__global__ void __launch_bounds__(256)
+activate_bwd_kernel(int P, int K, ActPtrs A) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int row_f = 3 * K;
+  if (i < (long long)P * row_f) {
+    const long long r = i / row_f;
+    const int c = (int)(i - r * row_f);
+    const float g = A.g_shs ? A.g_shs[i] : 0.0f;
+    if (c < 3) A.d_f_dc[3 * r + c] = g;
+    else A.d_f_rest[r * (row_f - 3) + (c - 3)] = g;
+  }
+  if (i >= P) return;
+  {
+    const float s = sigmoidf(A.opacity[i]);
+    A.d_opacity[i] = A.g_opacity ? A.g_opacity[i] * (s * (1.0f - s)) : 0.0f;
+    const float r = sigmoidf(A.roughness[i]);
+    A.d_roughness[i] = A.g_roughness ? A.g_roughness[i] * (r * (1.0f - r)) : 0.0f;
+    const float m = sigmoidf(A.metallic[i]);
+    A.d_metallic[i] = A.g_metallic ? A.g_metallic[i] * (m * (1.0f - m)) : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float a = sigmoidf(A.albedo[3 * i + k]);
+    A.d_albedo[3 * i + k] = A.g_albedo ? A.g_albedo[3 * i + k] * (a * (1.0f - a)) : 0.0f;
+    A.d_scaling[3 * i + k] = A.g_scales ? A.g_scales[3 * i + k] * expf(A.scaling[3 * i + k]) : 0.0f;
+  }
+  const float z4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  normalize_bwd<3>(A.normal + 3 * i, A.g_normal ? A.g_normal + 3 * i : z4, A.d_normal + 3 * i);
+  normalize_bwd<4>(A.rotation + 4 * i, A.g_rotations ? A.g_rotations + 4 * i : z4, A.d_rotation + 4 * i);
+}
+
 // ---- densification bookkeeping ----------------------------------------------------------
 // train.py:494-498 + GaussianModel.add_densification_stats (scene/gaussian_model.py:933-945) for the Gaussians with
 // radii > 0, one pass instead of ~20 masked torch ops per iteration:
@@ -699,6 +792,58 @@ int gigs_gather_rows(int n_tensors, const gigs_gather_tensor* tensors, long long
   }
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "gather_rows: launch failed");
+  return 0;
+}
+
+static bool act_raw_ok(const gigs_activation_raw* r, int K) {
+  return r && r->f_dc && (K == 1 || r->f_rest) && r->opacity && r->normal && r->albedo && r->roughness && r->metallic &&
+         r->scaling && r->rotation;
+}
+static void act_fill_raw(gigs::ActPtrs& A, const gigs_activation_raw* r) {
+  A.f_dc = r->f_dc; A.f_rest = r->f_rest; A.opacity = r->opacity; A.normal = r->normal; A.albedo = r->albedo;
+  A.roughness = r->roughness; A.metallic = r->metallic; A.scaling = r->scaling; A.rotation = r->rotation;
+}
+
+int gigs_activate_fwd(int P, int K, const gigs_activation_raw* raw, const gigs_activation_out* out, void* stream) {
+  if (P < 0 || K < 1 || (P > 0 && (!act_raw_ok(raw, K) || !out || !out->shs || !out->opacities || !out->normal ||
+                                   !out->albedo || !out->roughness || !out->metallic || !out->scales || !out->rotations)))
+    return gigs_internal_fail(GIGS_ERR_INVALID, "activate_fwd: bad argument");
+  if (P == 0) return 0;
+  gigs::ActPtrs A;
+  memset(&A, 0, sizeof(A));
+  act_fill_raw(A, raw);
+  A.shs = out->shs; A.o_opacity = out->opacities; A.o_normal = out->normal; A.o_albedo = out->albedo;
+  A.o_roughness = out->roughness; A.o_metallic = out->metallic; A.o_scales = out->scales; A.o_rotations = out->rotations;
+  void* tok; gigs_internal_stage_begin(30, stream, &tok);
+  const long long n = (long long)P * 3 * K;
+  hipLaunchKernelGGL(gigs::activate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K, A);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "activate_fwd: launch failed");
+  return 0;
+}
+
+int gigs_activate_bwd(int P, int K, const gigs_activation_raw* raw, const gigs_activation_out* grad_out,
+                      const gigs_activation_raw_grad* grad_raw, void* stream) {
+  if (P < 0 || K < 1 || (P > 0 && (!act_raw_ok(raw, K) || !grad_out || !grad_raw || !grad_raw->f_dc ||
+                                   (K > 1 && !grad_raw->f_rest) || !grad_raw->opacity || !grad_raw->normal ||
+                                   !grad_raw->albedo || !grad_raw->roughness || !grad_raw->metallic ||
+                                   !grad_raw->scaling || !grad_raw->rotation)))
+    return gigs_internal_fail(GIGS_ERR_INVALID, "activate_bwd: bad argument");
+  if (P == 0) return 0;
+  gigs::ActPtrs A;
+  memset(&A, 0, sizeof(A));
+  act_fill_raw(A, raw);
+  A.g_shs = grad_out->shs; A.g_opacity = grad_out->opacities; A.g_normal = grad_out->normal; A.g_albedo = grad_out->albedo;
+  A.g_roughness = grad_out->roughness; A.g_metallic = grad_out->metallic; A.g_scales = grad_out->scales;
+  A.g_rotations = grad_out->rotations;
+  A.d_f_dc = grad_raw->f_dc; A.d_f_rest = grad_raw->f_rest; A.d_opacity = grad_raw->opacity; A.d_normal = grad_raw->normal;
+  A.d_albedo = grad_raw->albedo; A.d_roughness = grad_raw->roughness; A.d_metallic = grad_raw->metallic;
+  A.d_scaling = grad_raw->scaling; A.d_rotation = grad_raw->rotation;
+  void* tok; gigs_internal_stage_begin(31, stream, &tok);
+  const long long n = (long long)P * 3 * K;
+  hipLaunchKernelGGL(gigs::activate_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K, A);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "activate_bwd: launch failed");
   return 0;
 }
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "gigs_masked_l1_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_masked_l1_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_adam_step": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, C.c_void_p]),
+    "gigs_activate_fwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gigs_activate_bwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gigs_densify_stats": (_i, [_i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_gather_rows": (_i, [_i, C.c_void_p, C.c_longlong, C.c_longlong, _f, _f, C.c_void_p]),
     "gigs_dist2_scratch_bytes": (C.c_size_t, [_i]),
@@ -109,6 +111,18 @@ class AdamGroup(C.Structure):
     """gigs_adam_group of include/gigs_hip.h."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_longlong), ("lr", C.c_double), ("step", C.c_int)]
+
+
+class ActivationRaw(C.Structure):
+    """gigs_activation_raw / gigs_activation_raw_grad of include/gigs_hip.h (nine pointers)."""
+    _fields_ = [(n, C.c_void_p) for n in ("f_dc", "f_rest", "opacity", "normal", "albedo", "roughness", "metallic",
+                                          "scaling", "rotation")]
+
+
+class ActivationOut(C.Structure):
+    """gigs_activation_out of include/gigs_hip.h (eight pointers)."""
+    _fields_ = [(n, C.c_void_p) for n in ("shs", "opacities", "normal", "albedo", "roughness", "metallic", "scales",
+                                          "rotations")]
 
 
 class GatherTensor(C.Structure):

@@ -297,6 +297,24 @@ int gigs_masked_l1_bwd(int channels, int height, int width, const float* a, cons
 int gigs_adam_step(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
                    void* stream);
 
+/* The parameter getters of GaussianModel (scene/gaussian_model.py:48-58, 178-263) as one pass each way:
+ * shs = cat(f_dc [P,1,3], f_rest [P,K-1,3]) -> [P,K,3]; opacities / albedo / roughness / metallic = sigmoid(raw);
+ * scales = exp(scaling); rotations = F.normalize(rotation), normal = F.normalize(normal) (dim -1, eps 1e-12).
+ * gigs_activate_bwd: grad_out members may be NULL (= zero gradient); every grad_raw tensor is overwritten
+ * (f_rest may be NULL when K == 1). */
+typedef struct gigs_activation_raw {
+  const float *f_dc, *f_rest, *opacity, *normal, *albedo, *roughness, *metallic, *scaling, *rotation;
+} gigs_activation_raw;
+typedef struct gigs_activation_out { /* forward: outputs; backward: their incoming gradients */
+  float *shs, *opacities, *normal, *albedo, *roughness, *metallic, *scales, *rotations;
+} gigs_activation_out;
+typedef struct gigs_activation_raw_grad {
+  float *f_dc, *f_rest, *opacity, *normal, *albedo, *roughness, *metallic, *scaling, *rotation;
+} gigs_activation_raw_grad;
+int gigs_activate_fwd(int P, int K, const gigs_activation_raw* raw, const gigs_activation_out* out, void* stream);
+int gigs_activate_bwd(int P, int K, const gigs_activation_raw* raw, const gigs_activation_out* grad_out,
+                      const gigs_activation_raw_grad* grad_raw, void* stream);
+
 /* Densification bookkeeping (gigs-hip extension).
  * gigs_densify_stats = train.py:494-498 + GaussianModel.add_densification_stats (scene/gaussian_model.py:933-945) in one
  *   pass over the P Gaussians, for those with radii > 0: max_radii2D = max(., radii); xyz_gradient_accum += |(gx,gy)|;

@@ -249,3 +249,38 @@ def test_env_tv_loss_matches_restatement():
     got.backward()
     assert abs(got.item() - want.item()) <= 2e-5 * abs(want.item())
     assert (b.grad.cpu().double() - br.grad).abs().max().item() <= 1e-4 * br.grad.abs().max().item()
+
+
+def test_fused_activations_match_the_getters():
+    """scene/gaussian_model.py:178-263 written with torch ops vs gigs_activate_fwd / _bwd."""
+    import activations
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    P, K = 1003, 9
+    shapes = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (K - 1, 3), "opacity": (1,), "normal": (3,), "albedo": (3,),
+              "roughness": (1,), "metallic": (1,), "scaling": (3,), "rotation": (4,)}
+    base = {n: torch.randn((P,) + s, generator=g) * 2.0 for n, s in shapes.items()}
+    base["normal"][:3] = 0.0  # F.normalize's eps branch
+    want_in = {n: t.clone().requires_grad_(True) for n, t in base.items()}
+    want = dict(shs=torch.cat((want_in["f_dc"], want_in["f_rest"]), dim=1), opacities=torch.sigmoid(want_in["opacity"]),
+                normal=F.normalize(want_in["normal"], p=2, dim=-1), albedo=torch.sigmoid(want_in["albedo"]),
+                roughness=torch.sigmoid(want_in["roughness"]), metallic=torch.sigmoid(want_in["metallic"]),
+                scales=torch.exp(want_in["scaling"]), rotations=F.normalize(want_in["rotation"]))
+    got_in = {n: t.clone().to(dev).requires_grad_(True) for n, t in base.items()}
+    got = activations.activate(got_in)
+    assert got["means3D"] is got_in["xyz"]
+    ws = {n: torch.randn(want[n].shape, generator=g) for n in want}
+    sum((want[n] * ws[n]).sum() for n in want if n != "metallic").backward()   # metallic: no incoming gradient
+    sum((got[n] * ws[n].to(dev)).sum() for n in want if n != "metallic").backward()
+    for n in want:
+        assert torch.allclose(got[n].detach().cpu(), want[n].detach(), rtol=2e-6, atol=1e-7), n
+    for n in shapes:
+        if n == "xyz":
+            continue
+        w = want_in[n].grad if want_in[n].grad is not None else torch.zeros_like(base[n])
+        gg = got_in[n].grad.cpu()
+        if n == "normal":  # rows 0-2 sit on the eps branch: gradient g / 1e-12
+            assert torch.allclose(gg[:3], w[:3], rtol=1e-5)
+            gg, w = gg[3:], w[3:]
+        assert (gg - w).abs().max().item() <= 1e-5 * max(w.abs().max().item(), 1e-30), n

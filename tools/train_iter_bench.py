@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "gi-gs_amd"))
 
+import activations  # noqa: E402
 import bench  # noqa: E402  (workload construction only)
 import losses  # noqa: E402
 import optim  # noqa: E402
@@ -55,6 +56,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--only", default="", help="stage1_hip | stage2_hip: run one variant (for profiling)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     gi = dict(scenes.GI_DEFAULTS, start=8)
@@ -115,7 +117,8 @@ def main():
                 return torch_masked_tv(mask, gt_image, brdf) + 0.01 * env_tv
 
             def it(i):
-                stepper(cams_t[i % n_views], activate(r), gt_image, view_dirs[i % n_views], extra_loss=reg)
+                stepper(cams_t[i % n_views], activations.activate(r) if hip else activate(r), gt_image,
+                        view_dirs[i % n_views], extra_loss=reg)
                 opt.step()
                 lopt.step()
                 for p in leaves:  # zero_grad(set_to_none=True), train.py:518-522
@@ -149,7 +152,7 @@ def main():
             return (((2 * mx * my + 1e-4) * (2 * cxy + 9e-4)) / ((mx * mx + my * my + 1e-4) * (vx + vy + 9e-4))).mean()
 
         def it(i):
-            res = pipeline.render(cams_t[i % n_views], activate(r), a.sh_degree, bg, gi)
+            res = pipeline.render(cams_t[i % n_views], activations.activate(r) if hip else activate(r), a.sh_degree, bg, gi)
             image, nm, nfd, mask = res["render"], res["normal_map"], res["normal_map_from_depth"], res["normal_from_depth_mask"]
             if hip:
                 loss, _, _ = losses.stage1_loss(image, gt_image, nm, nfd, mask, 0.2)
@@ -175,6 +178,10 @@ def main():
         return {"ms_per_iteration": round(dt * 1e3, 3), "iterations_per_s": round(1.0 / dt, 1)}
 
     out = {"workload": f"C2 P={a.gaussians} {a.res}x{a.res} sh{a.sh_degree} start=8", "steps": a.steps}
+    if a.only:
+        out[a.only] = run_stage1(True) if a.only == "stage1_hip" else run("hip")
+        print(json.dumps(out))
+        return
     out["stage1_full_iteration_hip_glue"] = run_stage1(True)
     out["stage1_full_iteration_torch_glue"] = run_stage1(False)
     out["metric_step_no_optimizer"] = run("metric")
