@@ -72,6 +72,90 @@ gbuffer_post_kernel(int H, int W, const float* __restrict__ normal_map, const fl
   onv[p] = o.x; onv[HW + p] = o.y; onv[2 * HW + p] = o.z;
 }
 
+// ---- backward of the normal post-processing (stage 1: train.py:327-328 differentiates through
+// gaussian_renderer/__init__.py:160-186) ---------------------------------------------------------------------------
+// normals_view = -(median3x3(normalize_where(normal_map)) @ R).  Pass 1, one lane per output pixel: rotate the
+// incoming gradient back, g_med[c] = -sum_j R[c][j] g[j], and hand it to the tap the median selected (first tap in
+// row-major order equal to the median, as median3x3_bwd_kernel; padding taps and NaN windows drop it).  Pass 2, one
+// lane per source pixel: the derivative of normalize_where.
+__global__ void __launch_bounds__(256)
+gbuffer_post_bwd_scatter_kernel(int H, int W, const float* __restrict__ normal_map, const float* __restrict__ vm,
+                                const float* __restrict__ g_nv, float* __restrict__ g_hat) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const size_t HW = (size_t)H * W, p = (size_t)y * W + x;
+  const float g0 = g_nv[p], g1 = g_nv[HW + p], g2 = g_nv[2 * HW + p];
+  float gm[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) gm[c] = -(vm[4 * c] * g0 + vm[4 * c + 1] * g1 + vm[4 * c + 2] * g2);
+  if (gm[0] == 0.0f && gm[1] == 0.0f && gm[2] == 0.0f) return;
+  float t[3][9];
+  bool nan[3] = {false, false, false};
+  int k = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++, k++) {
+      const int yy = y + dy, xx = x + dx;
+      v3 v = {0.0f, 0.0f, 0.0f};
+      if (!(yy < 0 || yy >= H || xx < 0 || xx >= W)) {
+        const size_t q = (size_t)yy * W + xx;
+        v = normalize_where({normal_map[q], normal_map[HW + q], normal_map[2 * HW + q]});
+      }
+      t[0][k] = v.x; t[1][k] = v.y; t[2][k] = v.z;
+      nan[0] |= v.x != v.x; nan[1] |= v.y != v.y; nan[2] |= v.z != v.z;
+    }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    if (nan[c] || gm[c] == 0.0f) continue;
+    float srt[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) srt[j] = t[c][j];
+    const float med = median9(srt);
+    int sel = -1;
+#pragma unroll
+    for (int j = 8; j >= 0; j--)
+      if (t[c][j] == med) sel = j;  // ends on the first match
+    if (sel < 0) continue;
+    const int yy = y + sel / 3 - 1, xx = x + sel % 3 - 1;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;  // a zero-padding tap was the median
+    atomicAdd(g_hat + c * HW + (size_t)yy * W + xx, gm[c]);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gbuffer_post_bwd_finish_kernel(size_t HW, const float* __restrict__ normal_map, const float* __restrict__ g_hat,
+                               float* __restrict__ g_normal_map) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float vx = normal_map[p], vy = normal_map[HW + p], vz = normal_map[2 * HW + p];
+  const float gx = g_hat[p], gy = g_hat[HW + p], gz = g_hat[2 * HW + p];
+  const float n2 = vx * vx + vy * vy + vz * vz;
+  const float n = sqrtf(n2);
+  float ox = gx, oy = gy, oz = gz;  // |v| == 0 (or NaN): torch.where passes v itself
+  if (n > 0.0f) {
+    if (n > 1e-12f) {
+      const float s = (vx * gx + vy * gy + vz * gz) / (n2 * n);
+      ox = gx / n - vx * s; oy = gy / n - vy * s; oz = gz / n - vz * s;
+    } else {
+      ox = gx / 1e-12f; oy = gy / 1e-12f; oz = gz / 1e-12f;
+    }
+  }
+  g_normal_map[p] = ox; g_normal_map[HW + p] = oy; g_normal_map[2 * HW + p] = oz;
+}
+
+// normal_map_from_depth of gaussian_renderer/__init__.py:157-163: mask = (v != 0).all(0), v <- normalize_where(v)
+__global__ void __launch_bounds__(256)
+normalize_mask_kernel(size_t HW, const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ mask) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const v3 v = {in[p], in[HW + p], in[2 * HW + p]};
+  if (mask) mask[p] = (v.x != 0.0f && v.y != 0.0f && v.z != 0.0f) ? 1 : 0;
+  const v3 o = normalize_where(v);
+  out[p] = o.x; out[HW + p] = o.y; out[2 * HW + p] = o.z;
+}
+
 // ---- loss -------------------------------------------------------------------------------------
 // acc[0] = sum |render_rgb - gt|, acc[1] = sum (1 - roughness) * mask, acc[2] = sum metallic * mask,
 // acc[3] = sum mask;  loss = acc0 / (3 H W) + 0.001 * (acc1 / acc3 + acc2 / acc3)   (train.py:396-402)
@@ -264,6 +348,34 @@ int gigs_gbuffer_post(int height, int width, const float* normal_map, const floa
                      normal_mask, normal_mask_f, out_normal_view_filtered);
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "gbuffer_post: launch failed");
+  return 0;
+}
+
+int gigs_gbuffer_post_bwd(int height, int width, const float* normal_map, const float* viewmatrix,
+                          const float* g_normals_view, float* scratch3, float* g_normal_map, void* stream) {
+  if (height <= 0 || width <= 0 || !normal_map || !viewmatrix || !g_normals_view || !scratch3 || !g_normal_map)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "gbuffer_post_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t HW = (size_t)height * width;
+  void* tok; gigs_internal_stage_begin(18, stream, &tok);
+  gigs::launch_zero(scratch3, 3 * HW, s);
+  hipLaunchKernelGGL(gigs::gbuffer_post_bwd_scatter_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, s,
+                     height, width, normal_map, viewmatrix, g_normals_view, scratch3);
+  hipLaunchKernelGGL(gigs::gbuffer_post_bwd_finish_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, HW,
+                     normal_map, scratch3, g_normal_map);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "gbuffer_post_bwd: launch failed");
+  return 0;
+}
+
+int gigs_normalize_mask(int height, int width, const float* in, float* out, uint8_t* mask, void* stream) {
+  if (height <= 0 || width <= 0 || !in || !out) return gigs_internal_fail(GIGS_ERR_INVALID, "normalize_mask: bad argument");
+  const size_t HW = (size_t)height * width;
+  void* tok; gigs_internal_stage_begin(18, stream, &tok);
+  hipLaunchKernelGGL(gigs::normalize_mask_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream, HW,
+                     in, out, mask);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "normalize_mask: launch failed");
   return 0;
 }
 

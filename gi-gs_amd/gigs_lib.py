@@ -70,6 +70,8 @@ SIGNATURES = {
                                C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
                                C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     "gigs_gbuffer_post": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_gbuffer_post_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_normalize_mask": (_i, [_i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_cube_texture_fwd": (_i, [_i, _f, _i, _f, _f, _i, C.c_void_p]),

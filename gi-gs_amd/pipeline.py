@@ -92,6 +92,58 @@ def gbuffer_post(normal_map_from_depth: torch.Tensor, normal_map: torch.Tensor, 
     return normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view
 
 
+class _GbufferPostFused(torch.autograd.Function):
+    """gbuffer_post as two kernels forward (gigs_gbuffer_post, gigs_normalize_mask) and two backward
+    (gigs_gbuffer_post_bwd): stage 1 differentiates through normal_map only (train.py:327-328)."""
+
+    @staticmethod
+    def forward(ctx, normal_map_from_depth, normal_map, out_normal_view, viewmatrix):
+        import gigs_lib
+        lib = gigs_lib.lib()
+        if not normal_map.is_cuda:
+            raise RuntimeError("gbuffer_post needs CUDA/HIP tensors: gigs-hip has no CPU path")
+        f = lambda t: t.contiguous().float()  # noqa: E731
+        nfd, nm, onv_in, vm = f(normal_map_from_depth), f(normal_map), f(out_normal_view), f(viewmatrix)
+        _, H, W = nm.shape
+        dev = nm.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        nfd_out, normals_view, onv = new(3, H, W), new(3, H, W), new(3, H, W)
+        nfd_mask = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        mask = torch.empty((1, H, W), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            s = torch.cuda.current_stream().cuda_stream
+            gigs_lib.check(lib.gigs_normalize_mask(H, W, nfd.data_ptr(), nfd_out.data_ptr(), nfd_mask.data_ptr(), s),
+                           "normalize_mask")
+            gigs_lib.check(lib.gigs_gbuffer_post(H, W, nm.data_ptr(), onv_in.data_ptr(), vm.data_ptr(),
+                                                 normals_view.data_ptr(), mask.data_ptr(), None, onv.data_ptr(), s),
+                           "gbuffer_post")
+        ctx.save_for_backward(nm, vm)
+        nfd_mask_b, mask_b = nfd_mask.bool(), mask.bool()
+        ctx.mark_non_differentiable(nfd_out, nfd_mask_b, mask_b, onv)
+        return nfd_out, nfd_mask_b, normals_view, mask_b, onv
+
+    @staticmethod
+    def backward(ctx, _g_nfd, _g_nfd_mask, g_normals_view, _g_mask, _g_onv):
+        import gigs_lib
+        lib = gigs_lib.lib()
+        nm, vm = ctx.saved_tensors
+        _, H, W = nm.shape
+        g = g_normals_view.contiguous().float()
+        scratch, g_nm = torch.empty_like(nm), torch.empty_like(nm)
+        with torch.cuda.device(nm.device):
+            gigs_lib.check(lib.gigs_gbuffer_post_bwd(H, W, nm.data_ptr(), vm.data_ptr(), g.data_ptr(), scratch.data_ptr(),
+                                                     g_nm.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                           "gbuffer_post_bwd")
+        return None, g_nm, None, None
+
+
+def gbuffer_post_fused(normal_map_from_depth: torch.Tensor, normal_map: torch.Tensor, out_normal_view: torch.Tensor,
+                       viewmatrix: torch.Tensor):
+    """Same five results as gbuffer_post; gradient flows to normal_map only (normal_map_from_depth and out_normal_view
+    receive none from the reference's operator either: their incoming gradients are dropped)."""
+    return _GbufferPostFused.apply(normal_map_from_depth, normal_map, out_normal_view, viewmatrix)
+
+
 def rasterize(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tensor, gi: Dict,
               inference: bool = False, derive_normal: bool = True, debug=False):
     """The operator call of gaussian_renderer.render (:53-155): returns the raw 12-tuple + means2D."""
@@ -106,13 +158,13 @@ def rasterize(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.T
 
 
 def render(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tensor, gi: Dict,
-           inference: bool = False, derive_normal: bool = True, debug=False) -> Dict[str, torch.Tensor]:
-    """gaussian_renderer.render with pad_normal=False."""
+           inference: bool = False, derive_normal: bool = True, debug=False, fused_post: bool = False) -> Dict[str, torch.Tensor]:
+    """gaussian_renderer.render with pad_normal=False; fused_post=True runs the post-processing as fused kernels."""
     ((rendered_image, radii, opacity_map, depth_map, normal_map_from_depth, normal_map, occlusion_map, albedo_map,
       roughness_map, metallic_map, out_normal_view, depth_pos), screenspace_points, st) = rasterize(
         cam, g, sh_degree, bg, gi, inference=inference, derive_normal=derive_normal, debug=debug)
-    (normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view) = gbuffer_post(
-        normal_map_from_depth, normal_map, out_normal_view, st.viewmatrix)
+    (normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view) = (
+        gbuffer_post_fused if fused_post else gbuffer_post)(normal_map_from_depth, normal_map, out_normal_view, st.viewmatrix)
     return {
         "render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
         "radii": radii, "opacity_map": opacity_map, "depth_map": depth_map,

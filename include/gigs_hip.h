@@ -238,6 +238,15 @@ int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs
 int gigs_gbuffer_post(int height, int width, const float* normal_map, const float* out_normal_view,
                       const float* viewmatrix, float* normals_view, uint8_t* normal_mask, float* normal_mask_f,
                       float* out_normal_view_filtered, void* stream);
+/* Stage 1 differentiates through the normal post-processing (train.py:327-328 use render()'s normal_map):
+ * gigs_gbuffer_post_bwd = gradient of gigs_gbuffer_post's normals_view w.r.t. normal_map (rotation, the median's tap
+ *   selection -- first tap in row-major order equal to the median, as gigs_median3x3_backward --, normalize_where);
+ *   scratch3 is [3,H,W] floats of scratch (zeroed inside), g_normal_map [3,H,W] is overwritten.
+ * gigs_normalize_mask = gaussian_renderer/__init__.py:157-163 for normal_map_from_depth: mask = (in != 0).all(0)
+ *   (u8 [H,W], may be NULL), out = normalize_where(in). */
+int gigs_gbuffer_post_bwd(int height, int width, const float* normal_map, const float* viewmatrix,
+                          const float* g_normals_view, float* scratch3, float* g_normal_map, void* stream);
+int gigs_normalize_mask(int height, int width, const float* in, float* out, uint8_t* mask, void* stream);
 int gigs_stage2_loss_fwd(int height, int width, const float* render_direct, const float* irr_linear,
                          const float* gt_image, const float* normal_mask_f, const float* roughness,
                          const float* metallic, float* render_rgb, float* acc4, float* loss, void* stream);

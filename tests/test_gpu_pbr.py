@@ -265,3 +265,33 @@ def test_stage2_fused_matches_unfused(orc, metallic):
                 assert rel_peak(gf[k].cpu().numpy(), gu[k].cpu().numpy()) < 2e-3, (mode, k)
             assert rel_peak(bf.cpu().numpy(), bu.cpu().numpy()) < 2e-3, mode
     assert abs(results["fused_graph"][0][0] - results["fused_graph"][1][0]) > 1e-6
+
+
+@pytest.mark.gpu
+def test_fused_gbuffer_post_matches_torch_chain_forward_and_backward():
+    """pipeline.gbuffer_post (torch ops, gaussian_renderer/__init__.py:157-199) vs the fused kernels incl. the
+    gradient w.r.t. normal_map that stage 1 needs."""
+    import pipeline
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    H, W = 70, 93
+    nm = torch.randn(3, H, W, generator=g)
+    nm[:, 10:20, 30:60] = 0.0                      # empty pixels
+    nm[:, 40, 5] = torch.tensor([0.0, 1.0, 0.0])   # a zero component: masked out, still normalised
+    nm = (nm * 8).round() / 8                       # coarse values: ties inside the median windows
+    nfd = torch.randn(3, H, W, generator=g)
+    nfd[:, 50:, :20] = 0.0
+    onv = torch.randn(3, H, W, generator=g)
+    onv[:, :5] = 0.0
+    vm = torch.linalg.qr(torch.randn(4, 4, generator=g))[0]
+    w = torch.randn(3, H, W, generator=g)
+    a = nm.clone().to(dev).requires_grad_(True)
+    ref = pipeline.gbuffer_post(nfd.to(dev), a, onv.to(dev), vm.to(dev))
+    (ref[2] * w.to(dev)).sum().backward()
+    b = nm.clone().to(dev).requires_grad_(True)
+    got = pipeline.gbuffer_post_fused(nfd.to(dev), b, onv.to(dev), vm.to(dev))
+    (got[2] * w.to(dev)).sum().backward()
+    assert torch.equal(got[1], ref[1]) and torch.equal(got[3], ref[3])
+    for i in (0, 2, 4):
+        assert torch.allclose(got[i], ref[i], rtol=1e-6, atol=1e-6), i
+    assert (b.grad - a.grad).abs().max().item() <= 1e-5 * a.grad.abs().max().item()

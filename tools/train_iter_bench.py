@@ -152,7 +152,8 @@ def main():
             return (((2 * mx * my + 1e-4) * (2 * cxy + 9e-4)) / ((mx * mx + my * my + 1e-4) * (vx + vy + 9e-4))).mean()
 
         def it(i):
-            res = pipeline.render(cams_t[i % n_views], activations.activate(r) if hip else activate(r), a.sh_degree, bg, gi)
+            res = pipeline.render(cams_t[i % n_views], activations.activate(r) if hip else activate(r), a.sh_degree, bg, gi,
+                                  fused_post=hip)
             image, nm, nfd, mask = res["render"], res["normal_map"], res["normal_map_from_depth"], res["normal_from_depth_mask"]
             if hip:
                 loss, _, _ = losses.stage1_loss(image, gt_image, nm, nfd, mask, 0.2)
