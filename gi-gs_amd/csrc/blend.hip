@@ -465,13 +465,14 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   float dp0 = 0, dp1 = 0, dp2 = 0, dn0 = 0, dn1 = 0, dn2 = 0, da0 = 0, da1 = 0, da2 = 0;
   float dop = 0, drg = 0, dmt = 0, ddp = 0;
   if (inside) {
-    dp0 = gi.color[pix_id]; dp1 = gi.color[HW + pix_id]; dp2 = gi.color[2 * HW + pix_id];
-    dn0 = gi.normal[pix_id]; dn1 = gi.normal[HW + pix_id]; dn2 = gi.normal[2 * HW + pix_id];
-    da0 = gi.albedo[pix_id]; da1 = gi.albedo[HW + pix_id]; da2 = gi.albedo[2 * HW + pix_id];
-    dop = gi.opacity[pix_id];
-    drg = gi.roughness[pix_id];
-    dmt = gi.metallic[pix_id];
-    ddp = gi.depth[pix_id];
+    // a NULL plane is an all-zero gradient (an output the loss does not use: no tensor is materialised for it)
+    if (gi.color) { dp0 = gi.color[pix_id]; dp1 = gi.color[HW + pix_id]; dp2 = gi.color[2 * HW + pix_id]; }
+    if (gi.normal) { dn0 = gi.normal[pix_id]; dn1 = gi.normal[HW + pix_id]; dn2 = gi.normal[2 * HW + pix_id]; }
+    if (gi.albedo) { da0 = gi.albedo[pix_id]; da1 = gi.albedo[HW + pix_id]; da2 = gi.albedo[2 * HW + pix_id]; }
+    if (gi.opacity) dop = gi.opacity[pix_id];
+    if (gi.roughness) drg = gi.roughness[pix_id];
+    if (gi.metallic) dmt = gi.metallic[pix_id];
+    if (gi.depth) ddp = gi.depth[pix_id];
   }
   if (px == 0 || px == (unsigned)(W - 1) || py == 0 || py == (unsigned)(H - 1)) {  // backward.cu:497-501
     dn0 = dn1 = dn2 = 0.0f;

@@ -226,12 +226,19 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
                                   metallic, scales, rotations, cov3Ds_precomp, sh, campos, viewmatrix,
                                   projmatrix, scale_modifier, tanfovx, tanfovy, sh_degree, grad_depth,
                                   grad_color, grad_opacity, grad_normal, grad_albedo, grad_roughness,
-                                  grad_metallic, geomBuffer, binningBuffer, imgBuffer, num_rendered, debug):
-    """_C.rasterize_gaussians_backward: 31 args -> 12 tensors (R/rasterize_points.cu:254-364)."""
+                                  grad_metallic, geomBuffer, binningBuffer, imgBuffer, num_rendered, debug,
+                                  image_size=None):
+    """_C.rasterize_gaussians_backward: 31 args -> 12 tensors (R/rasterize_points.cu:254-364).  An incoming gradient
+    may be None (= zeros, nothing is materialised); `image_size` = (H, W) is then needed if grad_color is None."""
     _need_gpu(means3D, "means3D")
     dev = means3D.device
     P = int(means3D.size(0))
-    H, W = int(grad_color.size(1)), int(grad_color.size(2))
+    if grad_color is not None:
+        H, W = int(grad_color.size(1)), int(grad_color.size(2))
+    elif image_size is not None:
+        H, W = int(image_size[0]), int(image_size[1])
+    else:
+        raise RuntimeError("rasterize_gaussians_backward: grad_color is None and no image_size was given")
     M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
     # every element of every gradient tensor is written by the backward kernels when P > 0
     # (the reference zero-fills 14 tensors first, rasterize_points.cu:299-312)
@@ -432,6 +439,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, normal, albedo, roughness, metallic, sh, colors_precomp,
                 scales, rotations, cov3Ds_precomp, raster_settings):
+        # outputs the loss does not use reach backward() as None instead of freshly filled zero planes
+        ctx.set_materialize_grads(False)
         args = (
             raster_settings.bg, means3D, colors_precomp, opacities, normal, albedo, roughness, metallic,
             scales, rotations, cov3Ds_precomp, sh, raster_settings.campos, raster_settings.viewmatrix,
@@ -469,6 +478,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         (colors_precomp, normal, albedo, roughness, metallic, means3D, scales, rotations, cov3Ds_precomp,
          radii, sh, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
         # grad_out_normal_view and grad_out_pos are dropped, as in the reference (:243-275)
+        if raster_settings.debug:  # the snapshot path keeps the reference's fully materialised argument tuple
+            H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+            zf = lambda t, c: t if t is not None else torch.zeros((c, H, W), device=means3D.device)  # noqa: E731
+            grad_out_color, grad_out_normal, grad_out_albedo = zf(grad_out_color, 3), zf(grad_out_normal, 3), zf(grad_out_albedo, 3)
+            grad_out_opacity, grad_depth = zf(grad_out_opacity, 1), zf(grad_depth, 1)
+            grad_out_roughness, grad_out_metallic = zf(grad_out_roughness, 1), zf(grad_out_metallic, 1)
         args = (
             raster_settings.bg, means3D, radii, colors_precomp, normal, albedo, roughness, metallic, scales,
             rotations, cov3Ds_precomp, sh, raster_settings.campos, raster_settings.viewmatrix,
@@ -486,7 +501,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            res = _C.rasterize_gaussians_backward(*args)
+            res = _rasterize_gaussians_backward(*args, image_size=(raster_settings.image_height,
+                                                                   raster_settings.image_width))
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_normal, grad_albedo, grad_roughness,
          grad_metallic, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations) = res
         return (grad_means3D, grad_means2D, grad_opacities, grad_normal, grad_albedo, grad_roughness,
