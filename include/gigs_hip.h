@@ -333,7 +333,8 @@ int gigs_activate_bwd(int P, int K, const gigs_activation_raw* raw, const gigs_a
  * gigs_gather_rows rebuilds any number of row-major fp32 tensors after a densify / prune decision in one launch
  *   (replaces the per-tensor boolean-mask indexing and torch.cat of scene/gaussian_model.py:595-706):
  *   dst_t[r, :] = (zero_row && zero_row[r] && t.zero_new) ? 0 : src_t[src_index[r], :] for r < n_rows_out;
- *   src_index values must lie in [0, n_rows_in) (checked by the host side, not by the kernel). */
+ *   src_index values must lie in [0, n_rows_in): the kernel does not check them (gi-gs_amd/densify.py builds them from
+ *   arange(n_rows_in) selections only). */
 typedef struct gigs_gather_tensor {
   const float* src;
   float* dst;
