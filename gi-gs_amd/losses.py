@@ -181,14 +181,67 @@ def masked_l1_loss(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor) -> torc
     return _MaskedL1.apply(a, b, mask)
 
 
+class _Stage1Loss(torch.autograd.Function):
+    """The three stage-1 terms as ONE autograd node: six kernels forward (three passes + their finish kernels), three
+    backward, instead of three nodes plus the scalar arithmetic between them (the Python / autograd hops cost more than
+    the kernels at 800x800).  Gradients: image <- colour term, normal_map <- masked L1 + TV."""
+
+    @staticmethod
+    def forward(ctx, image, gt, normal_map, nfd, mask, lam, w_normal, w_tv):
+        image, gt = _chw(image, "stage1_loss"), _chw(gt, "stage1_loss")
+        nm, nfd = _chw(normal_map, "stage1_loss"), _chw(nfd, "stage1_loss")
+        C, H, W = image.shape
+        if gt.shape != image.shape or nm.shape != (3, H, W) or nfd.shape != (3, H, W) or mask.numel() != H * W:
+            raise ValueError("stage1_loss: shapes differ")
+        dev = image.device
+        mask_u8 = mask.reshape(H, W).contiguous().to(torch.uint8)
+        need_img, need_nm = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[2])
+        d = torch.empty((3, C, H, W), dtype=torch.float32, device=dev) if need_img else None
+        out = torch.empty(6, dtype=torch.float32, device=dev)  # {colour loss, l1, ssim, normal l1, count, tv}
+        with torch.cuda.device(dev):
+            s = _stream()
+            gigs_lib.check(_lib.gigs_l1_ssim_fwd(C, H, W, _p(image), _p(gt), float(lam), _p(d[0]) if need_img else None,
+                                                 _p(d[1]) if need_img else None, _p(d[2]) if need_img else None,
+                                                 _p(_scratch(C, H, W, dev)), _p(out), s), "l1_ssim_fwd")
+            gigs_lib.check(_lib.gigs_masked_l1_fwd(3, H, W, _p(nm), _p(nfd), _p(mask_u8), _p(_scratch(3, H, W, dev)),
+                                                   _p(out[3:5]), s), "masked_l1_fwd")
+            gigs_lib.check(_lib.gigs_tv_loss_fwd(3, H, W, 1, _p(gt), _p(nm), None, _p(_scratch(3, H, W, dev)), _p(out[5:6]),
+                                                 s), "tv_loss_fwd")
+        loss = out[0] + float(w_normal) * out[3] + float(w_tv) * out[5]
+        ctx.lam, ctx.w_normal, ctx.w_tv = float(lam), float(w_normal), float(w_tv)
+        ctx.need_img, ctx.need_nm = need_img, need_nm
+        ctx.save_for_backward(image, gt, nm, nfd, mask_u8, out, d if need_img else torch.empty(0, device=dev))
+        ll1, nl = out[1].clone(), out[3].clone()
+        ctx.mark_non_differentiable(ll1, nl)
+        return loss, ll1, nl
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_l1, _g_nl):
+        image, gt, nm, nfd, mask_u8, out, d = ctx.saved_tensors
+        C, H, W = image.shape
+        g = g_loss.reshape(1).contiguous().float()
+        g_image = g_nm = None
+        with torch.cuda.device(image.device):
+            s = _stream()
+            if ctx.need_img:
+                g_image = torch.empty_like(image)
+                gigs_lib.check(_lib.gigs_l1_ssim_bwd(C, H, W, _p(image), _p(gt), ctx.lam, _p(d[0]), _p(d[1]), _p(d[2]), _p(g),
+                                                     _p(g_image), s), "l1_ssim_bwd")
+            if ctx.need_nm:
+                g_nm, g_tv = torch.empty_like(nm), torch.empty_like(nm)
+                gn, gt_ = g * ctx.w_normal, g * ctx.w_tv
+                gigs_lib.check(_lib.gigs_masked_l1_bwd(3, H, W, _p(nm), _p(nfd), _p(mask_u8), _p(out[3:5]), _p(gn), _p(g_nm),
+                                                       None, s), "masked_l1_bwd")
+                gigs_lib.check(_lib.gigs_tv_loss_bwd(3, H, W, 1, _p(gt), _p(nm), None, _p(gt_), _p(g_tv), s), "tv_loss_bwd")
+                g_nm += g_tv
+        return g_image, None, g_nm, None, None, None, None, None
+
+
 def stage1_loss(image, gt_image, normal_map, normal_map_from_depth, normal_from_depth_mask, lambda_dssim=0.2,
                 normal_loss_weight=1.0, normal_tv_weight=1.0):
-    """The stage-1 objective of train.py:318-331 -> (loss, Ll1, normal_loss)."""
-    out = _L1Ssim.apply(image, gt_image, lambda_dssim)
-    normal_loss = masked_l1_loss(normal_map, normal_map_from_depth, normal_from_depth_mask)
-    loss = out[0] + normal_loss_weight * normal_loss
-    loss = loss + get_tv_loss(gt_image, normal_map, pad=1, step=1) * normal_tv_weight
-    return loss, out[1].detach(), normal_loss
+    """The stage-1 objective of train.py:318-331 -> (loss, Ll1, normal_loss), one autograd node."""
+    return _Stage1Loss.apply(image, gt_image, normal_map, normal_map_from_depth, normal_from_depth_mask, lambda_dssim,
+                             normal_loss_weight, normal_tv_weight)
 
 
 def get_envmap_dirs(res=(512, 1024), device="cuda") -> torch.Tensor:
