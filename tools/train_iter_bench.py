@@ -56,10 +56,11 @@ def main():
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--start", type=int, default=8, help="GI march start (>= 16 = empty march)")
     ap.add_argument("--only", default="", help="stage1_hip | stage2_hip: run one variant (for profiling)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    gi = dict(scenes.GI_DEFAULTS, start=8)
+    gi = dict(scenes.GI_DEFAULTS, start=a.start)
     sc = scenes.surface_scene(P=a.gaussians, sh_degree=a.sh_degree, seed=0)
     n_views = 64
     cams = [scenes.orbit_camera(i, n_views, a.res, a.res, radius=3.5) for i in range(n_views)]
@@ -178,7 +179,7 @@ def main():
         dt = (time.perf_counter() - t0) / a.steps
         return {"ms_per_iteration": round(dt * 1e3, 3), "iterations_per_s": round(1.0 / dt, 1)}
 
-    out = {"workload": f"C2 P={a.gaussians} {a.res}x{a.res} sh{a.sh_degree} start=8", "steps": a.steps}
+    out = {"workload": f"C2 P={a.gaussians} {a.res}x{a.res} sh{a.sh_degree} start={a.start}", "steps": a.steps}
     if a.only:
         out[a.only] = run_stage1(True) if a.only == "stage1_hip" else run("hip")
         print(json.dumps(out))
