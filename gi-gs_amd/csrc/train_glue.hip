@@ -62,17 +62,32 @@ l1_ssim_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __r
   __shared__ float s_red[4];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int x0 = blockIdx.x * kSsimTile - kSsimR, y0 = blockIdx.y * kSsimTile - kSsimR;
-  for (int i = threadIdx.x; i < kSsimHalo * kSsimHalo; i += 256) {
-    const int ty = i / kSsimHalo, tx = i - ty * kSsimHalo;
-    const int yy = y0 + ty, xx = x0 + tx;
-    float a = 0.0f, b = 0.0f;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const size_t q = plane + (size_t)yy * W + xx;
-      a = img[q];
-      b = gt[q];
+  {
+    // all of a thread's halo loads are issued before the first LDS store: one global-memory latency, not seven
+    constexpr int kIters = (kSsimHalo * kSsimHalo + 255) / 256;
+    float va[kIters], vb[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; j++) {
+      const int i = threadIdx.x + 256 * j;
+      const int ty = i / kSsimHalo, tx = i - ty * kSsimHalo;
+      const int yy = y0 + ty, xx = x0 + tx;
+      va[j] = 0.0f;
+      vb[j] = 0.0f;
+      if (i < kSsimHalo * kSsimHalo && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const size_t q = plane + (size_t)yy * W + xx;
+        va[j] = img[q];
+        vb[j] = gt[q];
+      }
     }
-    s_x[ty][tx] = a;
-    s_y[ty][tx] = b;
+#pragma unroll
+    for (int j = 0; j < kIters; j++) {
+      const int i = threadIdx.x + 256 * j;
+      const int ty = i / kSsimHalo, tx = i - ty * kSsimHalo;
+      if (i < kSsimHalo * kSsimHalo) {
+        s_x[ty][tx] = va[j];
+        s_y[ty][tx] = vb[j];
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kSsimHalo * kSsimTile; i += 256) {
@@ -156,17 +171,28 @@ l1_ssim_bwd_kernel(int H, int W, const float* __restrict__ img, const float* __r
   __shared__ float s_h[3][kSsimHalo][kSsimTile + 1];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int x0 = blockIdx.x * kSsimTile - kSsimR, y0 = blockIdx.y * kSsimTile - kSsimR;
-  for (int i = threadIdx.x; i < kSsimHalo * kSsimHalo; i += 256) {
-    const int ty = i / kSsimHalo, tx = i - ty * kSsimHalo;
-    const int yy = y0 + ty, xx = x0 + tx;
-    float a = 0.0f, b = 0.0f, c = 0.0f;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const size_t q = plane + (size_t)yy * W + xx;
-      a = d_mu1[q];
-      b = d_e11[q];
-      c = d_e12[q];
+  {
+    constexpr int kIters = (kSsimHalo * kSsimHalo + 255) / 256;
+    float va[kIters], vb[kIters], vc[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; j++) {
+      const int i = threadIdx.x + 256 * j;
+      const int ty = i / kSsimHalo, tx = i - ty * kSsimHalo;
+      const int yy = y0 + ty, xx = x0 + tx;
+      va[j] = vb[j] = vc[j] = 0.0f;
+      if (i < kSsimHalo * kSsimHalo && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const size_t q = plane + (size_t)yy * W + xx;
+        va[j] = d_mu1[q];
+        vb[j] = d_e11[q];
+        vc[j] = d_e12[q];
+      }
     }
-    s_m[0][ty][tx] = a; s_m[1][ty][tx] = b; s_m[2][ty][tx] = c;
+#pragma unroll
+    for (int j = 0; j < kIters; j++) {
+      const int i = threadIdx.x + 256 * j;
+      const int ty = i / kSsimHalo, tx = i - ty * kSsimHalo;
+      if (i < kSsimHalo * kSsimHalo) { s_m[0][ty][tx] = va[j]; s_m[1][ty][tx] = vb[j]; s_m[2][ty][tx] = vc[j]; }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kSsimHalo * kSsimTile; i += 256) {
