@@ -7,7 +7,7 @@
     random_init_cloud                                                   scene/dataset_readers.py:303-312
     get_expon_lr_func                                                   utils/general_utils.py:33-71 (xyz learning rate)
 
-The COLMAP reader (binary model files) stays with the reference.
+    read_colmap_*_bin, readColmapCameras, readColmapSceneInfo           scene/colmap_loader.py:27-274; scene/dataset_readers.py:81-214
 """
 from __future__ import annotations
 
@@ -153,3 +153,137 @@ def get_expon_lr_func(lr_init: float, lr_final: float, lr_delay_steps: int = 0, 
         return delay * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
 
     return helper
+
+
+# ---- COLMAP sparse models (scene/colmap_loader.py:27-274; scene/dataset_readers.py:81-214) ----------------------
+import struct  # noqa: E402
+
+# model id -> (name, number of parameters), COLMAP's src/base/camera_models.h as listed at scene/colmap_loader.py:27-39
+COLMAP_CAMERA_MODELS = {0: ("SIMPLE_PINHOLE", 3), 1: ("PINHOLE", 4), 2: ("SIMPLE_RADIAL", 4), 3: ("RADIAL", 5),
+                        4: ("OPENCV", 8), 5: ("OPENCV_FISHEYE", 8), 6: ("FULL_OPENCV", 12), 7: ("FOV", 5),
+                        8: ("SIMPLE_RADIAL_FISHEYE", 4), 9: ("RADIAL_FISHEYE", 5), 10: ("THIN_PRISM_FISHEYE", 12)}
+
+
+class ColmapCamera(NamedTuple):
+    id: int
+    model: str
+    width: int
+    height: int
+    params: np.ndarray
+
+
+class ColmapImage(NamedTuple):
+    id: int
+    qvec: np.ndarray
+    tvec: np.ndarray
+    camera_id: int
+    name: str
+    xys: np.ndarray
+    point3D_ids: np.ndarray
+
+
+def qvec2rotmat(q) -> np.ndarray:
+    """scene/colmap_loader.py:46-65: rotation matrix of the (w, x, y, z) quaternion, not normalised."""
+    w, x, y, z = (float(v) for v in q)
+    return np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * z * x + 2 * w * y],
+                     [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x],
+                     [2 * z * x - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y]])
+
+
+def read_colmap_cameras_bin(path: str) -> Dict[int, ColmapCamera]:
+    """cameras.bin (scene/colmap_loader.py:249-273): u64 count, then per camera i32 id, i32 model, u64 width, u64 height,
+    f64 params[model]."""
+    buf = open(path, "rb").read()
+    (n,), off = struct.unpack_from("<Q", buf, 0), 8
+    out = {}
+    for _ in range(n):
+        cam_id, model_id, width, height = struct.unpack_from("<iiQQ", buf, off)
+        off += 24
+        if model_id not in COLMAP_CAMERA_MODELS:
+            raise ValueError(f"{path}: unknown COLMAP camera model id {model_id}")
+        name, n_params = COLMAP_CAMERA_MODELS[model_id]
+        params = np.frombuffer(buf, dtype="<f8", count=n_params, offset=off).copy()
+        off += 8 * n_params
+        out[cam_id] = ColmapCamera(cam_id, name, int(width), int(height), params)
+    if len(out) != n:
+        raise ValueError(f"{path}: duplicate camera ids")
+    return out
+
+
+def read_colmap_images_bin(path: str) -> Dict[int, ColmapImage]:
+    """images.bin (scene/colmap_loader.py:207-246): u64 count, then per image i32 id, f64 qvec[4], f64 tvec[3], i32
+    camera id, NUL-terminated name, u64 n, n x (f64 x, f64 y, i64 point3D id)."""
+    buf = open(path, "rb").read()
+    (n,), off = struct.unpack_from("<Q", buf, 0), 8
+    rec = np.dtype([("x", "<f8"), ("y", "<f8"), ("id", "<i8")])
+    out = {}
+    for _ in range(n):
+        vals = struct.unpack_from("<idddddddi", buf, off)
+        off += 64
+        end = buf.index(b"\x00", off)
+        name = buf[off:end].decode("utf-8")
+        off = end + 1
+        (m,) = struct.unpack_from("<Q", buf, off)
+        off += 8
+        pts = np.frombuffer(buf, dtype=rec, count=m, offset=off)
+        off += 24 * m
+        out[vals[0]] = ColmapImage(vals[0], np.array(vals[1:5]), np.array(vals[5:8]), vals[8], name,
+                                   np.column_stack([pts["x"], pts["y"]]) if m else np.zeros((0, 2)),
+                                   pts["id"].astype(np.int64))
+    return out
+
+
+def read_colmap_points3d_bin(path: str):
+    """points3D.bin (scene/colmap_loader.py:149-177) -> (xyz [N,3] f64, rgb [N,3] f64, error [N,1] f64)."""
+    buf = open(path, "rb").read()
+    (n,), off = struct.unpack_from("<Q", buf, 0), 8
+    xyz, rgb, err = np.empty((n, 3)), np.empty((n, 3)), np.empty((n, 1))
+    for i in range(n):
+        v = struct.unpack_from("<QdddBBBd", buf, off)
+        off += 43
+        (track,) = struct.unpack_from("<Q", buf, off)
+        off += 8 + 8 * track
+        xyz[i], rgb[i], err[i] = v[1:4], v[4:7], v[7]
+    return xyz, rgb, err
+
+
+def readColmapCameras(cam_extrinsics: Dict[int, ColmapImage], cam_intrinsics: Dict[int, ColmapCamera],
+                      images_folder: str) -> List[CameraInfo]:
+    """scene/dataset_readers.py:81-134: only undistorted (SIMPLE_PINHOLE / PINHOLE) cameras."""
+    from PIL import Image
+    infos = []
+    for key in cam_extrinsics:
+        extr = cam_extrinsics[key]
+        intr = cam_intrinsics[extr.camera_id]
+        R = np.transpose(qvec2rotmat(extr.qvec))
+        T = np.array(extr.tvec)
+        if intr.model == "SIMPLE_PINHOLE":
+            fovy, fovx = focal2fov(intr.params[0], intr.height), focal2fov(intr.params[0], intr.width)
+        elif intr.model == "PINHOLE":
+            fovy, fovx = focal2fov(intr.params[1], intr.height), focal2fov(intr.params[0], intr.width)
+        else:
+            raise AssertionError("Colmap camera model not handled: only undistorted datasets (PINHOLE or SIMPLE_PINHOLE "
+                                 "cameras) supported!")
+        image_path = os.path.join(images_folder, os.path.basename(extr.name))
+        infos.append(CameraInfo(uid=intr.id, R=R, T=T, FovY=fovy, FovX=fovx, image=Image.open(image_path),
+                                image_path=image_path, image_name=os.path.basename(image_path).split(".")[0],
+                                width=intr.width, height=intr.height))
+    return infos
+
+
+def readColmapSceneInfo(path: str, images: Optional[str], eval: bool, llffhold: int = 8) -> Dict:
+    """scene/dataset_readers.py:175-222 for binary models: cameras sorted by image name, every llffhold-th one held out
+    when eval, the normalisation of the training cameras, the sparse points as the initial cloud."""
+    sparse = os.path.join(path, "sparse/0")
+    extr = read_colmap_images_bin(os.path.join(sparse, "images.bin"))
+    intr = read_colmap_cameras_bin(os.path.join(sparse, "cameras.bin"))
+    cams = sorted(readColmapCameras(extr, intr, os.path.join(path, "images" if images is None else images)),
+                  key=lambda c: c.image_name)
+    train = [c for i, c in enumerate(cams) if not eval or i % llffhold != 0]
+    test = [c for i, c in enumerate(cams) if eval and i % llffhold == 0]
+    cloud = None
+    pts = os.path.join(sparse, "points3D.bin")
+    if os.path.exists(pts):
+        xyz, rgb, _ = read_colmap_points3d_bin(pts)
+        cloud = dict(points=xyz, colors=rgb / 255.0, normals=np.zeros_like(xyz))  # storePly / fetchPly round trip (:136-173)
+    return dict(train_cameras=train, test_cameras=test, nerf_normalization=getNerfppNorm(train), point_cloud=cloud)

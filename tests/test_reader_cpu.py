@@ -69,3 +69,57 @@ def test_scene_info_lr_schedule_and_init_cloud(tmp_path, monkeypatch):
     assert cloud["points"].shape == (1000, 3) and np.abs(cloud["points"]).max() <= 1.3 and not cloud["normals"].any()
     assert np.allclose(GOLD["sh_in"] * 0.28209479177387814 + 0.5, GOLD["sh2rgb"])  # SH2RGB as used for the colours
     assert cloud["colors"].min() >= 0.5 and cloud["colors"].max() <= 0.5 + 0.28209479177387814 / 255.0 + 1e-12
+
+
+COLMAP = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_colmap.npz"))
+
+
+def _write_colmap(root):
+    sparse = os.path.join(root, "sparse", "0")
+    os.makedirs(sparse, exist_ok=True)
+    for fn, key in (("cameras.bin", "cameras_bin"), ("images.bin", "images_bin"), ("points3D.bin", "points3D_bin")):
+        open(os.path.join(sparse, fn), "wb").write(COLMAP[key].tobytes())
+    return sparse
+
+
+def test_colmap_binary_readers_match_the_reference_loader(tmp_path):
+    """tests/golden/ref_colmap.npz = what the reference's scene/colmap_loader.py read from the same bytes."""
+    sparse = _write_colmap(str(tmp_path))
+    intr = dr.read_colmap_cameras_bin(os.path.join(sparse, "cameras.bin"))
+    assert sorted(intr) == COLMAP["cam_ids"].tolist()
+    for cid, c in intr.items():
+        assert c.model == str(COLMAP[f"cam{cid}_model"]) and [c.width, c.height] == COLMAP[f"cam{cid}_wh"].tolist()
+        assert np.array_equal(c.params, COLMAP[f"cam{cid}_params"])
+    extr = dr.read_colmap_images_bin(os.path.join(sparse, "images.bin"))
+    assert list(extr) == COLMAP["img_ids"].tolist()  # file order is kept
+    for iid, im in extr.items():
+        assert np.array_equal(im.qvec, COLMAP[f"img{iid}_qvec"]) and np.array_equal(im.tvec, COLMAP[f"img{iid}_tvec"])
+        assert im.camera_id == int(COLMAP[f"img{iid}_camera_id"]) and im.name == str(COLMAP[f"img{iid}_name"])
+        assert np.array_equal(im.xys.reshape(-1, 2), COLMAP[f"img{iid}_xys"])
+        assert np.array_equal(im.point3D_ids, COLMAP[f"img{iid}_p3d"])
+        assert np.allclose(dr.qvec2rotmat(im.qvec), COLMAP[f"img{iid}_R"], rtol=0, atol=1e-15)
+    xyz, rgb, err = dr.read_colmap_points3d_bin(os.path.join(sparse, "points3D.bin"))
+    assert np.array_equal(xyz, COLMAP["xyz"]) and np.array_equal(rgb, COLMAP["rgb"]) and np.array_equal(err, COLMAP["err"])
+
+
+def test_colmap_scene_info(tmp_path):
+    _write_colmap(str(tmp_path))
+    os.makedirs(os.path.join(tmp_path, "images"))
+    for iid in COLMAP["img_ids"].tolist():
+        name = os.path.basename(str(COLMAP[f"img{iid}_name"]))
+        wh = COLMAP[f"cam{int(COLMAP[f'img{iid}_camera_id'])}_wh"]
+        Image.new("RGB", (int(wh[0]), int(wh[1])), (10 * (iid % 20), 40, 90)).save(os.path.join(tmp_path, "images", name))
+    info = dr.readColmapSceneInfo(str(tmp_path), None, eval=True, llffhold=2)
+    names = [c.image_name for c in info["train_cameras"] + info["test_cameras"]]
+    assert sorted(names) == ["view_a", "view_b", "view_c", "view_d", "view_e"]
+    assert [c.image_name for c in info["test_cameras"]] == ["view_a", "view_c", "view_e"]  # every 2nd of the sorted list
+    by_name = {c.image_name: c for c in info["train_cameras"] + info["test_cameras"]}
+    cam = by_name["view_b"]  # image id 10, PINHOLE camera 1
+    assert np.allclose(cam.R, COLMAP["img10_R"].T) and np.array_equal(cam.T, COLMAP["img10_tvec"])
+    assert abs(cam.FovX - 2 * np.arctan(64 / (2 * 70.0))) < 1e-12 and abs(cam.FovY - 2 * np.arctan(48 / (2 * 72.5))) < 1e-12
+    simple = by_name["view_a"]  # SIMPLE_PINHOLE camera 2
+    assert abs(simple.FovX - 2 * np.arctan(50 / (2 * 55.0))) < 1e-12 and abs(simple.FovY - 2 * np.arctan(40 / (2 * 55.0))) < 1e-12
+    assert info["point_cloud"]["points"].shape == (17, 3) and info["point_cloud"]["colors"].max() <= 1.0
+    assert len(dr.readColmapSceneInfo(str(tmp_path), None, eval=False)["train_cameras"]) == 5
+    d = dr.camera_from_info(cam)
+    assert d["image_width"] == 64 and d["image_height"] == 48 and d["gt_alpha_mask"].min() == 1.0
