@@ -332,6 +332,31 @@ specular_weights_kernel(int N, const float4* __restrict__ table, const float* __
   }
 }
 
+// W2[o][i] = W[o][i] / divisor[texel i of o's window] (markers < 0 kept).  With divisor = the forward's weight sums this
+// folds the d(rgb / wsum) division of the normalised filter's backward into its (cached) table: the backward then gathers
+// the incoming gradient directly, one launch instead of a division pass + a gather.
+__global__ void __launch_bounds__(256)
+specular_divide_weights_kernel(int N, const float* __restrict__ bounds, const uint32_t* __restrict__ offsets,
+                               const float* __restrict__ W, const float* __restrict__ divisor, float* __restrict__ W2) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= 6 * N * N) return;
+  const float4* b4 = reinterpret_cast<const float4*>(bounds + 24 * (size_t)o);
+  for (int s = 0; s < 6; ++s) {
+    const float4 b = b4[s];
+    const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
+    if (xmin > xmax || ymin > ymax) continue;
+    const int wd = xmax - xmin + 1, n = wd * (ymax - ymin + 1);
+    const float inv = 1.0f / (float)wd;
+    const uint32_t base = offsets[6 * (size_t)o + s];
+    for (int i = lane; i < n; i += 64) {
+      const int yy = (int)(((float)i + 0.5f) * inv), xx = i - yy * wd;
+      const float w = W[(size_t)base + i];
+      W2[(size_t)base + i] = w >= 0.0f ? w / divisor[(s * N + ymin + yy) * N + xmin + xx] : w;
+    }
+  }
+}
+
 // forward: out[o] = (sum tex[in] * f * area(in) / 4, sum of weights); backward: g_in[o] = sum g[other].rgb * f * area(o) / 4
 // kNorm: the forward writes rgb / wsum to dst [.,3] and wsum to `wsum_out` (the division
 // ops.py:458 does in torch); the backward then reads a 3-channel gradient that the caller has
@@ -1063,6 +1088,16 @@ int gigs_specular_weights(int res, const float* bounds, const uint32_t* offsets,
     hipLaunchKernelGGL(gigs::specular_weights_kernel<true>, grid, dim3(256), 0, s, res, table, bounds, offsets, roughness, costheta_cutoff, weights);
   else
     hipLaunchKernelGGL(gigs::specular_weights_kernel<false>, grid, dim3(256), 0, s, res, table, bounds, offsets, roughness, costheta_cutoff, weights);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_specular_weights_divide(int res, const float* bounds, const uint32_t* offsets, const float* weights,
+                                 const float* texel_divisor, float* out_weights, void* stream) {
+  if (res <= 0 || !bounds || !offsets || !weights || !texel_divisor || !out_weights)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "specular_weights_divide: bad argument");
+  hipLaunchKernelGGL(gigs::specular_divide_weights_kernel, dim3((6 * res * res + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     res, bounds, offsets, weights, texel_divisor, out_weights);
   PBR_CHECK_LAUNCH();
   return 0;
 }

@@ -55,6 +55,7 @@ SIGNATURES = {
     "gigs_specular_cubemap_fwd": (_i, [_i, _f, _f, _fl, _fl, _f, C.c_void_p]),
     "gigs_specular_cubemap_bwd": (_i, [_i, _f, _f, _fl, _fl, _f, C.c_void_p]),
     "gigs_specular_weights": (_i, [_i, _f, _f, _fl, _fl, _i, _f, C.c_void_p]),
+    "gigs_specular_weights_divide": (_i, [_i, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_specular_cubemap_fwd_w": (_i, [_i, _f, _f, _f, _f, _i, _f, _f, C.c_void_p]),
     "gigs_specular_cubemap_bwd_w": (_i, [_i, _f, _f, _f, _i, _f, _i, _f, C.c_void_p]),
     "gigs_cubemap_mip_fwd": (_i, [_i, _i, _f, _f, C.c_void_p]),

@@ -150,11 +150,15 @@ class _specular_cubemap_normalized(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         bounds, wsum = ctx.saved_tensors
-        d = (_gpu(dout, "dout") / wsum).contiguous()  # d(rgb / w) / d(rgb); w does not depend on the cubemap
+        if len(ctx.tables) > 3 and ctx.tables[3] is not None:
+            # the 1 / wsum of d(rgb / w) / d(rgb) is folded into the cached table (gigs_specular_weights_divide)
+            d, table = _gpu(dout, "dout"), ctx.tables[3]
+        else:
+            d, table = (_gpu(dout, "dout") / wsum).contiguous(), ctx.tables[2]  # w does not depend on the cubemap
         g = torch.empty((6, ctx.res, ctx.res, 3), dtype=torch.float32, device=d.device)
         with torch.cuda.device(d.device):
             gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
-                                                            ctx.tables[2].data_ptr(), _avg_window(ctx.tables, ctx.res),
+                                                            table.data_ptr(), _avg_window(ctx.tables, ctx.res),
                                                             d.data_ptr(), 1, g.data_ptr(), _stream()),
                            "specular_cubemap_bwd_w")
         return g, None, None
@@ -175,7 +179,7 @@ def _weight_tables(res, roughness, cutoff, device):
         h = torch.where(b[..., 2] <= b[..., 3], b[..., 3] - b[..., 2] + 1, torch.zeros_like(b[..., 0]))
         cnt = (w * h).to(torch.int64).reshape(-1)
         total = int(cnt.sum().item())
-        used = sum(t[1].numel() * 8 for t in _weightTables.values() if t is not None)
+        used = sum(t[1].numel() * (12 if t[3] is not None else 8) for t in _weightTables.values() if t is not None)
         if total == 0 or total >= 2 ** 31 or used + total * 8 > _TABLE_MAX_BYTES:
             _weightTables[key] = None
         else:
@@ -188,7 +192,22 @@ def _weight_tables(res, roughness, cutoff, device):
                                                               float(cos_cut), swap, wt.data_ptr(), _stream()),
                                    "specular_weights")
                     tabs.append(wt)
-            _weightTables[key] = (offsets, tabs[0], tabs[1])
+            scaled = None
+            if os.environ.get("GIGS_SPEC_PRESCALED", "1") == "1" and used + total * 12 <= _TABLE_MAX_BYTES:
+                # weight sums of the forward (independent of the cubemap's values), then the backward table divided by them
+                with torch.cuda.device(device):
+                    ones = torch.ones((6, res, res, 3), dtype=torch.float32, device=device)
+                    tmp = torch.empty_like(ones)
+                    wsum = torch.empty((6, res, res), dtype=torch.float32, device=device)
+                    gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(res, ones.data_ptr(), bounds.data_ptr(),
+                                                                    offsets.data_ptr(), tabs[0].data_ptr(), 0,
+                                                                    tmp.data_ptr(), wsum.data_ptr(), _stream()),
+                                   "specular_cubemap_fwd_w")
+                    scaled = torch.empty(total, dtype=torch.float32, device=device)
+                    gigs_lib.check(_lib.gigs_specular_weights_divide(res, bounds.data_ptr(), offsets.data_ptr(),
+                                                                     tabs[1].data_ptr(), wsum.data_ptr(), scaled.data_ptr(),
+                                                                     _stream()), "specular_weights_divide")
+            _weightTables[key] = (offsets, tabs[0], tabs[1], scaled)
     return _weightTables[key]
 
 

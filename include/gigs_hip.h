@@ -152,6 +152,11 @@ int gigs_specular_cubemap_bwd(int res, const float* bounds, const float* grad_ou
  * bit-identical to the table-free entry points up to summation order). */
 int gigs_specular_weights(int res, const float* bounds, const uint32_t* offsets, float roughness,
                           float costheta_cutoff, int swap_roles, float* weights, void* stream);
+/* out_weights[o][i] = weights[o][i] / texel_divisor[texel i of o's window] (negative markers kept), texel_divisor
+ * [6,res,res].  Applied to the role-swapped table with the forward's weight sums it yields a table whose gather of the
+ * incoming gradient IS the backward of the normalised filter (no separate division by wsum). */
+int gigs_specular_weights_divide(int res, const float* bounds, const uint32_t* offsets, const float* weights,
+                                 const float* texel_divisor, float* out_weights, void* stream);
 /* wsum_out == NULL: out = [6,res,res,4] (rgb, weight sum) like the table-free entry point;
  * wsum_out != NULL: out = [6,res,res,3] = rgb / wsum (the division of ops.py:458 folded in) and the
  * weight sums go to wsum_out [6,res,res].  grad_is_rgb: grad_out is [6,res,res,3] (already divided
