@@ -609,7 +609,7 @@ cubemap_mip_fwd_kernel(int r, int C, const float* __restrict__ in, float* __rest
 }
 
 __global__ void __launch_bounds__(256)
-cubemap_mip_bwd_kernel(int r, const float* __restrict__ dout, float* __restrict__ din) {
+cubemap_mip_bwd_kernel(int r, const float* __restrict__ dout, float* __restrict__ din, const float* __restrict__ add) {
   const int res = 2 * r;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 6 * res * res) return;
@@ -632,6 +632,9 @@ cubemap_mip_bwd_kernel(int r, const float* __restrict__ dout, float* __restrict_
         v.y += (p[1] * 0.25f) * t.w[k];
         v.z += (p[2] * 0.25f) * t.w[k];
       }
+  }
+  if (add) {  // the level's own gradient (it also feeds a filter): summed here instead of by a separate pass
+    v.x += add[3 * (size_t)i]; v.y += add[3 * (size_t)i + 1]; v.z += add[3 * (size_t)i + 2];
   }
   din[3 * (size_t)i] = v.x; din[3 * (size_t)i + 1] = v.y; din[3 * (size_t)i + 2] = v.z;
 }
@@ -1143,7 +1146,17 @@ int gigs_cubemap_mip_bwd(int res_out, const float* dout, float* din, void* strea
   if (res_out <= 0 || !dout || !din) return gigs_internal_fail(GIGS_ERR_INVALID, "cubemap_mip_bwd: bad argument");
   const int res = 2 * res_out;
   void* tok; gigs_internal_stage_begin(17, stream, &tok);
-  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din);
+  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din, (const float*)nullptr);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_cubemap_mip_bwd_add(int res_out, const float* dout, const float* add, float* din, void* stream) {
+  if (res_out <= 0 || !dout || !add || !din) return gigs_internal_fail(GIGS_ERR_INVALID, "cubemap_mip_bwd_add: bad argument");
+  const int res = 2 * res_out;
+  void* tok; gigs_internal_stage_begin(17, stream, &tok);
+  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din, add);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;

@@ -59,6 +59,7 @@ SIGNATURES = {
     "gigs_specular_cubemap_fwd_w": (_i, [_i, _f, _f, _f, _f, _i, _f, _f, C.c_void_p]),
     "gigs_specular_cubemap_bwd_w": (_i, [_i, _f, _f, _f, _i, _f, _i, _f, C.c_void_p]),
     "gigs_cubemap_mip_fwd": (_i, [_i, _i, _f, _f, C.c_void_p]),
+    "gigs_cubemap_mip_bwd_add": (_i, [_i, _f, _f, _f, C.c_void_p]),
     "gigs_cubemap_mip_bwd": (_i, [_i, _f, _f, C.c_void_p]),
     "gigs_shade_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
                             C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, C.c_void_p]),

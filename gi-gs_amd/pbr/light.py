@@ -2,6 +2,7 @@
 pre-filter run in libgigs_hip.so.  Image I/O (cv2) parts of the reference class are out of scope."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -57,6 +58,51 @@ class cubemap_mip(torch.autograd.Function):
         return out
 
 
+class _mip_chain(torch.autograd.Function):
+    """base -> (mip1, ..., mipN) by repeated cubemap_mip, as ONE autograd node: each level also feeds a GGX filter (and the
+    last one the diffuse filter), so op-by-op autograd runs a separate accumulation pass per level before every
+    cubemap_mip backward; here the level's own gradient is added inside the mip backward kernel
+    (gigs_cubemap_mip_bwd_add).  Same arithmetic as the chain of cubemap_mip calls."""
+
+    @staticmethod
+    def forward(ctx, base, n_levels):
+        if not base.is_cuda:
+            raise RuntimeError("cubemap must be a CUDA/HIP tensor: pbr (gigs-hip) has no CPU path")
+        cur = base.contiguous().float()
+        outs = []
+        with torch.cuda.device(cur.device):
+            s = torch.cuda.current_stream().cuda_stream
+            for _ in range(n_levels):
+                r = cur.shape[1] // 2
+                nxt = torch.empty((6, r, r, 3), dtype=torch.float32, device=cur.device)
+                gigs_lib.check(_lib.gigs_cubemap_mip_fwd(r, 3, cur.data_ptr(), nxt.data_ptr(), s), "cubemap_mip_fwd")
+                outs.append(nxt)
+                cur = nxt
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        # walk back from the coarsest level; gs[k] is the gradient level k+1 receives from its filters (None = zero)
+        gs = [None if g is None else g.contiguous().float() for g in gs]
+        dev = next(g for g in gs if g is not None).device
+        G = gs[-1]
+        if G is None:
+            raise RuntimeError("_mip_chain.backward: the coarsest level received no gradient")
+        with torch.cuda.device(dev):
+            s = torch.cuda.current_stream().cuda_stream
+            for k in range(len(gs) - 1, -1, -1):
+                r = G.shape[1]
+                fine = torch.empty((6, 2 * r, 2 * r, 3), dtype=torch.float32, device=dev)
+                add = gs[k - 1] if k > 0 else None
+                if add is not None:
+                    gigs_lib.check(_lib.gigs_cubemap_mip_bwd_add(r, G.data_ptr(), add.data_ptr(), fine.data_ptr(), s),
+                                   "cubemap_mip_bwd_add")
+                else:
+                    gigs_lib.check(_lib.gigs_cubemap_mip_bwd(r, G.data_ptr(), fine.data_ptr(), s), "cubemap_mip_bwd")
+                G = fine
+        return G, None
+
+
 class CubemapLight(nn.Module):
     LIGHT_MIN_RES = 16
     MIN_ROUGHNESS = 0.08
@@ -87,8 +133,15 @@ class CubemapLight(nn.Module):
 
     def build_mips(self, cutoff: float = 0.99) -> None:
         self.specular = [self.base]
-        while self.specular[-1].shape[1] > self.LIGHT_MIN_RES:
-            self.specular += [cubemap_mip.apply(self.specular[-1])]
+        if os.environ.get("GIGS_MIP_CHAIN", "1") == "1" and self.base.shape[3] == 3:
+            n_levels, r = 0, self.base.shape[1]
+            while r > self.LIGHT_MIN_RES:
+                n_levels, r = n_levels + 1, r // 2
+            if n_levels:
+                self.specular += list(_mip_chain.apply(self.base, n_levels))
+        else:
+            while self.specular[-1].shape[1] > self.LIGHT_MIN_RES:
+                self.specular += [cubemap_mip.apply(self.specular[-1])]
         self.diffuse = diffuse_cubemap(self.specular[-1])
         for idx in range(len(self.specular) - 1):
             roughness = (idx / (len(self.specular) - 2)) * (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) + self.MIN_ROUGHNESS

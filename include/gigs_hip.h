@@ -171,6 +171,9 @@ int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* of
  * bilinear cube lookup of 0.25*dout at every fine texel direction, dout [6,r,r,3] -> din [6,2r,2r,3]. */
 int gigs_cubemap_mip_fwd(int res_out, int channels, const float* in, float* out, void* stream);
 int gigs_cubemap_mip_bwd(int res_out, const float* dout, float* din, void* stream);
+/* din = add + the above (add [6,2r,2r,3]: the gradient the fine level receives from its other consumer, so that the
+ * chain base <- mip1 <- ... <- mipN is walked back without separate accumulation passes). */
+int gigs_cubemap_mip_bwd_add(int res_out, const float* dout, const float* add, float* din, void* stream);
 
 /* pbr_shading (pbr/shade.py:108-241) fused into one kernel.  normals/view_dirs/albedo [H,W,3],
  * roughness/occlusion/metallic [H,W,1] (occlusion, metallic, background may be NULL), mask = bool

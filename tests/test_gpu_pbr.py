@@ -295,3 +295,34 @@ def test_fused_gbuffer_post_matches_torch_chain_forward_and_backward():
     for i in (0, 2, 4):
         assert torch.allclose(got[i], ref[i], rtol=1e-6, atol=1e-6), i
     assert (b.grad - a.grad).abs().max().item() <= 1e-5 * a.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_build_mips_fused_chain_and_prescaled_tables_match_op_by_op(monkeypatch):
+    """build_mips with the one-node mip chain and the 1/wsum-folded backward tables (defaults) against the op-by-op
+    formulation (GIGS_MIP_CHAIN=0, division pass + unscaled table): same light, same gradient of a random functional."""
+    import pbr
+    from pbr.renderutils import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    base0 = torch.rand(6, 64, 64, 3, device=dev) + 0.1
+    ws = None
+    results = []
+    for chain, prescaled in (("0", "0"), ("1", "1")):
+        monkeypatch.setenv("GIGS_MIP_CHAIN", chain)
+        monkeypatch.setenv("GIGS_SPEC_PRESCALED", prescaled)
+        ops._weightTables.clear()
+        light = pbr.CubemapLight(base_res=64, device=dev)
+        with torch.no_grad():
+            light.base.copy_(base0)
+        light.build_mips()
+        outs = [light.diffuse] + list(light.specular)
+        if ws is None:
+            ws = [torch.randn_like(o) for o in outs]
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        results.append(([o.detach().clone() for o in outs], light.base.grad.detach().clone()))
+    ops._weightTables.clear()
+    (o0, g0), (o1, g1) = results
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)  # the forward runs the same kernels
+    assert (g0 - g1).abs().max().item() <= 2e-6 * g0.abs().max().item()
