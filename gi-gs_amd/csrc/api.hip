@@ -422,6 +422,18 @@ int gigs_depth_to_normal(int width, int height, float focal_x, float focal_y,
   return 0;
 }
 
+int gigs_derive_normal(int width, int height, float focal_x, float focal_y, const float* viewmatrix, const float* depth,
+                       float sigma_color, float sigma_x, float sigma_y, float* normal_from_depth, float* depth_pos_filter,
+                       void* stream) {
+  if (width <= 1 || height <= 1 || !viewmatrix || !depth || !normal_from_depth || !depth_pos_filter)
+    return fail(GIGS_ERR_INVALID, "derive_normal: bad argument (images must be larger than 1x1)");
+  StageScope sc(kDepthToNormal, (hipStream_t)stream);
+  gigs::launch_derive_normal_fused(width, height, focal_x, focal_y, viewmatrix, sigma_color, sigma_x, sigma_y, depth,
+                                   normal_from_depth, depth_pos_filter, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius, float bias,
               float thick, float delta, int step, int start, const float* normal_view,
               const float* pos, float* occlusion, void* stream) {

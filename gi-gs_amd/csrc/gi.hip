@@ -879,6 +879,170 @@ void launch_bilateral3x3(int C, int H, int W, float sigma_color, float sx, float
   else if (C == 3) hipLaunchKernelGGL(bilateral3x3_kernel<3>, grid, dim3(256), 0, s, H, W, kk, in, out);
 }
 
+// ------------------------------------------------------------------------------------------
+// The four passes between the blend kernel and SSAO as one launch
+// ------------------------------------------------------------------------------------------
+// GaussianRasterizer.forward (R/.../__init__.py:475-517) chains median3x3(depth) -> depth_to_normal -> bilateral3x3
+// (normal) and median3x3(depth_pos): four small kernels (0.16 ms) with a launch gap after each, all on the critical path
+// in front of the SSAO march.  Here a 32x8 pixel tile stages the raw depth with a 4-pixel halo in LDS and runs the same
+// stages over shrinking halos (median: 3, normal / position: 1, outputs: 0).  Every stage evaluates exactly the
+// expressions of the stand-alone kernels above (same taps, same padding rules, same operation order), so the outputs are
+// bit-identical to the four-kernel chain (tests/test_gpu_parity.py compares them).
+constexpr int kDnW = 32, kDnH = 8;
+
+__global__ void __launch_bounds__(256)
+derive_normal_fused_kernel(int W, int H, float fx, float fy, const float* __restrict__ vm, BilatK kk,
+                           const float* __restrict__ depth_raw, float* __restrict__ normal_out,
+                           float* __restrict__ pos_filter_out) {
+  __shared__ float s_d[kDnH + 8][kDnW + 8];     // raw depth, halo 4; 0 outside the image (median_blur's zero padding)
+  __shared__ float s_f[kDnH + 6][kDnW + 6];     // median-filtered depth, halo 3
+  __shared__ float s_n[3][kDnH + 2][kDnW + 2];  // depth_to_normal's normal, halo 1
+  __shared__ float s_p[3][kDnH + 2][kDnW + 2];  // depth_to_normal's position, halo 1; 0 outside the image
+  const int x0 = blockIdx.x * kDnW, y0 = blockIdx.y * kDnH;
+  const size_t HW = (size_t)H * W;
+
+  for (int i = threadIdx.x; i < (kDnH + 8) * (kDnW + 8); i += 256) {
+    const int ty = i / (kDnW + 8), tx = i - ty * (kDnW + 8);
+    const int gx = x0 - 4 + tx, gy = y0 - 4 + ty;
+    s_d[ty][tx] = (gx < 0 || gx >= W || gy < 0 || gy >= H) ? 0.0f : depth_raw[(size_t)gy * W + gx];
+  }
+  __syncthreads();
+
+  for (int i = threadIdx.x; i < (kDnH + 6) * (kDnW + 6); i += 256) {  // = median3x3_kernel on the depth plane
+    const int ty = i / (kDnW + 6), tx = i - ty * (kDnW + 6);
+    const int gx = x0 - 3 + tx, gy = y0 - 3 + ty;
+    float r = 0.0f;
+    if (!(gx < 0 || gx >= W || gy < 0 || gy >= H)) {
+      float v[9];
+      bool has_nan = false;
+      int k = 0;
+#pragma unroll
+      for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+          const float t = s_d[ty + 1 + dy][tx + 1 + dx];
+          has_nan |= (t != t);
+          v[k++] = t;
+        }
+      r = has_nan ? __builtin_nanf("") : median9(v);
+    }
+    s_f[ty][tx] = r;
+  }
+  __syncthreads();
+
+  for (int i = threadIdx.x; i < (kDnH + 2) * (kDnW + 2); i += 256) {  // = depth_to_normal_kernel
+    const int ty = i / (kDnW + 2), tx = i - ty * (kDnW + 2);
+    const int x = x0 - 1 + tx, y = y0 - 1 + ty;
+    v3 nrm = {0.0f, 0.0f, 0.0f}, pos = {0.0f, 0.0f, 0.0f};
+    if (!(x < 0 || x >= W || y < 0 || y >= H) && !(x <= 0 || x >= W - 1 || y <= 0 || y >= H - 1)) {
+#define DP(dx, dy) s_f[ty + 2 + (dy)][tx + 2 + (dx)]
+      const float depth_thresh = 0.01f;
+      const float depth = DP(0, 0);
+      const float cx = float(W) / 2.0f, cy = float(H) / 2.0f;
+      pos = get_position(x, y, cx, cy, fx, fy, depth);
+      bool ok = !(depth < depth_thresh);
+      const int pad = 2;
+      for (int dx = -pad; ok && dx < pad + 1; ++dx) {
+        if (x + dx < 0 || x + dx > W - 1) { ok = false; break; }
+        for (int dy = -pad; dy < pad + 1; ++dy) {
+          if (y + dy < 0 || y + dy > H - 1) { ok = false; break; }
+          if (DP(dx, dy) < depth_thresh) { ok = false; break; }
+        }
+      }
+      if (ok) {
+        const v3 pos_aa = get_position(x, y - 1, cx, cy, fx, fy, DP(0, -1));
+        const v3 pos_bb = get_position(x + 1, y, cx, cy, fx, fy, DP(1, 0));
+        const v3 pos_cc = get_position(x, y + 1, cx, cy, fx, fy, DP(0, 1));
+        const v3 pos_dd = get_position(x - 1, y, cx, cy, fx, fy, DP(-1, 0));
+        const v3 pos_ab = get_position(x + 1, y - 1, cx, cy, fx, fy, DP(1, -1));
+        const v3 pos_bc = get_position(x + 1, y + 1, cx, cy, fx, fy, DP(1, 1));
+        const v3 pos_cd = get_position(x - 1, y + 1, cx, cy, fx, fy, DP(-1, 1));
+        const v3 pos_da = get_position(x - 1, y - 1, cx, cy, fx, fy, DP(-1, -1));
+        const v3 edge_a = pos_da - pos_ab, edge_b = pos_ab - pos_bc, edge_c = pos_bc - pos_cd, edge_d = pos_cd - pos_da;
+        const v3 edge_ac = pos_cc - pos_aa, edge_bd = pos_dd - pos_bb;
+        const v3 edge_cdab = pos_ab - pos_cd, edge_bcad = pos_da - pos_bc;
+        const v3 n1 = cross3(edge_a, edge_d), n2 = cross3(edge_d, edge_c), n3 = cross3(edge_c, edge_b);
+        const v3 n4 = cross3(edge_b, edge_a), n5 = cross3(edge_ac, edge_bd), n6 = cross3(edge_bcad, edge_cdab);
+        const v3 sum = normalize3(n1) + normalize3(n2) + normalize3(n3) + normalize3(n4) + normalize3(n5) + normalize3(n6);
+        const float inv6 = 1.0f / 6.0f;
+        const v3 normal = sum * inv6;
+        nrm = {vm[0] * normal.x + vm[1] * normal.y + vm[2] * normal.z, vm[4] * normal.x + vm[5] * normal.y + vm[6] * normal.z,
+               vm[8] * normal.x + vm[9] * normal.y + vm[10] * normal.z};
+      }
+#undef DP
+    }
+    s_n[0][ty][tx] = nrm.x; s_n[1][ty][tx] = nrm.y; s_n[2][ty][tx] = nrm.z;
+    s_p[0][ty][tx] = pos.x; s_p[1][ty][tx] = pos.y; s_p[2][ty][tx] = pos.z;
+  }
+  __syncthreads();
+
+  const int lx = threadIdx.x & (kDnW - 1), ly = threadIdx.x / kDnW;
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= W || y >= H) return;
+  const size_t p = (size_t)y * W + x;
+  {  // = bilateral3x3_kernel<3> on the normal
+    float ctr[3], num[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < 3; c++) ctr[c] = s_n[c][ly + 1][lx + 1];
+    float den = 0.0f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        int yy = y + dy, xx = x + dx;
+        yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);  // reflect
+        xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+        float tap[3], dist = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          tap[c] = s_n[c][yy - y0 + 1][xx - x0 + 1];
+          dist += fabsf(tap[c] - ctr[c]);
+        }
+        const float color_k = expf(kk.color_scale * (dist * dist));
+        const float k = (kk.ky[dy + 1] * kk.kx[dx + 1]) * color_k;
+#pragma unroll
+        for (int c = 0; c < 3; c++) num[c] += tap[c] * k;
+        den += k;
+      }
+#pragma unroll
+    for (int c = 0; c < 3; c++) normal_out[c * HW + p] = num[c] / den;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {  // = median3x3_kernel on the three position planes
+    float v[9];
+    bool has_nan = false;
+    int k = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const float t = s_p[c][ly + 1 + dy][lx + 1 + dx];
+        has_nan |= (t != t);
+        v[k++] = t;
+      }
+    pos_filter_out[c * HW + p] = has_nan ? __builtin_nanf("") : median9(v);
+  }
+}
+
+void launch_derive_normal_fused(int W, int H, float fx, float fy, const float* viewmatrix, float sigma_color, float sx,
+                                float sy, const float* depth_raw, float* normal_out, float* pos_filter_out, hipStream_t s) {
+  BilatK kk;
+  auto k1d = [](float sigma, float* k) {
+    float sum = 0;
+    for (int i = 0; i < 3; i++) {
+      const float xv = (float)(i - 1);
+      k[i] = expf(-(xv * xv) / (2.0f * sigma * sigma));
+      sum += k[i];
+    }
+    for (int i = 0; i < 3; i++) k[i] /= sum;
+  };
+  k1d(sy, kk.ky);
+  k1d(sx, kk.kx);
+  kk.color_scale = -0.5f / (sigma_color * sigma_color);
+  hipLaunchKernelGGL(derive_normal_fused_kernel, dim3((W + kDnW - 1) / kDnW, (H + kDnH - 1) / kDnH), dim3(256), 0, s, W, H, fx,
+                     fy, viewmatrix, kk, depth_raw, normal_out, pos_filter_out);
+}
+
 // diagnostic: fast shared-reciprocal division vs the compiler's IEEE division
 __global__ void __launch_bounds__(256)
 selftest_div2_kernel(int n, const float* __restrict__ nx, const float* __restrict__ ny,

@@ -271,5 +271,7 @@ void launch_median3x3_bwd(int C, int H, int W, const float* in, const float* gou
                           hipStream_t s);
 void launch_bilateral3x3(int C, int H, int W, float sigma_color, float sx, float sy,
                          const float* in, float* out, hipStream_t s);
+void launch_derive_normal_fused(int W, int H, float fx, float fy, const float* viewmatrix, float sigma_color, float sx,
+                                float sy, const float* depth_raw, float* normal_out, float* pos_filter_out, hipStream_t s);
 
 }  // namespace gigs

@@ -557,18 +557,24 @@ class GaussianRasterizer(nn.Module):
 
         focal_x = raster_settings.image_width / (2.0 * raster_settings.tanfovx)
         focal_y = raster_settings.image_height / (2.0 * raster_settings.tanfovy)
-        if derive_normal:
-            depth_filter = filters.median_blur(depth.detach()[None, ...], (3, 3))[0]
-            normal_from_depth, depth_pos = _C.depth_to_normal(
-                raster_settings.image_width, raster_settings.image_height, focal_x, focal_y,
-                raster_settings.viewmatrix, depth_filter)
+        W_, H_ = int(raster_settings.image_width), int(raster_settings.image_height)
+        if derive_normal and W_ > 1 and H_ > 1 and os.environ.get("GIGS_FUSED_DERIVE", "1") == "1":
+            # the four passes below as one launch (gigs_derive_normal; bit-identical, tests/test_gpu_parity.py)
+            normal_from_depth, depth_pos_filter = _derive_normal(W_, H_, focal_x, focal_y, raster_settings.viewmatrix,
+                                                                 depth.detach())
         else:
-            normal_from_depth = torch.zeros_like(out_normal)
-            depth_pos = torch.zeros_like(out_normal)
+            if derive_normal:
+                depth_filter = filters.median_blur(depth.detach()[None, ...], (3, 3))[0]
+                normal_from_depth, depth_pos = _C.depth_to_normal(
+                    raster_settings.image_width, raster_settings.image_height, focal_x, focal_y,
+                    raster_settings.viewmatrix, depth_filter)
+            else:
+                normal_from_depth = torch.zeros_like(out_normal)
+                depth_pos = torch.zeros_like(out_normal)
 
-        normal_from_depth = filters.bilateral_blur(normal_from_depth[None, ...], (3, 3), 1, (3, 3))[0]
+            normal_from_depth = filters.bilateral_blur(normal_from_depth[None, ...], (3, 3), 1, (3, 3))[0]
 
-        depth_pos_filter = filters.median_blur(depth_pos[None, ...], (3, 3))[0]
+            depth_pos_filter = filters.median_blur(depth_pos[None, ...], (3, 3))[0]
         occlusion = _C.SSAO(
             raster_settings.image_width, raster_settings.image_height, focal_x, focal_y,
             raster_settings.radius, raster_settings.bias, raster_settings.thick, raster_settings.delta,
@@ -576,6 +582,20 @@ class GaussianRasterizer(nn.Module):
 
         return (color, radii, opacity_map, depth, normal_from_depth, out_normal, occlusion, albedo_map,
                 roughness_map, metallic_map, out_normal_view, depth_pos_filter)
+
+
+def _derive_normal(width, height, focal_x, focal_y, viewmatrix, depth):
+    """median3x3(depth) -> depth_to_normal -> bilateral3x3(normal, 1, (3, 3)), median3x3(pos) in one launch."""
+    _need_gpu(depth, "depth")
+    d = depth.contiguous().float()
+    dev = d.device
+    normal = _new("normal_from_depth", (3, height, width), dev)  # every pixel is written
+    pos = _new("depth_pos", (3, height, width), dev)
+    vptr, vkeep = _fptr(viewmatrix, "viewmatrix")
+    with torch.cuda.device(dev):
+        gigs_lib.check(_lib.gigs_derive_normal(width, height, float(focal_x), float(focal_y), vptr, d.data_ptr(), 1.0, 3.0, 3.0,
+                                               normal.data_ptr(), pos.data_ptr(), _stream()), "derive_normal")
+    return normal, pos
 
 
 class _SSR(torch.autograd.Function):

@@ -43,6 +43,7 @@ SIGNATURES = {
                            _i, C.c_void_p]),
     "gigs_mark_visible": (_i, [_i, _f, _f, _f, _f, C.c_void_p]),
     "gigs_depth_to_normal": (_i, [_i, _i, _fl, _fl, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_derive_normal": (_i, [_i, _i, C.c_float, C.c_float, _f, _f, C.c_float, C.c_float, C.c_float, _f, _f, C.c_void_p]),
     "gigs_ssao": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_ssr": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f,
                       C.c_void_p]),

@@ -100,6 +100,13 @@ int gigs_depth_to_normal(int width, int height, float focal_x, float focal_y,
                          float* depth_pos, void* stream);
 
 /* Rasterizer::SSAO (rasterizer_impl.cu:222-253 -> forward.cu:635-724). occlusion = [1,H,W], fully written. */
+/* The chain GaussianRasterizer.forward runs between the blend and SSAO (R/diff_gaussian_rasterization/__init__.py:475-517)
+ * as ONE launch: normal_from_depth = bilateral3x3(depth_to_normal(median3x3(depth)).normal, sigma_color, sigma_x, sigma_y),
+ * depth_pos_filter = median3x3(depth_to_normal(median3x3(depth)).pos).  Bit-identical to calling gigs_median3x3,
+ * gigs_depth_to_normal, gigs_bilateral3x3 and gigs_median3x3 in turn (gigs-hip extension; depth [1,H,W], outputs [3,H,W]). */
+int gigs_derive_normal(int width, int height, float focal_x, float focal_y, const float* viewmatrix, const float* depth,
+                       float sigma_color, float sigma_x, float sigma_y, float* normal_from_depth, float* depth_pos_filter,
+                       void* stream);
 int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius, float bias,
               float thick, float delta, int step, int start, const float* normal_view,
               const float* pos, float* occlusion, void* stream);

@@ -505,3 +505,46 @@ def test_pixel_rounding_is_exact_for_every_float():
     assert lib.gigs_selftest_round(bad.data_ptr(), None) == 0
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+
+
+@pytest.mark.parametrize("W,H", [(176, 144), (161, 127), (33, 9)])
+def test_fused_derive_normal_is_bit_identical_to_the_four_kernel_chain(W, H, monkeypatch):
+    """gigs_derive_normal (one launch) == median3x3 -> depth_to_normal -> bilateral3x3, median3x3 bit for bit, including
+    image borders, empty regions (zero depth), NaN depths and sizes that are not a multiple of the 32x8 tile."""
+    dgr = _dgr()
+    sc = scenes.surface_scene(P=9_000, sh_degree=1, seed=4, scale_mu=0.03)
+    cam = scenes.orbit_camera(1, 5, W, H, radius=3.5)
+    t = {k: tt(sc[k]) for k in GAUSS_KEYS}
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("GIGS_FUSED_DERIVE", fused)
+        st = settings(dgr, cam, 1)
+        out = dgr.GaussianRasterizer(st)(t["means3D"], torch.zeros_like(t["means3D"]), t["opacities"], t["normal"],
+                                         t["albedo"], t["roughness"], t["metallic"], shs=t["shs"], scales=t["scales"],
+                                         rotations=t["rotations"], derive_normal=True)
+        outs.append([o.detach().clone() for o in out])
+    for i, name in ((4, "normal_from_depth"), (11, "depth_pos_filter"), (6, "occlusion")):
+        a, b = outs[0][i], outs[1][i]
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name
+    # the stand-alone entry point on a depth plane with holes and NaNs
+    import ctypes as C
+    import gigs_lib
+    lib = gigs_lib.lib()
+    g = torch.Generator().manual_seed(W * 1000 + H)
+    depth = (torch.rand(1, H, W, generator=g) * 3 + 0.5)
+    depth[:, H // 3: H // 3 + 4, W // 4: W // 2] = 0.0
+    depth[:, H // 2, W // 2] = float("nan")
+    depth = depth.to(DEV)
+    vm = tt(cam["viewmatrix"])
+    fx, fy = focal(cam)
+    df = dgr.filters.median_blur(depth[None], (3, 3))[0]
+    n0, p0 = dgr._C.depth_to_normal(W, H, fx, fy, vm, df)
+    n0 = dgr.filters.bilateral_blur(n0[None], (3, 3), 1, (3, 3))[0]
+    p0 = dgr.filters.median_blur(p0[None], (3, 3))[0]
+    n1, p1 = torch.empty_like(n0), torch.empty_like(p0)
+    gigs_lib.check(lib.gigs_derive_normal(W, H, float(fx), float(fy), vm.data_ptr(), depth.data_ptr(), 1.0, 3.0, 3.0,
+                                          n1.data_ptr(), p1.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "derive_normal")
+    torch.cuda.synchronize()
+    assert torch.equal(n0.view(torch.int32), n1.view(torch.int32))
+    assert torch.equal(p0.view(torch.int32), p1.view(torch.int32))
