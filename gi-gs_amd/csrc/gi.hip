@@ -884,13 +884,17 @@ void launch_bilateral3x3(int C, int H, int W, float sigma_color, float sx, float
 // ------------------------------------------------------------------------------------------
 // GaussianRasterizer.forward (R/.../__init__.py:475-517) chains median3x3(depth) -> depth_to_normal -> bilateral3x3
 // (normal) and median3x3(depth_pos): four small kernels (0.16 ms) with a launch gap after each, all on the critical path
-// in front of the SSAO march.  Here a 32x8 pixel tile stages the raw depth with a 4-pixel halo in LDS and runs the same
+// in front of the SSAO march.  Here a 32x4 pixel tile stages the raw depth with a 4-pixel halo in LDS and runs the same
 // stages over shrinking halos (median: 3, normal / position: 1, outputs: 0).  Every stage evaluates exactly the
 // expressions of the stand-alone kernels above (same taps, same padding rules, same operation order), so the outputs are
-// bit-identical to the four-kernel chain (tests/test_gpu_parity.py compares them).
-constexpr int kDnW = 32, kDnH = 8;
+// bit-identical to the four-kernel chain (tests/test_gpu_parity.py compares them).  Small tiles win: the kernel is
+// latency-bound (four dependent LDS stages), so more, smaller workgroups beat the smaller halo overhead of large ones.
+#ifndef GIGS_DN_H
+#define GIGS_DN_H 4  // measured at 800x800: tile heights 2 / 4 / 8 / 16 / 32 -> 100 / 70 / 97 / 114 / 135 us
+#endif
+constexpr int kDnW = 32, kDnH = GIGS_DN_H, kDnThreads = kDnW * kDnH;
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kDnThreads)
 derive_normal_fused_kernel(int W, int H, float fx, float fy, const float* __restrict__ vm, BilatK kk,
                            const float* __restrict__ depth_raw, float* __restrict__ normal_out,
                            float* __restrict__ pos_filter_out) {
@@ -901,14 +905,14 @@ derive_normal_fused_kernel(int W, int H, float fx, float fy, const float* __rest
   const int x0 = blockIdx.x * kDnW, y0 = blockIdx.y * kDnH;
   const size_t HW = (size_t)H * W;
 
-  for (int i = threadIdx.x; i < (kDnH + 8) * (kDnW + 8); i += 256) {
+  for (int i = threadIdx.x; i < (kDnH + 8) * (kDnW + 8); i += kDnThreads) {
     const int ty = i / (kDnW + 8), tx = i - ty * (kDnW + 8);
     const int gx = x0 - 4 + tx, gy = y0 - 4 + ty;
     s_d[ty][tx] = (gx < 0 || gx >= W || gy < 0 || gy >= H) ? 0.0f : depth_raw[(size_t)gy * W + gx];
   }
   __syncthreads();
 
-  for (int i = threadIdx.x; i < (kDnH + 6) * (kDnW + 6); i += 256) {  // = median3x3_kernel on the depth plane
+  for (int i = threadIdx.x; i < (kDnH + 6) * (kDnW + 6); i += kDnThreads) {  // = median3x3_kernel on the depth plane
     const int ty = i / (kDnW + 6), tx = i - ty * (kDnW + 6);
     const int gx = x0 - 3 + tx, gy = y0 - 3 + ty;
     float r = 0.0f;
@@ -930,7 +934,7 @@ derive_normal_fused_kernel(int W, int H, float fx, float fy, const float* __rest
   }
   __syncthreads();
 
-  for (int i = threadIdx.x; i < (kDnH + 2) * (kDnW + 2); i += 256) {  // = depth_to_normal_kernel
+  for (int i = threadIdx.x; i < (kDnH + 2) * (kDnW + 2); i += kDnThreads) {  // = depth_to_normal_kernel
     const int ty = i / (kDnW + 2), tx = i - ty * (kDnW + 2);
     const int x = x0 - 1 + tx, y = y0 - 1 + ty;
     v3 nrm = {0.0f, 0.0f, 0.0f}, pos = {0.0f, 0.0f, 0.0f};
@@ -1039,7 +1043,7 @@ void launch_derive_normal_fused(int W, int H, float fx, float fy, const float* v
   k1d(sy, kk.ky);
   k1d(sx, kk.kx);
   kk.color_scale = -0.5f / (sigma_color * sigma_color);
-  hipLaunchKernelGGL(derive_normal_fused_kernel, dim3((W + kDnW - 1) / kDnW, (H + kDnH - 1) / kDnH), dim3(256), 0, s, W, H, fx,
+  hipLaunchKernelGGL(derive_normal_fused_kernel, dim3((W + kDnW - 1) / kDnW, (H + kDnH - 1) / kDnH), dim3(kDnThreads), 0, s, W, H, fx,
                      fy, viewmatrix, kk, depth_raw, normal_out, pos_filter_out);
 }
 

@@ -510,7 +510,7 @@ def test_pixel_rounding_is_exact_for_every_float():
 @pytest.mark.parametrize("W,H", [(176, 144), (161, 127), (33, 9)])
 def test_fused_derive_normal_is_bit_identical_to_the_four_kernel_chain(W, H, monkeypatch):
     """gigs_derive_normal (one launch) == median3x3 -> depth_to_normal -> bilateral3x3, median3x3 bit for bit, including
-    image borders, empty regions (zero depth), NaN depths and sizes that are not a multiple of the 32x8 tile."""
+    image borders, empty regions (zero depth), NaN depths and sizes that are not a multiple of the tile."""
     dgr = _dgr()
     sc = scenes.surface_scene(P=9_000, sh_degree=1, seed=4, scale_mu=0.03)
     cam = scenes.orbit_camera(1, 5, W, H, radius=3.5)
