@@ -26,6 +26,7 @@
 //     them only on a hit: forward.cu:820-826).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -506,6 +507,178 @@ __device__ __forceinline__ bool tbn_never_hits(const Tbn& m) {
   return (m.t.x != m.t.x) && (m.t.y != m.t.y) && (m.t.z != m.t.z);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Tolerance-spending marches (GIGS_GI_MARCH; kMode > 0)
+// ------------------------------------------------------------------------------------------
+// The exact march above reproduces the oracle's pixel choice bit for bit and pays for it with ~31 VALU
+// instructions per ray-step.  north_star's bar for the fp planes is 1e-4 mean per-pixel L1, and the reference's
+// own binary is an FMA-contracted compilation of the same lines (nvcc -fmad=true), so its projected coordinates
+// already differ from the contraction-free oracle in the last place.  The variants below spend that tolerance:
+//
+//   kMode 1 "hoist"      per-ray step vector k = ((sv*a)*a*radius) (then * j/step), sp = pos + (j/step)*k with a
+//                        separate multiply and add; both quotients IEEE-correct (the shared-reciprocal chain);
+//                        q*f + c as multiply and add.  Only the order of the multiplies differs from forward.cu:693.
+//   kMode 2 "hoist_fma"  the same with FMAs for pos + fj*k and q*f + c (what nvcc's contraction does to ssr.h:133).
+//   kMode 3 "proj_nr"    projective form: numerators (pos.xy*f + fj*Bxy), denominator (pos.z + 1e-7 + fj*Bz), one
+//                        v_rcp_f32 refined by one Newton step, t = n*r + (c + 0.5): 3 packed FMAs + rcp per sample.
+//   kMode 4 "proj"       kMode 3 with the raw 1-ulp v_rcp_f32.
+//
+// In modes 3/4 the depth test z in [spz - thick, spz + bias] is evaluated as |z - (den + cm)| <= hh with
+// cm = (bias - thick)/2 - 1e-7, hh = (bias + thick)/2 (same interval, different rounding of its ends).
+// Every mode keeps the march's control flow: in-order resolution, break on leaving the image, first hit wins.
+// tools/gi_variants.py measures each mode against mode 0 (= the oracle, bit for bit) on the C2 view and the GI test
+// scenes; DESIGN.md section 5 holds the table and the choice of default.
+struct FastPix {
+  f32x2 Axy;      // modes 1/2: pos.xy;            modes 3/4: pos.xy * (fx, fy)
+  float Dz;       // modes 1/2: pos.z;             modes 3/4: pos.z + 1e-7
+  f32x2 cxy;      // (cx, cy) + round_pix's addend
+  f32x2 c0xy;     // (cx, cy)
+  f32x2 fxy;
+  float cm, hh, bias, thick;
+};
+
+__device__ __forceinline__ int cvt_flr(float t) {  // (int)floor(t), saturating, NaN -> 0: one VOP1 instruction
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(t));
+  return r;
+}
+
+template <int kMode, int kGroup>
+__device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c, const f32x2* Bxy, f32x2 Bz2,
+                                            __amdgpu_buffer_rsrc_t pos_z, int* hit) {
+  bool open[2] = {true, true};
+  hit[0] = hit[1] = -1;
+  const f32x2 Dz2 = {c.Dz, c.Dz};
+  for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
+    unsigned off[2][kGroup];
+    bool inb[2][kGroup];
+    f32x2 ta[kGroup], tb[kGroup];  // modes 1/2: spz + bias, spz - thick; modes 3/4: mid (ta only)
+#pragma unroll
+    for (int g = 0; g < kGroup; g++) {
+      const float fj = p.fjt[j0 - p.start + g];  // j / step
+      const f32x2 fj2 = {fj, fj};
+      const bool in_range = (j0 + g) < p.step;
+      f32x2 r;
+      f32x2 den;
+      if constexpr (kMode >= 3) {
+        den = __builtin_elementwise_fma(Bz2, fj2, Dz2);
+        ta[g] = den + c.cm;
+        r = f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        if constexpr (kMode == 3) {
+          const f32x2 e0 = __builtin_elementwise_fma(-den, r, f32x2{1.0f, 1.0f});
+          r = __builtin_elementwise_fma(e0, r, r);
+        }
+      } else {
+        const f32x2 spz = (kMode == 2) ? __builtin_elementwise_fma(Bz2, fj2, Dz2) : Dz2 + Bz2 * fj2;
+        den = spz + 0.0000001f;
+        ta[g] = spz + c.bias;
+        tb[g] = spz - c.thick;
+        const f32x2 r0 = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        const f32x2 e0 = __builtin_elementwise_fma(-den, r0, f32x2{1.0f, 1.0f});
+        r = __builtin_elementwise_fma(e0, r0, r0);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const float rk = k == 0 ? r.x : r.y;
+        const f32x2 rr = {rk, rk};
+        f32x2 t;
+        if constexpr (kMode >= 3) {
+          const f32x2 n = __builtin_elementwise_fma(Bxy[k], fj2, c.Axy);
+          t = __builtin_elementwise_fma(n, rr, c.cxy);
+        } else {
+          const f32x2 sp = (kMode == 2) ? __builtin_elementwise_fma(Bxy[k], fj2, c.Axy) : c.Axy + Bxy[k] * fj2;
+          const float d = k == 0 ? den.x : den.y;
+          const f32x2 nd = {-d, -d};
+          const f32x2 q0 = sp * rr;
+          const f32x2 e1 = __builtin_elementwise_fma(nd, q0, sp);
+          const f32x2 q1 = __builtin_elementwise_fma(e1, rr, q0);
+          const f32x2 e2 = __builtin_elementwise_fma(nd, q1, sp);
+          const f32x2 qv = __builtin_elementwise_fma(e2, rr, q1);
+          t = ((kMode == 2) ? __builtin_elementwise_fma(qv, c.fxy, c.c0xy) : qv * c.fxy + c.c0xy) + 0.49999997f;
+        }
+        const int ix = cvt_flr(t.x);
+        const int iy = cvt_flr(t.y);
+        inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+        off[k][g] = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;
+      }
+    }
+    float zn[2 * kGroup];
+    {
+      unsigned in[2 * kGroup];
+#pragma unroll
+      for (int g = 0; g < kGroup; g++) { in[2 * g] = off[0][g]; in[2 * g + 1] = off[1][g]; }
+      gather_idx<2 * kGroup>(zn, in, pos_z);
+    }
+    bool any_open = false;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+      for (int g = 0; g < kGroup; g++) {
+        const float z = zn[2 * g + k];
+        bool h;
+        if constexpr (kMode >= 3) {
+          h = inb[k][g] && fabsf(z - (k == 0 ? ta[g].x : ta[g].y)) <= c.hh;
+        } else {
+          h = inb[k][g] && (z <= (k == 0 ? ta[g].x : ta[g].y)) && (z >= (k == 0 ? tb[g].x : tb[g].y));
+        }
+        hit[k] = (open[k] && h) ? (int)off[k][g] : hit[k];
+        open[k] = open[k] && inb[k][g] && !h;
+      }
+      any_open = any_open || open[k];
+    }
+    if (!__any(any_open)) break;
+  }
+}
+
+// per-pixel constants of the fast marches and the per-ray vectors
+template <int kMode>
+__device__ __forceinline__ FastPix make_fast(const GiParams& p, v3 pos, float cx, float cy) {
+  FastPix c;
+  c.fxy = f32x2{p.fx, p.fy};
+  c.cxy = f32x2{cx + 0.49999997f, cy + 0.49999997f};
+  c.c0xy = f32x2{cx, cy};
+  c.bias = p.bias; c.thick = p.thick;
+  c.cm = 0.5f * (p.bias - p.thick) - 0.0000001f;
+  c.hh = 0.5f * (p.bias + p.thick);
+  if constexpr (kMode >= 3) {
+    c.Axy = f32x2{pos.x * p.fx, pos.y * p.fy};
+    c.Dz = pos.z + 0.0000001f;
+  } else {
+    c.Axy = f32x2{pos.x, pos.y};
+    c.Dz = pos.z;
+  }
+  return c;
+}
+// rows of the tangent frame pre-scaled so that B = M * ts is the per-ray step vector (times j/step per sample)
+struct FastTbn { v3 mx, my, mz; };
+template <int kMode>
+__device__ __forceinline__ FastTbn make_fast_tbn(const GiParams& p, const Tbn& m, float a) {
+  const float s = a * a * p.radius;
+  const float sx = kMode >= 3 ? s * p.fx : s, sy = kMode >= 3 ? s * p.fy : s;
+  FastTbn r;
+  r.mx = {m.t.x * sx, m.b.x * sx, m.n.x * sx};
+  r.my = {m.t.y * sy, m.b.y * sy, m.n.y * sy};
+  r.mz = {m.t.z * s, m.b.z * s, m.n.z * s};
+  return r;
+}
+template <int kMode>
+__device__ __forceinline__ void fast_ray(const GiParams& p, const Tbn& tbn, const FastTbn& ft, float a, float4 ra, f32x2& bxy,
+                                         float& bz) {
+  float bx, by;
+  if constexpr (kMode >= 3) {
+    bx = __builtin_fmaf(ft.mx.z, ra.z, __builtin_fmaf(ft.mx.y, ra.y, ft.mx.x * ra.x));
+    by = __builtin_fmaf(ft.my.z, ra.z, __builtin_fmaf(ft.my.y, ra.y, ft.my.x * ra.x));
+    bz = __builtin_fmaf(ft.mz.z, ra.z, __builtin_fmaf(ft.mz.y, ra.y, ft.mz.x * ra.x));
+  } else {
+    const v3 sv = tbn_apply(tbn, ra.x, ra.y, ra.z);  // as the reference computes sampleVec
+    bx = ((sv.x * a) * a) * p.radius;
+    by = ((sv.y * a) * a) * p.radius;
+    bz = ((sv.z * a) * a) * p.radius;
+  }
+  bxy = f32x2{bx, by};
+}
+
 #ifndef GIGS_GI_GROUP
 #define GIGS_GI_GROUP 4
 #endif
@@ -538,7 +711,7 @@ __device__ __forceinline__ bool gi_pixel(const GiParams& p, int& x, int& y, int&
 #define GIGS_GI_OCC
 #endif
 
-template <bool kPow2>
+template <bool kPow2, int kMode>
 __global__ void __launch_bounds__(256) GIGS_GI_OCC
 ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             const float* __restrict__ nrm, const float* __restrict__ pos_map,
@@ -560,6 +733,25 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
       const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
       const int r0 = wave * chunk, r1 = min(p.nrays, r0 + chunk);
       const bool mag_ok = gi_mag_ok(pos, a, p.radius);
+      if constexpr (kMode > 0) {
+        // absurd magnitudes (|pos| >= 2^59) are outside the fast marches' contract: such a pixel takes no hits
+        if (mag_ok) {
+          const FastPix c = make_fast<kMode>(p, pos, cx, cy);
+          const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a);
+          for (int r = r0; r < r1; r += 2) {
+            const int rb = min(r + 1, r1 - 1);  // an odd chunk marches its last ray twice and counts it once
+            f32x2 Bxy[2], Bz2;
+            float bz0, bz1;
+            fast_ray<kMode>(p, tbn, ft, a, rays[2 * r], Bxy[0], bz0);
+            fast_ray<kMode>(p, tbn, ft, a, rays[2 * rb], Bxy[1], bz1);
+            Bz2 = f32x2{bz0, bz1};
+            int hit[2];
+            march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
+            occ += hit[0] >= 0 ? rays[2 * r + 1].y : 0.0f;
+            occ += (hit[1] >= 0 && rb != r) ? rays[2 * rb + 1].y : 0.0f;
+          }
+        }
+      } else {
       const unsigned sv_min_bits = gi_sv_min_bits(a, p.radius, p.inv_step);
       int r = r0;
       for (; r + kGiRays <= r1; r += kGiRays) {
@@ -583,6 +775,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
         march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, sv_min_bits, &hit);
         occ += hit >= 0 ? rays[2 * r + 1].y : 0.0f;
       }
+      }
     }
   }
   s_part[wave][lane] = occ;
@@ -596,7 +789,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
   }
 }
 
-template <bool kPow2>
+template <bool kPow2, int kMode>
 __global__ void __launch_bounds__(256) GIGS_GI_OCC
 ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict__ nrm,
            const float* __restrict__ pos_map, const float* __restrict__ rgb,
@@ -618,7 +811,6 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
     const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
     const int r0 = wave * chunk, r1 = min(p.nrays, r0 + chunk);
     const bool mag_ok = gi_mag_ok(pos, a, p.radius);
-      const unsigned sv_min_bits = gi_sv_min_bits(a, p.radius, p.inv_step);
     auto add_hit = [&](int q, float cos_t, float sin_t) {
       if (q >= 0) {
         // rgb * cosf(theta) * sinf(theta), left to right (forward.cu:824-826)
@@ -627,6 +819,29 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
         diffuse.z += rgb[2 * HW + q] * cos_t * sin_t;
       }
     };
+    if constexpr (kMode > 0) {
+      if (mag_ok) {  // see ssao_kernel
+        const FastPix c = make_fast<kMode>(p, pos, cx, cy);
+        const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a);
+        for (int r = r0; r < r1; r += 2) {
+          const int rb = min(r + 1, r1 - 1);
+          const float4 ra0 = rays[2 * r], ra1 = rays[2 * rb];
+          f32x2 Bxy[2], Bz2;
+          float bz0, bz1;
+          fast_ray<kMode>(p, tbn, ft, a, ra0, Bxy[0], bz0);
+          fast_ray<kMode>(p, tbn, ft, a, ra1, Bxy[1], bz1);
+          Bz2 = f32x2{bz0, bz1};
+          int hit[2];
+          march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
+          if (rb == r) hit[1] = -1;
+          if (__any(hit[0] >= 0 || hit[1] >= 0)) {
+            add_hit(hit[0], ra0.w, rays[2 * r + 1].x);
+            add_hit(hit[1], ra1.w, rays[2 * rb + 1].x);
+          }
+        }
+      }
+    } else {
+    const unsigned sv_min_bits = gi_sv_min_bits(a, p.radius, p.inv_step);
     int r = r0;
     for (; r + kGiRays <= r1; r += kGiRays) {
       v3 sv[kGiRays];
@@ -654,6 +869,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
       int hit;
       march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, sv_min_bits, &hit);
       add_hit(hit, ra.w, rays[2 * r + 1].x);
+    }
     }
   }
   s_part[wave][0][lane] = diffuse.x;
@@ -705,11 +921,26 @@ static GiParams make_params(int W, int H, float fx, float fy, float radius, floa
   pow2 = step > 0 && (step & (step - 1)) == 0 && step <= (1 << 20);
   p.inv_step = pow2 ? 1.0f / (float)step : 0.0f;
   if (step - start > 64 - kGiGroup) pow2 = false;  // a partial last group may index kGiGroup - 1 entries past step - 1
-  for (int k = 0; k < 64; k++) p.fjt[k] = (float)(start + k) * p.inv_step;
+  // j / step: exact for a power-of-two step; otherwise the correctly rounded quotient (read by the fast marches only)
+  for (int k = 0; k < 64; k++) p.fjt[k] = pow2 ? (float)(start + k) * p.inv_step : (float)(start + k) / (float)step;
   // GIGS_GI_TILE_LOG2W: tuning knob for the pixel rectangle of a workgroup (3 = 8x8 ... 6 = 64x1)
   const char* e = getenv("GIGS_GI_TILE_LOG2W");
   p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
   return p;
+}
+// GIGS_GI_MARCH: exact | hoist | hoist_fma | proj_nr | proj (see the block comment above march2_fast).  The fast
+// marches read the j/step table, so marches of more than 64 - kGiGroup steps take the exact path.
+#ifndef GIGS_GI_DEFAULT_MODE
+#define GIGS_GI_DEFAULT_MODE 4  // "proj": measured 1.3e-7 mean L1 / 1e-4 changed pixels vs the exact march at C2
+#endif
+static int gi_march_mode(int step, int start) {
+  static const char* names[] = {"exact", "hoist", "hoist_fma", "proj_nr", "proj"};
+  int mode = GIGS_GI_DEFAULT_MODE;
+  if (const char* e = getenv("GIGS_GI_MARCH"))
+    for (int i = 0; i < 5; i++)
+      if (strcmp(e, names[i]) == 0) mode = i;
+  if (step - start > 64 - kGiGroup || step <= 0) mode = 0;
+  return mode;
 }
 static dim3 gi_grid(const GiParams& p) {
   const int tw = 1 << p.tile_log2w, th = 64 >> p.tile_log2w;
@@ -726,10 +957,18 @@ int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, floa
   const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
   if (W >= (1 << 15) || H >= (1 << 15)) return -2;  // rejected with a message by the C-ABI wrapper
   const dim3 grid = gi_grid(p);
-  if (pow2)
-    hipLaunchKernelGGL(ssao_kernel<true>, grid, dim3(256), 0, s, p, t.dev, t.sum_w, normal, pos, occlusion);
-  else
-    hipLaunchKernelGGL(ssao_kernel<false>, grid, dim3(256), 0, s, p, t.dev, t.sum_w, normal, pos, occlusion);
+#define GIGS_SSAO_LAUNCH(POW2, MODE) \
+  hipLaunchKernelGGL((ssao_kernel<POW2, MODE>), grid, dim3(256), 0, s, p, t.dev, t.sum_w, normal, pos, occlusion)
+  switch (gi_march_mode(step, start)) {
+    case 1: GIGS_SSAO_LAUNCH(false, 1); break;
+    case 2: GIGS_SSAO_LAUNCH(false, 2); break;
+    case 3: GIGS_SSAO_LAUNCH(false, 3); break;
+    case 4: GIGS_SSAO_LAUNCH(false, 4); break;
+    default:
+      if (pow2) GIGS_SSAO_LAUNCH(true, 0);
+      else GIGS_SSAO_LAUNCH(false, 0);
+  }
+#undef GIGS_SSAO_LAUNCH
   return 0;
 }
 
@@ -744,10 +983,19 @@ int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float
   const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
   if (W >= (1 << 15) || H >= (1 << 15)) return -2;  // rejected with a message by the C-ABI wrapper
   const dim3 grid = gi_grid(p);
-  if (pow2)
-    hipLaunchKernelGGL(ssr_kernel<true>, grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd);
-  else
-    hipLaunchKernelGGL(ssr_kernel<false>, grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd);
+#define GIGS_SSR_LAUNCH(POW2, MODE)                                                                                   \
+  hipLaunchKernelGGL((ssr_kernel<POW2, MODE>), grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, \
+                     color, abd)
+  switch (gi_march_mode(step, start)) {
+    case 1: GIGS_SSR_LAUNCH(false, 1); break;
+    case 2: GIGS_SSR_LAUNCH(false, 2); break;
+    case 3: GIGS_SSR_LAUNCH(false, 3); break;
+    case 4: GIGS_SSR_LAUNCH(false, 4); break;
+    default:
+      if (pow2) GIGS_SSR_LAUNCH(true, 0);
+      else GIGS_SSR_LAUNCH(false, 0);
+  }
+#undef GIGS_SSR_LAUNCH
   return 0;
 }
 

@@ -25,11 +25,28 @@ c_int_p = C.POINTER(C.c_int)
 
 
 def build(force: bool = False) -> str:
-    """Compile the oracle with the recipe in oracle/Makefile (g++ -O2 -ffp-contract=off)."""
-    src = os.path.join(_HERE, "gigs_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    """Compile the oracle with the recipe in oracle/Makefile (g++ -O2 -ffp-contract=off; plus the
+    FMA-contracted twin libgigs_oracle_fma.so)."""
+    srcs = [os.path.join(_HERE, f) for f in ("gigs_oracle.cpp", "pbr_oracle.cpp")]
+    libs = [os.path.join(_HERE, f) for f in ("libgigs_oracle.so", "libgigs_oracle_fma.so")]
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs) for so in libs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
+
+
+def variant(name: str):
+    """A second, independent copy of this module bound to another build of the same sources:
+    variant("fma") = libgigs_oracle_fma.so (FMA contraction on, like nvcc's default for the reference's
+    CUDA binary).  Used to measure how far two legitimate compilations of the cited lines are apart."""
+    import importlib.util
+    build()
+    spec = importlib.util.spec_from_file_location("oracle_%s" % name, os.path.abspath(__file__))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod._LIB_PATH = os.path.join(_HERE, "libgigs_oracle_%s.so" % name)
+    if not os.path.exists(mod._LIB_PATH):
+        raise FileNotFoundError(mod._LIB_PATH)
+    return mod
 
 
 def lib():
