@@ -1,9 +1,11 @@
 #!/usr/bin/env python
-"""bench.py -- train-step renders/sec (fwd+bwd, G-buffer + indirect) at 800x800.
+"""bench.py -- train-step renders/sec (fwd+bwd, G-buffer + indirect) at 800x800; PSNR vs the CPU oracle.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                       # BASELINE configs[1] (C2), the headline
+    python bench.py --config c3                                          # configs[2]: relight inference, PBR + indirect
+    python bench.py --config c4                                          # configs[3]: 3 M Gaussians, SH 3, 1237x822
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W           # configs[4] with --config c5 (1297x840)
 
 One "step" is one stage-2 training iteration of the reference (train.py:266-422) on one
 camera view per GPU: rasterizer forward (preprocess, scan, duplicate, radix sort, ranges,
@@ -137,40 +139,68 @@ def stub_step(cam, g, sh_degree, gi, gt_image):
     return dict(loss=loss.detach(), radii=res["radii"])
 
 
-def cpu_baseline(sc, cam, gi, sh_degree):
-    """The oracle (a scalar fp32 port, OpenMP over tiles/pixels) timed on the host cores for ONE
-    step of the same workload: rasterizer fwd + filters + depth->normal + SSAO + SSR + bwd."""
+def cpu_baseline_and_parity(sc, cam, gi, sh_degree, light, brdf_lut, stepper, config):
+    """The checker leg (rank 0, N = 1 only): ONE view of the timed workload on the CPU oracle -- rasterizer fwd, the
+    operator's filters + SSAO, light pre-filter, shade, SSR, sRGB/median, rasterizer bwd (oracle/stage2_ref.py; no
+    shade / light backward on the CPU, so the CPU time is a lower bound of a full step) -- timed on all host cores,
+    and the same view from the timed GPU path compared with it (oracle/parity.py): integer state bit for bit,
+    every fp plane's mean L1, rasterizer-backward gradients, and the PSNR (utils/image_utils.py:31) of the final
+    stage-2 image."""
     from oracle import oracle as orc
+    from oracle import parity
     orc.build()
     cores = orc.max_threads()
     orc.set_threads(cores)
-    H, W = cam["image_height"], cam["image_width"]
-    fx, fy = W / (2 * cam["tanfovx"]), H / (2 * cam["tanfovy"])
+    only = ("albedo", "roughness", "metallic")  # the planes stage 2 differentiates (SURVEY App. D)
+    gpu = parity.gpu_capture(sc, cam, gi, sh_degree, light=light, brdf_lut=brdf_lut, stepper=stepper, grads_only=only,
+                             dev=str(light.base.device) if light is not None else "cuda:0")
+    ref, t = parity.oracle_capture(orc, sc, cam, gi, sh_degree, light_base=gpu.get("light_base"), grads_only=only)
+    rep = parity.compare(gpu, ref)
+    cpu = dict(value=round(1.0 / t["total"], 4), unit="renders/s", cores=cores, kind="port",
+               sample="1 step of the same workload (%s, 1 view) on the oracle: " % config
+                      + ", ".join("%s %.2fs" % (k, v) for k, v in t.items() if k != "total")
+                      + "; backward blend is single-threaded (deterministic double sums), no shade/light backward on the CPU")
+    return cpu, rep
+
+
+def cpu_baseline_and_parity_c3(sc, cam, gi, sh_degree, relighter, light, g, view_dirs, cam_t):
+    """C3 checker leg: one relit view on the oracle (mips built once, outside the timed view -- relight.py:141)."""
+    from oracle import oracle as orc
+    from oracle import stage2_ref
+    orc.build()
+    cores = orc.max_threads()
+    orc.set_threads(cores)
+    base = light.base.detach().cpu().numpy()
     t0 = time.perf_counter()
-    r = orc.Rasterizer()
-    out = r.forward(bg=np.zeros(3, np.float32), **{k: sc[k] for k in PARAM_KEYS}, sh_degree=sh_degree,
-                    viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
-                    tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], image_height=H, image_width=W)
-    t_fwd = time.perf_counter()
-    depth_f = orc.median3x3(out["depth"])
-    nd, pos = orc.depth_to_normal(W, H, fx, fy, cam["viewmatrix"], depth_f)
-    nd = orc.bilateral3x3(nd)
-    posf = orc.median3x3(pos)
-    a = (gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
-    occ = orc.ssao(W, H, fx, fy, *a, out["normal_view"], posf)
-    F0 = ((1.0 - out["metallic"]) * 0.04 + out["albedo"] * out["metallic"]).astype(np.float32)
-    col, abd = orc.ssr(W, H, fx, fy, *a, out["normal_view"], posf, out["color"], out["albedo"], out["roughness"],
-                       out["metallic"], F0)
-    t_gi = time.perf_counter()
-    g1 = np.full((1, H, W), 1.0 / (H * W), np.float32)
-    g3 = np.full((3, H, W), 1.0 / (3 * H * W), np.float32)
-    r.backward(grad_color=0 * g3, grad_opacity=0 * g1, grad_depth=0 * g1, grad_normal=0 * g3, grad_albedo=g3,
-               grad_roughness=g1, grad_metallic=g1)
-    t1 = time.perf_counter()
-    return dict(value=1.0 / (t1 - t0), unit="renders/s", cores=cores, kind="port",
-                sample="1 step of the same workload (C2, 1 view): oracle rasterizer fwd %.2fs + filters/SSAO/SSR %.2fs + bwd %.2fs; "
-                       "backward blend is single-threaded (deterministic double sums), the rest OpenMP"
-                       % (t_fwd - t0, t_gi - t_fwd, t1 - t_gi))
+    diffuse, spec = stage2_ref.build_mips(orc, base)
+    t_mips = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref = stage2_ref.relight_view(orc, sc, cam, gi, sh_degree, diffuse, spec, metallic=relighter.metallic)
+    t_view = time.perf_counter() - t0
+    out = relighter(cam_t, g, view_dirs)
+    torch.cuda.synchronize()
+    planes = {}
+    for k in ("render_direct", "IRR", "render_rgb", "occlusion"):
+        a, b = out[k].cpu().numpy(), ref[k]
+        d = np.abs(np.nan_to_num(a.astype(np.float64)) - np.nan_to_num(b.astype(np.float64)))
+        planes[k] = {"mean_l1": float(d.mean()), "max": float(d.max()),
+                     "nan_pattern_equal": bool(np.array_equal(np.isnan(a), np.isnan(b)))}
+    rep = dict(planes=planes, worst_plane_mean_l1=max(v["mean_l1"] for v in planes.values()),
+               psnr_render_rgb=round(stage2_ref.psnr(np.nan_to_num(out["render_rgb"].cpu().numpy()),
+                                                     np.nan_to_num(ref["render_rgb"])), 2))
+    cpu = dict(value=round(1.0 / t_view, 4), unit="renders/s", cores=cores, kind="port",
+               sample="1 relit view of the same workload on the oracle: %.2fs (light pre-filter, once per run: %.2fs, not "
+                      "counted -- the GPU path builds it once outside the timed region too)" % (t_view, t_mips))
+    return cpu, rep
+
+
+CONFIGS = {
+    # name: (Gaussians, width, height, SH degree, what BASELINE.json calls it)
+    "c2": (300_000, 800, 800, 2, "configs[1] TensoIR lego stand-in"),
+    "c3": (300_000, 800, 800, 2, "configs[2] TensoIR hotdog relight stand-in (inference, synthetic HDR envmap)"),
+    "c4": (3_000_000, 1237, 822, 3, "configs[3] Mip-NeRF360 bicycle images_4 stand-in (--metallic --indirect)"),
+    "c5": (3_000_000, 1297, 840, 3, "configs[4] Mip-NeRF360 garden images_4 stand-in, one view per GPU"),
+}
 
 
 def main():
@@ -178,9 +208,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gaussians", type=int, default=300_000)
-    ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="BASELINE.json configuration (c2 = the headline metric's; c3 relight inference; c4/c5 3 M Gaussians "
+                         "at the Mip-NeRF360 images_4 resolutions)")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--res", type=int, default=None, help="square image (overrides the config's size)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--sh-degree", type=int, default=None)
     ap.add_argument("--start", type=int, default=8, help="GI march start (8 = reference CLI default, 64 = README)")
     ap.add_argument("--shade", choices=["auto", "hip", "none"], default="auto")
     ap.add_argument("--graphs", choices=["on", "off"], default="on",
@@ -188,8 +223,13 @@ def main():
     ap.add_argument("--fused", choices=["on", "off"], default="on",
                     help="run the tensor glue between rasterizer and loss.backward() as the fused stage-2 node "
                          "(gi-gs_amd/stage2_fused.py) instead of op-by-op torch")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and parity)")
     args = ap.parse_args()
+    cP, cW, cH, cD, cname = CONFIGS[args.config]
+    args.gaussians = cP if args.gaussians is None else args.gaussians
+    args.sh_degree = cD if args.sh_degree is None else args.sh_degree
+    W = args.width or args.res or cW
+    H = args.height or args.res or cH
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -233,9 +273,8 @@ def main():
     P, M = sc["means3D"].shape[0], sc["shs"].shape[1]
     g = {k: torch.from_numpy(sc[k]).to(dev).requires_grad_(True) for k in PARAM_KEYS}
     n_views = 64
-    cams = [scenes.orbit_camera(i, n_views, args.res, args.res, radius=3.5) for i in range(n_views)]
+    cams = [scenes.orbit_camera(i, n_views, W, H, radius=3.5) for i in range(n_views)]
     cams_t = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
-    H = W = args.res
     yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, W, device=dev), indexing="ij")
     gt_image = torch.stack([0.5 + 0.3 * torch.sin(6 * xx), 0.5 + 0.3 * torch.cos(5 * yy), 0.4 + 0.2 * xx * yy])
     light, brdf_lut = make_light(dev, shade)
@@ -246,21 +285,34 @@ def main():
     else:
         params_light = []
     flat_params = [g[k] for k in PARAM_KEYS] + params_light
-    stepper = None
-    if shade == "hip":
+    stepper = relighter = None
+    inference = args.config == "c3"
+    if inference:
+        # configs[2]: relight.py -- HDR latlong map -> 256^2 cubemap, build_mips ONCE, then per view
+        # render(inference=True) -> pbr_shading -> Gaussian_SSR -> sRGB -> median -> sum (gi-gs_amd/relight.py)
+        import relight
+        if shade != "hip":
+            raise SystemExit("--config c3 needs the HIP shade")
+        hdri = torch.from_numpy(scenes.synthetic_envmap(512, 1024, seed=1)).to(dev)
+        light = relight.make_light(hdri, res=256)
+        relighter = relight.Relighter(light, gi, args.sh_degree, metallic=False, fused=(args.fused == "on"), brdf_lut=brdf_lut)
+        g_inf = {k: v.detach() for k, v in g.items()}
+    elif shade == "hip":
         stepper = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=(args.graphs == "on"),
                                       fused=(args.fused == "on"))
 
     def one_step(i):
         vi = dp.view_for(i, rank, world, n_views)
         cam = cams_t[vi]
+        if inference:
+            return relighter(cam, g_inf, view_dirs[vi])
         for p in flat_params:
             p.grad = None
         if shade == "hip":
             out = stepper(cam, g, gt_image, view_dirs[vi])
         else:
             out = stub_step(cam, g, args.sh_degree, gi, gt_image)
-        if use_dist and dist.is_initialized():
+        if use_dist and dist.is_initialized() and not inference:
             # one flat bucket: xGMI is point-to-point, a single large all-reduce keeps every link busy
             dp.allreduce_gradients(flat_params)
         return out
@@ -321,7 +373,7 @@ def main():
                 kernels[name] = rec
 
         add_stages(prof.stages, args.steps, "live")  # hipEvents over the timed region
-        if shade == "hip" and args.graphs == "on" and world == 1:
+        if shade == "hip" and args.graphs == "on" and world == 1 and not inference:
             # stages replayed from a hipGraph carry no events: time them on a few extra eager steps of the same
             # workload OUTSIDE the timed region (marked "eager-extra"; the live entries above are not touched)
             eager = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=False, fused=(args.fused == "on"))
@@ -343,22 +395,37 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(a / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
                         "valu_busy": pmc_valu_busy(dom),
-                        "note": "dominant kernel by time; it is bound by fp32 VALU issue (valu_busy = fraction of its "
-                                "cycles with the vector ALUs issuing, from the committed PMC pass), not by HBM (DESIGN.md)"}
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(sc, cams[args.warmup % n_views], gi, args.sh_degree)
+                        "note": "dominant kernel by time; its per-sample z-plane gathers are served by L2/L1 (the plane is "
+                                "2.5 MB), so it is bound by the texture-address / L1 path and VALU issue, not by HBM "
+                                "(valu_busy from the committed PMC pass; DESIGN.md section 5)"}
+        cpu = parity_rep = None
+        vi0 = args.warmup % n_views
+        if not args.no_cpu_baseline and world == 1 and shade == "hip":
+            if inference:
+                cpu, parity_rep = cpu_baseline_and_parity_c3(sc, cams[vi0], gi, args.sh_degree, relighter, light, g_inf,
+                                                             view_dirs[vi0], cams_t[vi0])
+            else:
+                cpu, parity_rep = cpu_baseline_and_parity(sc, cams[vi0], gi, args.sh_degree, light, brdf_lut, stepper,
+                                                          args.config.upper())
+        what = ("relight renders/sec (inference, PBR+indirect, mips built once)" if inference
+                else "train-step renders/sec (fwd+bwd, G-buffer+indirect)")
         line = {
-            "metric": "train-step renders/sec (fwd+bwd, G-buffer+indirect) at 800x800",
+            "metric": "%s at %dx%d; PSNR vs the CPU oracle" % (what, W, H),
             "value": round(args.steps * world / elapsed, 3), "unit": "renders/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 stand-in: %dk surface Gaussians, %dx%d, SH deg %d, GI step=%d start=%d delta=%g"
-                                   % (P // 1000, W, H, args.sh_degree, gi["step"], gi["start"], gi["delta"]),
+            "config": {"workload": "%s (%s): %dk surface Gaussians, %dx%d, SH deg %d, GI step=%d start=%d delta=%g"
+                                   % (args.config.upper(), cname, P // 1000, W, H, args.sh_degree, gi["step"], gi["start"],
+                                      gi["delta"]),
                        "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade, "hip_graphs": args.graphs, "fused_glue": args.fused,
+                       "gi_march": os.environ.get("GIGS_GI_MARCH", "proj (default)"),
                        "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
+        if parity_rep is not None:
+            # the timed GPU path vs the CPU oracle on one view of this very workload (oracle/parity.py)
+            line["psnr_vs_oracle_db"] = parity_rep.get("psnr_render_rgb")
+            line["parity_" + args.config] = parity_rep
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -677,6 +677,54 @@ cube_texture_bwd_kernel(int res, int n, const float* __restrict__ dirs, const fl
     }
 }
 
+
+// latlong_to_cubemap (relight.py:92-111): every cube texel looks its direction up in an equirectangular map.
+//   gy, gx = linspace(-1 + 1/res, 1 - 1/res, res)   (torch: start + i*step below the middle, end - (n-1-i)*step above)
+//   v = normalize(cube_to_dir(face, gx, gy));  tu = atan2(v.x, -v.z) / (2 pi) + 0.5;  tv = acos(clamp(v.y, -1, 1)) / pi
+//   out = dr.texture(latlong[None], (tu, tv), filter_mode="linear")   -- nvdiffrast, third party and absent: restated
+//   from its documented behaviour (bilinear, texel centres at (i + 0.5)/size, boundary_mode "wrap"): PARITY UNPINNED.
+__device__ __forceinline__ float torch_linspace(float start, float end, int n, int i) {
+  if (n <= 1) return start;
+  const float step = (end - start) / (float)(n - 1);
+  return (i < n / 2) ? start + step * (float)i : end - step * (float)(n - 1 - i);
+}
+__global__ void __launch_bounds__(256)
+latlong_to_cubemap_kernel(int res_y, int res_x, int Hl, int Wl, int C, const float* __restrict__ latlong,
+                          float* __restrict__ cube) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = 6 * res_y * res_x;
+  if (i >= n) return;
+  const int face = i / (res_y * res_x), rem = i - face * res_y * res_x;
+  const int ty = rem / res_x, tx = rem - ty * res_x;
+  const float gy = torch_linspace(-1.0f + 1.0f / (float)res_y, 1.0f - 1.0f / (float)res_y, res_y, ty);
+  const float gx = torch_linspace(-1.0f + 1.0f / (float)res_x, 1.0f - 1.0f / (float)res_x, res_x, tx);
+  float rx, ry, rz;  // cube_to_dir (relight.py:75-89)
+  switch (face) {
+    case 0: rx = 1.0f; ry = -gy; rz = -gx; break;
+    case 1: rx = -1.0f; ry = -gy; rz = gx; break;
+    case 2: rx = gx; ry = 1.0f; rz = gy; break;
+    case 3: rx = gx; ry = -1.0f; rz = -gy; break;
+    case 4: rx = gx; ry = -gy; rz = 1.0f; break;
+    default: rx = -gx; ry = -gy; rz = -1.0f; break;
+  }
+  const float inv = 1.0f / fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);  // F.normalize
+  rx *= inv; ry *= inv; rz *= inv;
+  const float kPi = 3.14159265358979323846f;
+  const float tu = atan2f(rx, -rz) / (2.0f * kPi) + 0.5f;
+  const float tv = acosf(fminf(fmaxf(ry, -1.0f), 1.0f)) / kPi;
+  const float u = tu * (float)Wl - 0.5f, v = tv * (float)Hl - 0.5f;
+  const float fu0 = floorf(u), fv0 = floorf(v);
+  const float fu = u - fu0, fv = v - fv0;
+  auto wrap = [](int a, int m) { a %= m; return a < 0 ? a + m : a; };
+  const int iu0 = wrap((int)fu0, Wl), iu1 = wrap((int)fu0 + 1, Wl);
+  const int iv0 = wrap((int)fv0, Hl), iv1 = wrap((int)fv0 + 1, Hl);
+  for (int c = 0; c < C; c++) {
+    const float a = latlong[((size_t)iv0 * Wl + iu0) * C + c] * (1.0f - fu) + latlong[((size_t)iv0 * Wl + iu1) * C + c] * fu;
+    const float b = latlong[((size_t)iv1 * Wl + iu0) * C + c] * (1.0f - fu) + latlong[((size_t)iv1 * Wl + iu1) * C + c] * fu;
+    cube[(size_t)i * C + c] = a * (1.0f - fv) + b * fv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // shade
 // ------------------------------------------------------------------------------------------
@@ -1170,6 +1218,19 @@ int gigs_cube_texture_fwd(int res, const float* cubemap, int n, const float* dir
   void* tok; gigs_internal_stage_begin(16, stream, &tok);
   hipLaunchKernelGGL(gigs::cube_texture_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, res,
                      cubemap, n, dirs, out, planar);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_latlong_to_cubemap(int res_y, int res_x, int lat_h, int lat_w, int channels, const float* latlong, float* cubemap,
+                            void* stream) {
+  if (res_y <= 0 || res_x <= 0 || lat_h <= 0 || lat_w <= 0 || channels <= 0 || !latlong || !cubemap)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "latlong_to_cubemap: bad argument");
+  const int n = 6 * res_y * res_x;
+  void* tok; gigs_internal_stage_begin(16, stream, &tok);
+  hipLaunchKernelGGL(gigs::latlong_to_cubemap_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_y, res_x,
+                     lat_h, lat_w, channels, latlong, cubemap);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;

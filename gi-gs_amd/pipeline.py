@@ -74,11 +74,22 @@ def graphed(callable_, sample_args):
 
 
 def gbuffer_post(normal_map_from_depth: torch.Tensor, normal_map: torch.Tensor, out_normal_view: torch.Tensor,
-                 viewmatrix: torch.Tensor):
-    """The tensor post-processing of gaussian_renderer.render (:157-199, pad_normal=False): masks,
-    normalisation, 3x3 medians and the rotation of the shading normal into view space."""
+                 viewmatrix: torch.Tensor, opacity_map: Optional[torch.Tensor] = None, pad_normal: bool = False):
+    """The tensor post-processing of gaussian_renderer.render (:157-199): masks, the optional background padding
+    of the two normal maps (pad_normal, :159-173; render.py:212 uses it), normalisation, 3x3 medians and the
+    rotation of the shading normal into view space.  With pad_normal the thresholded opacity map is returned as a
+    sixth value (the reference returns it in place of the raw one)."""
     normal_from_depth_mask = (normal_map_from_depth != 0).all(0)
     normal_mask = (normal_map != 0).all(0, keepdim=True)
+    if pad_normal:
+        if opacity_map is None:
+            raise ValueError("pad_normal=True needs the opacity map")
+        opacity_map = torch.where(opacity_map < 0.004, torch.zeros_like(opacity_map), opacity_map)  # filters out 1 / 255
+        opacity_map = torch.where(opacity_map > 1.0 - 0.004, torch.ones_like(opacity_map), opacity_map)
+        normal_bg = torch.tensor([0.0, 0.0, 1.0], device=normal_map.device)
+        normal_map = normal_map * opacity_map + (1.0 - opacity_map) * normal_bg[:, None, None]
+        mask_from_depth = (normal_map_from_depth == 0.0).all(0, keepdim=True).float()
+        normal_map_from_depth = normal_map_from_depth * (1.0 - mask_from_depth) + mask_from_depth * normal_bg[:, None, None]
     normal_map_from_depth = torch.where(torch.norm(normal_map_from_depth, dim=0, keepdim=True) > 0,
                                         F.normalize(normal_map_from_depth, dim=0, p=2), normal_map_from_depth)
     normal_map = torch.where(torch.norm(normal_map, dim=0, keepdim=True) > 0, F.normalize(normal_map, dim=0, p=2),
@@ -89,6 +100,8 @@ def gbuffer_post(normal_map_from_depth: torch.Tensor, normal_map: torch.Tensor, 
     out_normal_view = torch.where(torch.norm(out_normal_view, dim=0, keepdim=True) > 0,
                                   F.normalize(out_normal_view, dim=0, p=2), out_normal_view)
     out_normal_view = filters.median_blur(out_normal_view[None, ...], (3, 3))[0]
+    if pad_normal:
+        return normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view, opacity_map
     return normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view
 
 
@@ -158,13 +171,18 @@ def rasterize(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.T
 
 
 def render(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tensor, gi: Dict,
-           inference: bool = False, derive_normal: bool = True, debug=False, fused_post: bool = False) -> Dict[str, torch.Tensor]:
-    """gaussian_renderer.render with pad_normal=False; fused_post=True runs the post-processing as fused kernels."""
+           inference: bool = False, derive_normal: bool = True, debug=False, fused_post: bool = False,
+           pad_normal: bool = False) -> Dict[str, torch.Tensor]:
+    """gaussian_renderer.render (:30-220); fused_post=True runs the pad_normal=False post-processing as fused kernels."""
     ((rendered_image, radii, opacity_map, depth_map, normal_map_from_depth, normal_map, occlusion_map, albedo_map,
       roughness_map, metallic_map, out_normal_view, depth_pos), screenspace_points, st) = rasterize(
         cam, g, sh_degree, bg, gi, inference=inference, derive_normal=derive_normal, debug=debug)
-    (normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view) = (
-        gbuffer_post_fused if fused_post else gbuffer_post)(normal_map_from_depth, normal_map, out_normal_view, st.viewmatrix)
+    if pad_normal:
+        (normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view, opacity_map) = gbuffer_post(
+            normal_map_from_depth, normal_map, out_normal_view, st.viewmatrix, opacity_map=opacity_map, pad_normal=True)
+    else:
+        (normal_map_from_depth, normal_from_depth_mask, normals_view, normal_mask, out_normal_view) = (
+            gbuffer_post_fused if fused_post else gbuffer_post)(normal_map_from_depth, normal_map, out_normal_view, st.viewmatrix)
     return {
         "render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
         "radii": radii, "opacity_map": opacity_map, "depth_map": depth_map,

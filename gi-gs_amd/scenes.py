@@ -138,3 +138,25 @@ def surface_scene(P: int = 300_000, sh_degree: int = 2, seed: int = 0, scale_mu:
 
 
 GI_DEFAULTS = dict(radius=0.8, bias=0.01, thick=0.05, delta=0.0625, step=16, start=8)  # train.py:850-855
+
+
+def synthetic_envmap(height: int = 512, width: int = 1024, seed: int = 1) -> np.ndarray:
+    """HDR-like equirectangular environment map [H, W, 3] fp32 (stand-in for the TensoIR `bridge.hdr` of BASELINE
+    config C3, which is not available offline): a sky/ground gradient, a few soft area lights and one small, very
+    bright 'sun' so that the GGX pre-filter sees a high dynamic range."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(height) + 0.5) / height
+    u = (np.arange(width) + 0.5) / width
+    uu, vv = np.meshgrid(u, v)
+    sky = np.stack([0.35 + 0.3 * (1 - vv), 0.45 + 0.35 * (1 - vv), 0.6 + 0.5 * (1 - vv)], -1)
+    ground = np.stack([0.25 + 0 * vv, 0.22 + 0 * vv, 0.18 + 0 * vv], -1)
+    img = np.where((vv < 0.5)[..., None], sky, ground) * (0.8 + 0.2 * np.cos(2 * np.pi * uu)[..., None])
+    for _ in range(6):
+        cu, cv, s = rng.uniform(0, 1), rng.uniform(0.1, 0.6), rng.uniform(0.02, 0.08)
+        du = np.minimum(np.abs(uu - cu), 1 - np.abs(uu - cu))
+        blob = np.exp(-0.5 * ((du / s) ** 2 + ((vv - cv) / s) ** 2))
+        img += blob[..., None] * rng.uniform(1.0, 6.0, size=3)
+    cu, cv = 0.3, 0.25
+    du = np.minimum(np.abs(uu - cu), 1 - np.abs(uu - cu))
+    img += np.exp(-0.5 * ((du / 0.006) ** 2 + ((vv - cv) / 0.006) ** 2))[..., None] * np.array([60.0, 55.0, 45.0])
+    return np.ascontiguousarray(img, dtype=np.float32)

@@ -278,6 +278,12 @@ int gigs_stage2_loss_bwd(int height, int width, const float* render_direct, cons
  * The backward accumulates into d_cubemap [6,res,res,3] (caller zeroes); directions get no gradient. */
 int gigs_cube_texture_fwd(int res, const float* cubemap, int n, const float* dirs, float* out, int planar,
                           void* stream);
+/* latlong_to_cubemap (relight.py:92-111): cubemap [6,res_y,res_x,C] from an equirectangular map [lat_h,lat_w,C]:
+ * texel direction = normalize(cube_to_dir(face, linspace(-1+1/res, 1-1/res))), tu = atan2(x,-z)/(2pi)+0.5,
+ * tv = acos(clamp(y))/pi, then the 2D lookup dr.texture(latlong, (tu,tv), filter_mode="linear") -- nvdiffrast
+ * (third party, absent): bilinear, texel centres at (i+0.5)/size, boundary_mode "wrap".  PARITY UNPINNED. */
+int gigs_latlong_to_cubemap(int res_y, int res_x, int lat_h, int lat_w, int channels, const float* latlong,
+                            float* cubemap, void* stream);
 int gigs_cube_texture_bwd(int res, int n, const float* dirs, const float* g_out, float* d_cubemap, int planar,
                           void* stream);
 

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 from typing import Dict, Optional
 
 import numpy as np
@@ -46,9 +47,12 @@ def srgb_to_linear(x):  # train.py:70-81
     return np.where(x <= _f32(0.04045), l0, l1).astype(_f32)
 
 
-def psnr(img1, img2):  # utils/image_utils.py:31-33 (one image: mean over all of it)
-    mse = float(((np.asarray(img1, np.float64) - np.asarray(img2, np.float64)) ** 2).mean())
-    return 20.0 * math.log10(1.0 / math.sqrt(max(mse, 1e-30)))
+def psnr(img1, img2):
+    """utils/image_utils.py:31-33 as the callers use it (`psnr(a, b).mean()`, train.py:786, render.py:379): one
+    PSNR per leading index (channel of a [3,H,W] image), then their mean.  Pinned by tests/golden/ref_psnr.npz."""
+    a, b = np.asarray(img1, np.float64), np.asarray(img2, np.float64)
+    mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1)
+    return float(np.mean(20.0 * np.log10(1.0 / np.sqrt(np.maximum(mse, 1e-30)))))
 
 
 def focal(cam):
@@ -56,26 +60,35 @@ def focal(cam):
 
 
 # --------------------------------------------------------------------------------------------------
-def operator_forward(orc, sc, cam, gi, sh_degree, bg=(0.0, 0.0, 0.0), inference=False, keep_state=False):
+def _tick(timings, name, t0):
+    if timings is not None:
+        timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0)
+    return time.perf_counter()
+
+
+def operator_forward(orc, sc, cam, gi, sh_degree, bg=(0.0, 0.0, 0.0), inference=False, keep_state=False, timings=None):
     """GaussianRasterizer.forward: rasterizer, median(depth), depth->normal, bilateral, median(pos), SSAO on the RAW
     view-space normal (R/.../__init__.py:475-517).  Returns the 12-tuple's planes by name (+ the Rasterizer)."""
     H, W = cam["image_height"], cam["image_width"]
     fx, fy = focal(cam)
+    t0 = time.perf_counter()
     r = orc.Rasterizer()
     out = r.forward(bg=np.asarray(bg, _f32), **{k: sc[k] for k in KEYS}, sh_degree=sh_degree,
                     viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
                     tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], image_height=H, image_width=W,
                     inference=inference)
+    t0 = _tick(timings, "rasterizer_fwd", t0)
     depth_f = orc.median3x3(out["depth"])
     nd, pos = orc.depth_to_normal(W, H, fx, fy, cam["viewmatrix"], depth_f)
     nd = orc.bilateral3x3(nd)
     posf = orc.median3x3(pos)
     occ = orc.ssao(W, H, fx, fy, gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"],
                    out["normal_view"], posf)
+    _tick(timings, "filters_ssao", t0)
     res = dict(render=out["color"], radii=out["radii"], opacity_map=out["opacity"], depth_map=out["depth"],
                normal_map_from_depth=nd, normal_map=out["normal"], occlusion_map=occ, albedo_map=out["albedo"],
                roughness_map=out["roughness"], metallic_map=out["metallic"], out_normal_view=out["normal_view"],
-               depth_pos=posf, num_rendered=out["num_rendered"])
+               depth_pos=posf, pos_raw=out["pos"], num_rendered=out["num_rendered"])
     if keep_state:
         res["rasterizer"] = r
     return res
@@ -184,15 +197,18 @@ def shade_direct(orc, post, view_dirs, albedo_chw, roughness_chw, metallic_chw, 
 
 
 def stage2_forward(orc, sc, cam, gi, sh_degree, light_base, metallic=True, indirect=True, tone=False, gamma=False,
-                   keep_state=False):
+                   keep_state=False, timings=None):
     """train.py:266-385 for one view: returns render_rgb (the stage-2 image the L1 loss sees) and the intermediates."""
     H, W = cam["image_height"], cam["image_width"]
     fx, fy = focal(cam)
-    raw = operator_forward(orc, sc, cam, gi, sh_degree, keep_state=keep_state)
+    raw = operator_forward(orc, sc, cam, gi, sh_degree, keep_state=keep_state, timings=timings)
+    t0 = time.perf_counter()
     post = gbuffer_post(orc, raw, cam["viewmatrix"])
     rough = (post["roughness_map"] * _f32(1.0 - 0.04) + _f32(0.04)).astype(_f32)  # :297-298
     occ = post["occlusion_map"] if indirect else np.ones_like(rough)
+    t0 = _tick(timings, "gbuffer_post", t0)
     diffuse, spec = build_mips(orc, light_base)
+    t0 = _tick(timings, "light_prefilter_fwd", t0)
     lut = brdf_lut()
     vd = canonical_view_dirs(cam)
     direct = shade_direct(orc, post, vd, post["albedo_map"], rough, post["metallic_map"] if metallic else None, occ, diffuse,
@@ -204,10 +220,13 @@ def stage2_forward(orc, sc, cam, gi, sh_degree, light_base, metallic=True, indir
         F0 = np.full_like(post["albedo_map"], 0.04)
         metal = np.zeros_like(rough)
     lin = srgb_to_linear(direct)
+    t0 = _tick(timings, "shade_fwd", t0)
     a = (gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
     irr, abd = orc.ssr(W, H, fx, fy, *a, post["out_normal_view"], post["depth_pos"], lin, post["albedo_map"], rough, metal, F0)
+    t0 = _tick(timings, "ssr", t0)
     irr_s = orc.median3x3(linear_to_srgb(irr))
     render_rgb = (direct + irr_s).astype(_f32)
+    _tick(timings, "srgb_median_sum", t0)
     return dict(render_rgb=render_rgb, render_direct=direct, IRR=irr, IRR_srgb=irr_s, abd=abd, raw=raw, post=post,
                 roughness=rough, F0=F0, diffuse=diffuse, specular=spec)
 

@@ -1,6 +1,7 @@
 """GPU tests at BASELINE.json's full sizes (configs[1] 300k Gaussians / 800x800 / SH 2; configs[2] inference-only
-PBR + indirect; configs[3] 2 M Gaussians / SH 3), where the CPU oracle would take minutes: size-independent
-properties of the path instead of oracle values --
+PBR + indirect; configs[3] 3 M Gaussians / SH 3 / 1237x822).  C2 is compared with the CPU oracle at FULL size
+(all host cores: ~10 s on the GPU box) -- integer state bit for bit, every fp plane, gradients, PSNR of the
+stage-2 image -- and so is a ragged 611x403 view; beyond that, size-independent properties of the path --
 
   * binning: keys sorted, point_list consistent with keys, ranges partition [0, R) by tile, sum(tiles_touched) = R;
   * compositing: opacity + final_T = 1 (the weights telescope), n_contrib within the tile's list, finite planes;
@@ -13,7 +14,7 @@ import pytest
 import torch
 
 import scenes
-from test_gpu_parity import DEV, _dgr, hip_planes, hip_raw_forward, scratch_views, settings, tt
+from test_gpu_parity import DEV, L1_TOL, _dgr, hip_planes, hip_raw_forward, scratch_views, settings, tt
 
 pytestmark = pytest.mark.gpu
 
@@ -134,10 +135,59 @@ def test_c3_inference_planes():
         np.testing.assert_array_equal(ha[k], hb[k])
 
 
-def test_c4_two_million_gaussians_sh3():
-    """configs[3] scale: 2 M Gaussians, SH degree 3, forward + backward on one GPU; structural checks only."""
+def _oracle_parity(orc, sc, cam, deg, light_res, tag, grads_only=None):
+    """One view through the product (timed formulation: fused stage-2 node) and through the oracle composition."""
+    import pbr
+    from oracle import parity
+    orc.set_threads(orc.max_threads())  # full-size views: use every host core (conftest caps the small tests at 8)
+    try:
+        torch.manual_seed(0)
+        light = pbr.CubemapLight(base_res=light_res).to(DEV)
+        gi = scenes.GI_DEFAULTS
+        gpu = parity.gpu_capture(sc, cam, gi, deg, light=light, brdf_lut=pbr.get_brdf_lut().to(DEV), grads_only=grads_only, dev=DEV)
+        ref, _ = parity.oracle_capture(orc, sc, cam, gi, deg, light_base=gpu["light_base"], grads_only=grads_only)
+    finally:
+        orc.set_threads(min(8, orc.max_threads()))
+    rep = parity.compare(gpu, ref)
+    print(tag, {k: rep[k] for k in ("num_rendered", "n_contrib_flips", "worst_plane_mean_l1", "worst_grad_rel_l1", "psnr_render_rgb")})
+    # north_star: bit-exact tile/point indices ...
+    assert rep["num_rendered"][0] == rep["num_rendered"][1], tag
+    for k in ("radii_equal", "keys_equal", "point_list_equal", "ranges_equal"):
+        assert rep[k], (tag, k)
+    N = cam["image_width"] * cam["image_height"]
+    assert rep["n_contrib_flips"] <= 1e-4 * N, (tag, rep["n_contrib_flips"])
+    # ... and every fp plane within 1e-4 mean per-pixel L1 of the reference arithmetic
+    for k, v in rep["planes"].items():
+        assert v["nan_pattern_equal"], (tag, k)
+        assert v["mean_l1"] <= L1_TOL, (tag, k, v["mean_l1"])
+    for k, v in rep["grads_rel_l1"].items():
+        assert v <= 1e-3, (tag, k, v)
+    assert rep["psnr_render_rgb"] >= 60.0, (tag, rep["psnr_render_rgb"])
+    return rep
+
+
+def test_c2_full_size_matches_oracle(orc):
+    """BASELINE configs[1] at its own size -- 300k Gaussians, 800x800, SH 2, 256^2 light (5-level GGX chain incl. the
+    roughness-0.08 level), GI step 16 / start 8 -- against the oracle, through the same fused stage-2 node bench.py times."""
+    sc = scenes.surface_scene(P=300_000, sh_degree=2, seed=0)
+    cam = scenes.orbit_camera(5, 64, 800, 800, radius=3.5)
+    rep = _oracle_parity(orc, sc, cam, 2, 256, "C2", grads_only=("albedo", "roughness", "metallic"))
+    assert rep["num_rendered"][0] > 1_000_000
+
+
+def test_ragged_view_matches_oracle_all_gradients(orc):
+    """A non-square, non-multiple-of-16 view (611x403: partial tiles on both edges, like the 1237x822 / 1297x840 of
+    configs[3]/[4]) with all seven incoming gradient planes live."""
+    sc = scenes.surface_scene(P=80_000, sh_degree=3, seed=2, scale_mu=0.015)
+    cam = scenes.orbit_camera(7, 16, 611, 403, radius=3.2)
+    _oracle_parity(orc, sc, cam, 3, 64, "ragged 611x403")
+
+
+def test_c4_three_million_gaussians_sh3_native_resolution():
+    """configs[3] at its own resolution: 3 M Gaussians, SH degree 3, 1237x822 (Mip-NeRF360 bicycle images_4:
+    78 x 52 tiles with partial last column/row), forward + backward on one GPU; structural checks."""
     dgr = _dgr()
-    P, W, H = 2_000_000, 800, 800
+    P, W, H = 3_000_000, 1237, 822
     sc = scenes.surface_scene(P=P, sh_degree=3, seed=3, scale_mu=0.004)
     cam = scenes.orbit_camera(1, 64, W, H, radius=3.5)
     res = hip_raw_forward(dgr, sc, cam)

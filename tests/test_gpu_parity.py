@@ -371,7 +371,16 @@ def test_backward_scratch_gradients_c_abi(orc):
 
 
 # ------------------------------------------------------------------------------------------
-def test_gi_passes_match_oracle(orc):
+@pytest.mark.parametrize("march", ["exact", "default", "hoist", "hoist_fma", "proj_nr"])
+def test_gi_passes_match_oracle(orc, march, monkeypatch):
+    """SSAO / SSR against the oracle.  GIGS_GI_MARCH=exact reproduces the oracle's pixel choices (only fp sums differ);
+    the default march ("proj") and the other tolerance-spending variants must stay inside a quarter of north_star's
+    1e-4 mean L1 with at most 0.2 % of the pixels moved by more than 1e-5 (measured: ~1e-7 / ~1e-4)."""
+    if march != "default":
+        monkeypatch.setenv("GIGS_GI_MARCH", march)
+    else:
+        monkeypatch.delenv("GIGS_GI_MARCH", raising=False)
+    l1_tol, moved_tol = (L1_TOL, 1e-3) if march == "exact" else (2.5e-5, 2e-3)
     dgr = _dgr()
     sc = scenes.surface_scene(P=30_000, sh_degree=1, seed=3, scale_mu=0.02)
     cam = scenes.orbit_camera(0, 4, 208, 160, radius=3.5)
@@ -398,14 +407,14 @@ def test_gi_passes_match_oracle(orc):
         occ = orc.ssao(W, H, fx, fy, *a, ref["normal_view"], posf)
         got = dgr._C.SSAO(W, H, fx, fy, *a, tt(ref["normal_view"]), tt(posf)).cpu().numpy()
         d = np.abs(got - occ)
-        assert d.mean() <= L1_TOL and (d > 1e-5).mean() <= 1e-3, (gi, d.mean(), d.max())
+        assert d.mean() <= l1_tol and (d > 1e-5).mean() <= moved_tol, (march, gi, d.mean(), d.max())
         col, abd = orc.ssr(W, H, fx, fy, *a, ref["normal_view"], posf, ref["color"], ref["albedo"], ref["roughness"], ref["metallic"], F0)
         gc, ga = dgr._C.SSR(W, H, fx, fy, *a, tt(ref["normal_view"]), tt(posf), tt(ref["color"]), tt(ref["albedo"]),
                             tt(ref["roughness"]), tt(ref["metallic"]), tt(F0))
         for x, y in ((gc.cpu().numpy(), col), (ga.cpu().numpy(), abd)):
             assert np.array_equal(np.isnan(x), np.isnan(y))
             d = np.abs(np.nan_to_num(x) - np.nan_to_num(y))
-            assert d.mean() <= L1_TOL and (d > 1e-5).mean() <= 1e-3, (gi, d.mean(), d.max())
+            assert d.mean() <= l1_tol and (d > 1e-5).mean() <= moved_tol, (march, gi, d.mean(), d.max())
     assert occ.shape == (1, H, W)
 
 
