@@ -194,6 +194,16 @@ def cpu_baseline_and_parity_c3(sc, cam, gi, sh_degree, relighter, light, g, view
     return cpu, rep
 
 
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _Null()
+
 CONFIGS = {
     # name: (Gaussians, width, height, SH degree, what BASELINE.json calls it)
     "c2": (300_000, 800, 800, 2, "configs[1] TensoIR lego stand-in"),
@@ -285,6 +295,14 @@ def main():
     else:
         params_light = []
     flat_params = [g[k] for k in PARAM_KEYS] + params_light
+    # multi-rank: every gradient lives in one persistent flat slab; the rasterizer's backward writes into it directly
+    # (dgr.grad_sink), so the all-reduce bucket needs no packing pass
+    slab = sink = None
+    if use_dist:
+        import diff_gaussian_rasterization as dgr_mod
+        slab = dp.GradSlab(flat_params)
+        sink = slab.sink(["means3D", "opacity", "normal", "albedo", "roughness", "metallic", "sh", "scales", "rotations"])
+    force_coll = os.environ.get("GIGS_BENCH_FORCE_DIST", "0") == "1"
     stepper = relighter = None
     inference = args.config == "c3"
     if inference:
@@ -308,13 +326,17 @@ def main():
             return relighter(cam, g_inf, view_dirs[vi])
         for p in flat_params:
             p.grad = None
-        if shade == "hip":
-            out = stepper(cam, g, gt_image, view_dirs[vi])
-        else:
-            out = stub_step(cam, g, args.sh_degree, gi, gt_image)
-        if use_dist and dist.is_initialized() and not inference:
-            # one flat bucket: xGMI is point-to-point, a single large all-reduce keeps every link busy
-            dp.allreduce_gradients(flat_params)
+        with (dgr_mod.grad_sink(sink) if sink is not None else _NULL):
+            if shade == "hip":
+                out = stepper(cam, g, gt_image, view_dirs[vi])
+            else:
+                out = stub_step(cam, g, args.sh_degree, gi, gt_image)
+        if use_dist and dist.is_initialized():
+            # one flat bucket on the communication stream: xGMI is point-to-point, a single large all-reduce keeps every
+            # link busy.  The step ends where an optimizer would read the reduced gradients, so the wait is part of it
+            # (exact, no one-step gradient delay).
+            slab.allreduce_async(force=force_coll)
+            slab.wait()
         return out
 
     def barrier():

@@ -7,21 +7,25 @@
 // `power > 0`, `alpha < 1/255`, `T*(1-alpha) < 1e-4`, same recurrences), so n_contrib /
 // final_T and every plane match the CPU oracle up to the ulp difference of expf.
 //
-// MI355X design
-//   * one 256-lane workgroup per 16x16 tile (the tile is fixed by `ranges`), four wave64s,
-//     each wave owning an 8x8 pixel quadrant: a compact footprint makes "no lane of this wave
-//     touches this Gaussian" common, and that case is skipped with one wave-uniform branch;
-//   * the tile's instance list is consumed in batches of 256: every lane gathers ONE packed
-//     80-byte record (5 x 16-byte loads, written by the preprocess kernel) into LDS, laid out
-//     k-major so the staging stores are conflict-free and the per-Gaussian reads in the inner
-//     loop are single-address broadcasts;
-//   * backward: per-Gaussian partial gradients of a wave are summed with DPP row/bank
-//     reductions (no LDS traffic), lane 63 adds the 19 sums into a per-batch LDS accumulator
-//     (ds_add_f32), and after the batch the workgroup flushes the accumulator to the packed
-//     80-byte gradient record in HBM with global_atomic_add_f32 so that each atomic
-//     wave-instruction covers whole contiguous rows (the shape the float-atomic path of the
-//     chip handles at full rate), skipping zero entries.  This replaces the reference's 21
-//     same-address atomics per (pixel, Gaussian) pair.
+// MI355X design (DESIGN.md section 5 has the measurements)
+//   * one 256-lane workgroup per 16x16 tile (the tile is fixed by `ranges`), four wave64s, each owning an 8x8
+//     pixel quadrant -- and each wave walks the tile's instance list ON ITS OWN: there is no workgroup barrier in
+//     either kernel.  Tile lists are very skewed, so a kernel lasts as long as the busiest quadrant of its
+//     longest tile; autonomous waves make that max_quadrant(sum over chunks) instead of sum(max_quadrant);
+//   * the list is consumed in chunks of 64 instances (one per lane) through a two-deep register pipeline (ids two
+//     chunks ahead, the packed 80-byte record `brec` -- five 16-byte loads, written by the preprocess kernel -- one
+//     chunk ahead) and staged in a 5 KB per-wave LDS slab for the broadcast reads of the walk;
+//   * quadrant cull, instance-parallel: the 64 lanes test 64 DIFFERENT Gaussians against the wave's pixel box
+//     (minimum of the convex exponent over the box vs log(255 * opacity)), a ballot turns the survivors into an
+//     SGPR mask and the wave iterates set bits in list order, so the blend order and every output bit are
+//     unchanged; the forward records per instance which quadrants really blended it (`hit_mask`), the backward
+//     walks exactly those pairs;
+//   * backward: the 64 pixels' partial gradients of one Gaussian are summed with DPP row/bank reductions
+//     (registers only, single v_add_f32_dpp instructions), lane 63 drops the 19 sums into 80 bytes of LDS and
+//     lanes 0-19 add them to the Gaussian's packed gradient record `grec` with ONE global_atomic_add_f32
+//     wave-instruction (consecutive lanes -> consecutive floats of one row, the shape the float-atomic path runs
+//     at full rate); gradient groups that are zero over the quadrant are skipped.  This replaces the reference's
+//     21 same-address atomics per (pixel, Gaussian) pair.
 //   No MFMA: the per-pair work is a scalar recurrence over depth-ordered Gaussians.
 #include <cstdlib>
 #include "gigs_common.h"

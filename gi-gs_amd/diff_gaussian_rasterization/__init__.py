@@ -127,6 +127,30 @@ class after_blend:
         return False
 
 
+_grad_sink = None
+
+
+class grad_sink:
+    """`with grad_sink({"means3D": t0, "opacity": t1, ...}):` -- the rasterizer's backward writes the gradient of the
+    named operator input into the given tensor instead of a fresh one (gigs-hip extension, off by default).  Names:
+    means3D, opacity, normal, albedo, roughness, metallic, sh, scales, rotations, colors, cov3D, means2D; a tensor is
+    used only if its shape, dtype and device fit.  dp.GradSlab.sink() provides views of one flat bucket, so the
+    gradients are born inside the all-reduce buffer (no torch.cat per step)."""
+
+    def __init__(self, tensors):
+        self.tensors = dict(tensors)
+
+    def __enter__(self):
+        global _grad_sink
+        self._prev, _grad_sink = _grad_sink, self.tensors
+        return self
+
+    def __exit__(self, *exc):
+        global _grad_sink
+        _grad_sink = self._prev
+        return False
+
+
 def _new(tag: str, shape, device, dtype=torch.float32) -> torch.Tensor:
     """Uninitialised output tensor (every element is written by the kernel that receives it)."""
     if _pool is not None:
@@ -243,11 +267,21 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
     # every element of every gradient tensor is written by the backward kernels when P > 0
     # (the reference zero-fills 14 tensors first, rasterize_points.cu:299-312)
     _mk = torch.empty if P != 0 else torch.zeros
-    z = lambda *shape: _mk(shape, dtype=torch.float32, device=dev)  # noqa: E731
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, NUM_CHANNELS)
-    dL_dconic, dL_ddepth, dL_dopacity = z(P, 2, 2), z(P, 1), z(P, 1)
-    dL_dnormal, dL_dalbedo, dL_droughness, dL_dmetallic = z(P, 3), z(P, 3), z(P, 1), z(P, 1)
-    dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
+    sink = _grad_sink or {}
+
+    def z(name, *shape):
+        t = sink.get(name)
+        if (t is not None and P != 0 and tuple(t.shape) == shape and t.dtype == torch.float32 and t.device == dev
+                and t.is_contiguous()):
+            return t
+        return _mk(shape, dtype=torch.float32, device=dev)
+
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = z("means3D", P, 3), z("means2D", P, 3), z("colors", P, NUM_CHANNELS)
+    dL_dconic, dL_ddepth, dL_dopacity = z("", P, 2, 2), z("", P, 1), z("opacity", P, 1)
+    dL_dnormal, dL_dalbedo = z("normal", P, 3), z("albedo", P, 3)
+    dL_droughness, dL_dmetallic = z("roughness", P, 1), z("metallic", P, 1)
+    dL_dcov3D, dL_dsh = z("cov3D", P, 6), z("sh", P, M, 3)
+    dL_dscales, dL_drotations = z("scales", P, 3), z("rotations", P, 4)
     if P != 0:
         keep = []
 

@@ -6,21 +6,38 @@ RCCL/xGMI; `gloo` on CPU for tests) each render a different view and the paramet
 are summed once per step.
 
 Collective design for MI355X: the 8 GPUs of a node are fully connected by point-to-point xGMI
-links (7 x ~153 GB/s per GPU), so a ring is bound by ONE link.  All gradient tensors are packed
-into a single flat fp32 bucket (268 B per Gaussian at SH degree 3 -> 0.8 GB at 3 M Gaussians)
-and reduced with one call, which lets RCCL use its direct (all links busy) algorithms; many
-small per-tensor all-reduces would each pay the launch + latency floor.  Gradients only become
-final when the preprocess-backward kernel finishes (it writes every tensor at once), so there
-is nothing to overlap inside a step.
+links (7 x ~153 GB/s per GPU), so a ring is bound by ONE link.  All gradients live in ONE
+persistent flat fp32 slab (`GradSlab`: every parameter's `.grad` is a view into it, so the backward
+kernels write straight into the bucket -- no per-step `torch.cat`, no second 0.8 GB copy at 3 M
+Gaussians) and are reduced with one call, which lets RCCL use its direct (all links busy) algorithms;
+many small per-tensor all-reduces would each pay the launch + latency floor.
+
+Overlap (`GradSlab.allreduce_async` / `.wait`): the all-reduce is issued on a dedicated communication
+stream behind an event recorded after the backward, and the compute stream only waits for it where the
+reduced gradients are consumed (the optimizer step).  Everything the training loop does between
+`loss.backward()` and `optimizer.step()` -- densification statistics, logging, the NEXT view's camera
+set-up -- runs beside the collective.  The update stays exact (no one-step gradient delay): gradients
+only become final when the preprocess-backward kernel finishes (it writes every tensor at once), so
+there is nothing earlier inside a step to overlap with.
+
+A parameter without a gradient (e.g. the SH rest or the light in stage 1) keeps `.grad = None` after
+the reduction, exactly as on one GPU: Adam must not decay its moments or advance its step.  In an SPMD
+training loop the set of such parameters is a function of the iteration number and therefore the same on
+every rank (the default, `agree_presence=False`: no extra traffic); `agree_presence=True` agrees it with a
+tiny presence-mask all-reduce (MAX) issued together with the bucket, for loops where it can differ.
+
+Zero-copy packing: `GradSlab.sink()` hands the slab's views to the rasterizer's backward
+(`diff_gaussian_rasterization.grad_sink`), whose kernels then write the per-Gaussian gradients straight into
+the bucket; autograd adopts those tensors as `.grad` without a copy.
 
 Densification statistics must be reduced as STATISTICS, not recomputed from reduced gradients:
 the norm of `means2D.grad[:, :2]` and the abs accumulator are per-view quantities that the
-reference sums over views (scene/gaussian_model.py:933-945), and `max_radii2D` is a max
-(train.py:495-498).
+reference sums over views (scene/gaussian_model.py:933-945), `xyz_gradient_accum_abs_max` and
+`max_radii2D` are maxima (gaussian_model.py:944, train.py:495-498).
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -31,38 +48,147 @@ def view_for(step: int, rank: int, world: int, n_views: int) -> int:
     return (step * world + rank) % n_views
 
 
-def flatten_grads(params: Sequence[torch.Tensor]) -> torch.Tensor:
-    """One contiguous fp32 bucket with every parameter's gradient (zeros where absent)."""
-    parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
-    return torch.cat(parts) if parts else torch.zeros(0)
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
-def unflatten_to_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.grad = flat[off:off + n].view_as(p)
-        off += n
+class GradSlab:
+    """One persistent flat fp32 buffer holding the gradients of `params`, in order.
+
+        slab = GradSlab(params)
+        each step:  slab.attach()            # p.grad = zeroed view into the slab (autograd accumulates in place)
+                    loss.backward()
+                    slab.allreduce_async()   # comm stream; returns at once
+                    ... statistics, logging ...
+                    slab.wait()              # compute stream waits; gradient-less parameters get .grad = None
+                    optimizer.step()
+
+    `attach(zero=True)` clears the slab with one fill instead of one per tensor.  With world size 1 the
+    collective is skipped entirely (no copies, no stream hops)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], group=None, agree_presence: bool = False):
+        self.params: List[torch.Tensor] = list(params)
+        self.group = group
+        self.agree_presence = bool(agree_presence)
+        if not self.params:
+            raise ValueError("GradSlab needs at least one parameter")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("GradSlab: all parameters must share one device and dtype")
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += p.numel()
+        self.flat = torch.zeros(n, dtype=dt, device=dev)
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+        self.presence = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        self._comm = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._work: list = []
+        self._pending = False
+
+    def rebuild_if_resized(self) -> bool:
+        """After densification the parameter tensors change size: re-carve the slab (returns True if it did)."""
+        if all(v.shape == p.shape for v, p in zip(self.views, self.params)):
+            return False
+        self.__init__(self.params, self.group, self.agree_presence)
+        return True
+
+    def sink(self, names: Sequence[str]) -> Dict[str, torch.Tensor]:
+        """{name: slab view} for the first len(names) parameters, for diff_gaussian_rasterization.grad_sink: the
+        rasterizer's backward writes the gradient of its input `name` into that view."""
+        return {n: v for n, v in zip(names, self.views)}
+
+    def attach(self, zero: bool = True) -> None:
+        """Point every parameter's .grad at its slab view (autograd then accumulates into the slab)."""
+        if zero:
+            self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def _gather_stray(self) -> None:
+        # a gradient that is not already the slab view (autograd made a fresh tensor) is copied in once
+        pres = []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                pres.append(0.0)
+                v.zero_()
+                continue
+            pres.append(1.0)
+            if g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+                v.copy_(g)
+                p.grad = v
+        self._local_presence = pres
+        if self.agree_presence:
+            self.presence.copy_(torch.tensor(pres, dtype=torch.float32), non_blocking=True)
+
+    def allreduce_async(self, average: bool = False, force: bool = False) -> None:
+        """Sum (or average) the slab over all ranks on the communication stream.  Parameters whose .grad is None
+        here contribute zeros.  `force` issues the collective even with a single rank (a one-GPU rehearsal of the
+        whole code path: process group, communication stream, RCCL launch)."""
+        world = _world(self.group)
+        if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
+            self._pending = False
+            return
+        self._gather_stray()
+        self._average = average
+        if self._comm is not None:
+            self._comm.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                if self.agree_presence:
+                    dist.all_reduce(self.presence, op=dist.ReduceOp.MAX, group=self.group)
+                if average:
+                    self.flat.div_(world)
+        else:  # CPU tensors (gloo tests): genuinely asynchronous work handles
+            self._work = [dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+            if self.agree_presence:
+                self._work.append(dist.all_reduce(self.presence, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+        self._pending = True
+
+    def wait(self) -> None:
+        """Make the reduced gradients visible to the compute stream and restore `.grad = None` where no rank had one."""
+        if not self._pending:
+            return
+        if self._comm is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
+        else:
+            for w in self._work:
+                w.wait()
+            self._work = []
+            if self._average:
+                self.flat.div_(_world(self.group))
+        # agree_presence: one small read-back per step, after the collective; otherwise the local pattern is everyone's
+        pres = self.presence.tolist() if self.agree_presence else self._local_presence
+        for p, v, has in zip(self.params, self.views, pres):
+            p.grad = v if has > 0 else None
+        self._pending = False
+
+    def allreduce(self, average: bool = False) -> torch.Tensor:
+        self.allreduce_async(average)
+        self.wait()
+        return self.flat
 
 
 def allreduce_gradients(params: Sequence[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
-                        average: bool = False) -> torch.Tensor:
-    """Sum (or average) the gradients of `params` over all ranks with ONE all-reduce."""
-    flat = flatten_grads(params)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat /= dist.get_world_size(group)
-    unflatten_to_grads(flat, params)
-    return flat
+                        average: bool = False, slab: Optional[GradSlab] = None) -> Optional[torch.Tensor]:
+    """Sum (or average) the gradients of `params` over all ranks with ONE all-reduce.  World size 1: nothing to do
+    (gradients stay where they are, None stays None).  Pass a persistent `slab` to avoid the per-call packing;
+    without one the presence pattern is agreed across ranks (a parameter that has a gradient on any rank gets the sum)."""
+    if _world(group) == 1:
+        return None
+    if slab is None:
+        slab = GradSlab(params, group, agree_presence=True)
+    return slab.allreduce(average)
 
 
 def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, xyz_gradient_accum_abs: torch.Tensor,
                                denom: torch.Tensor, max_radii2D: torch.Tensor,
+                               xyz_gradient_accum_abs_max: Optional[torch.Tensor] = None,
                                group: Optional[dist.ProcessGroup] = None) -> None:
     """In-place reduction of the per-view densification statistics: sums for the gradient-norm
-    accumulators and the visit counter, max for the screen-space radius."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    accumulators and the visit counter, max for the screen-space radius and the abs-gradient maximum."""
+    if _world(group) == 1:
         return
     packed = torch.cat([xyz_gradient_accum.reshape(-1), xyz_gradient_accum_abs.reshape(-1), denom.reshape(-1)])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
@@ -70,15 +196,25 @@ def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, xyz_gradient_ac
     xyz_gradient_accum.copy_(packed[:n].view_as(xyz_gradient_accum))
     xyz_gradient_accum_abs.copy_(packed[n:2 * n].view_as(xyz_gradient_accum_abs))
     denom.copy_(packed[2 * n:].view_as(denom))
-    dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+    if xyz_gradient_accum_abs_max is not None:
+        mx = torch.cat([max_radii2D.reshape(-1).to(xyz_gradient_accum_abs_max.dtype), xyz_gradient_accum_abs_max.reshape(-1)])
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        m = max_radii2D.numel()
+        max_radii2D.copy_(mx[:m].view_as(max_radii2D).to(max_radii2D.dtype))
+        xyz_gradient_accum_abs_max.copy_(mx[m:].view_as(xyz_gradient_accum_abs_max))
+    else:
+        dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
 
 
 def per_view_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """What ONE view contributes (scene/gaussian_model.py:933-945): |grad[:, :2]|, grad[:, 2:], 1 for
-    visible Gaussians; radii for the running max."""
+    """What ONE view contributes (scene/gaussian_model.py:933-945): ||grad[:, :2]|| to xyz_gradient_accum,
+    |grad_x| + |grad_y| to xyz_gradient_accum_abs and (as a running max) to xyz_gradient_accum_abs_max, 1 to denom, for
+    visible Gaussians; radii for the running max of max_radii2D (train.py:495-498).  Same arithmetic as the
+    library's one-pass gigs_densify_stats (densify.add_densification_stats), which is what a training loop calls."""
     vis = radii > 0
     z = torch.zeros((viewspace_grad.shape[0], 1), dtype=viewspace_grad.dtype, device=viewspace_grad.device)
     accum = torch.where(vis[:, None], torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True), z)
-    accum_abs = torch.where(vis[:, None], viewspace_grad[:, 2:3], z)
-    return dict(xyz_gradient_accum=accum, xyz_gradient_accum_abs=accum_abs, denom=vis[:, None].to(viewspace_grad.dtype),
-                max_radii2D=radii.to(viewspace_grad.dtype))
+    abs_xy = viewspace_grad[:, 0:1].abs() + viewspace_grad[:, 1:2].abs()
+    accum_abs = torch.where(vis[:, None], abs_xy, z)
+    return dict(xyz_gradient_accum=accum, xyz_gradient_accum_abs=accum_abs, xyz_gradient_accum_abs_max=accum_abs.clone(),
+                denom=vis[:, None].to(viewspace_grad.dtype), max_radii2D=radii.to(viewspace_grad.dtype))

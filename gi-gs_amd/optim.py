@@ -19,12 +19,41 @@ _lib = gigs_lib.lib()
 
 
 class FusedAdam(torch.optim.Optimizer):
-    """torch.optim.Adam(params, lr, betas, eps) without weight decay / amsgrad, fp32 parameters on one GPU."""
+    """torch.optim.Adam(params, lr, betas, eps) without weight decay / amsgrad, fp32 parameters on one GPU.
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+    The param-group dictionaries carry every key torch.optim.Adam's groups carry (at their inert defaults), so a
+    `state_dict()` written here -- e.g. inside a `chkpntN.pth` by scene_io.capture -- loads into the reference's
+    `torch.optim.Adam` (GaussianModel.restore, scene/gaussian_model.py:151-176) and steps there."""
+
+    # torch.optim.Adam's remaining group keys and the only values this optimizer implements
+    _INERT = dict(weight_decay=0.0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                  fused=None, decoupled_weight_decay=False)
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, **kw):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("FusedAdam: invalid lr / eps / betas")
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        for k, v in kw.items():
+            if k not in self._INERT:
+                raise TypeError(f"FusedAdam: unexpected argument {k!r}")
+            self._check_inert(k, v)
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, **self._INERT))
+
+    @classmethod
+    def _check_inert(cls, key, value):
+        if key in ("weight_decay",) and float(value or 0.0) != 0.0:
+            raise ValueError("FusedAdam implements no weight decay (the reference uses none)")
+        if key in ("amsgrad", "maximize", "capturable", "differentiable", "decoupled_weight_decay") and bool(value):
+            raise ValueError(f"FusedAdam does not implement {key}=True")
+
+    def load_state_dict(self, state_dict):
+        for g in state_dict.get("param_groups", []):
+            for k in self._INERT:
+                if k in g:
+                    self._check_inert(k, g[k])
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:  # a dict saved by an older FusedAdam lacks the inert keys
+            for k, v in self._INERT.items():
+                g.setdefault(k, v)
 
     @torch.no_grad()
     def step(self, closure=None, zero_grad: bool = False):

@@ -15,22 +15,6 @@ from .renderutils import diffuse_cubemap, specular_cubemap
 _lib = gigs_lib.lib()
 
 
-def cube_to_dir(s: int, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:  # pbr/light.py:38-51
-    if s == 0:
-        rx, ry, rz = torch.ones_like(x), -y, -x
-    elif s == 1:
-        rx, ry, rz = -torch.ones_like(x), -y, x
-    elif s == 2:
-        rx, ry, rz = x, torch.ones_like(x), y
-    elif s == 3:
-        rx, ry, rz = x, -torch.ones_like(x), -y
-    elif s == 4:
-        rx, ry, rz = x, -y, torch.ones_like(x)
-    elif s == 5:
-        rx, ry, rz = -x, -y, -torch.ones_like(x)
-    return torch.stack((rx, ry, rz), dim=-1)
-
-
 class cubemap_mip(torch.autograd.Function):
     """pbr/light.py:54-79: forward = 2x2 average pool, backward = bilinear cube lookup of 0.25*dout."""
 

@@ -1,8 +1,9 @@
-"""CPU, world_size 2, gloo: the view-parallel gradient / statistics reduction (gi-gs_amd/dp.py)."""
+"""CPU, world_size 2, gloo: the view-parallel gradient / statistics reduction (gi-gs_amd/dp.py) -- the flat
+gradient slab with the asynchronous (communication-side) all-reduce, gradient-less parameters, densification
+statistics reduced as statistics, and replicated densification decisions."""
 import os
 import socket
 
-import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -23,25 +24,65 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, root)
     importlib.import_module("gi-gs_amd")
     import dp
+    from oracle import densify_ref
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(100 + rank)
     P = 257
     params = [torch.zeros(P, 3, requires_grad=True), torch.zeros(P, 9, 3, requires_grad=True),
-              torch.zeros(P, 1, requires_grad=True), torch.zeros(P, 4, requires_grad=True)]
+              torch.zeros(P, 1, requires_grad=True), torch.zeros(P, 4, requires_grad=True),
+              torch.zeros(P, 2, requires_grad=True)]
     grads = [torch.randn(p.shape, generator=g) for p in params]
-    for p, gr in zip(params[:-1], grads[:-1]):
-        p.grad = gr.clone()  # the last parameter has no gradient on purpose
-    flat = dp.allreduce_gradients(params)
+    for p, gr in zip(params[:3], grads[:3]):
+        p.grad = gr.clone()
+    # params[3] has no gradient on any rank; params[4] has one on rank 1 only
+    if rank == 1:
+        params[4].grad = grads[4].clone()
+    flat = dp.allreduce_gradients(params)  # convenience path: presence agreed across ranks
     assert flat.numel() == sum(p.numel() for p in params)
+    conv = [None if p.grad is None else p.grad.clone() for p in params]
+
+    # the persistent slab, asynchronous: gradients born in the slab (views), one stray tensor, one absent parameter
+    slab = dp.GradSlab(params[:4])
+    sink = slab.sink(["a", "b", "c", "d"])
+    assert sink["b"].data_ptr() == slab.views[1].data_ptr()
+    out = []
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        local = [torch.randn(p.shape, generator=g) for p in params[:3]]
+        sink["a"].copy_(local[0]); params[0].grad = sink["a"]          # written in place (rasterizer backward + grad_sink)
+        sink["b"].copy_(local[1]); params[1].grad = sink["b"]
+        params[2].grad = local[2].clone()                                # a stray tensor: copied into the slab once
+        slab.allreduce_async()
+        busy = torch.randn(64, 64, generator=g) @ torch.randn(64, 64, generator=g)  # work beside the collective
+        slab.wait()
+        assert params[0].grad.data_ptr() == slab.views[0].data_ptr() and params[2].grad.data_ptr() == slab.views[2].data_ptr()
+        out.append(dict(local=local, reduced=[None if p.grad is None else p.grad.clone() for p in params[:4]], busy=float(busy.sum())))
+
     # statistics
     vg = torch.randn(P, 3, generator=g)
     radii = torch.randint(0, 30, (P,), generator=g)
     st = dp.per_view_densification_stats(vg, radii)
-    dp.reduce_densification_stats(st["xyz_gradient_accum"], st["xyz_gradient_accum_abs"], st["denom"], st["max_radii2D"])
+    dp.reduce_densification_stats(st["xyz_gradient_accum"], st["xyz_gradient_accum_abs"], st["denom"], st["max_radii2D"],
+                                  st["xyz_gradient_accum_abs_max"])
+    # replicated densification: identical reduced statistics + identically seeded draws -> identical decisions
+    gm = torch.Generator().manual_seed(7)  # the same on every rank
+    prm = {n: torch.randn(P, *s, generator=gm) for n, s in
+           zip(densify_ref.NAMES, [(3,), (1, 3), (3, 3), (1,), (3,), (3,), (1,), (1,), (3,), (4,)])}
+    prm["scaling"] = prm["scaling"] * 0.3 - 3.0
+    stats = dict(accum=st["xyz_gradient_accum"].clone(), accum_abs=st["xyz_gradient_accum_abs"].clone(),
+                 accum_abs_max=st["xyz_gradient_accum_abs_max"].clone(), denom=st["denom"].clone(),
+                 max_radii2D=st["max_radii2D"].clone())
+    model = dict(params=prm, exp_avg={n: torch.zeros_like(t) for n, t in prm.items()},
+                 exp_avg_sq={n: torch.zeros_like(t) for n, t in prm.items()}, stats=stats)
+    z_clone, z_split = torch.randn(P, 3, generator=gm), torch.randn(4 * P, 3, generator=gm)
+    densify_ref.densify_and_prune(model, 0.6, 0.005, 2.0, None, z_clone, z_split)
+    dens = {n: model["params"][n].clone() for n in densify_ref.NAMES}
+    assert dens["xyz"].shape[0] != P  # something was cloned / split / pruned
     views = [dp.view_for(s, rank, world, 7) for s in range(5)]
-    torch.save(dict(grads=[p.grad for p in params], local=grads, vg=vg, radii=radii, stats=st, views=views),
+    torch.save(dict(conv=conv, local=grads, slab=out, vg=vg, radii=radii, stats=st, views=views, dens=dens),
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -51,22 +92,38 @@ def test_view_parallel_reduction_world2(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r = [torch.load(os.path.join(tmp_path, f"r{k}.pt")) for k in range(world)]
-    # every rank holds the same, summed gradients; the gradient-less parameter reduces to zeros
+    # every rank holds the same, summed gradients
     for i in range(3):
         want = r[0]["local"][i] + r[1]["local"][i]
         for k in range(world):
-            torch.testing.assert_close(r[k]["grads"][i], want)
-    assert float(r[0]["grads"][3].abs().sum()) == 0.0
-    # statistics: sums of per-view norms (NOT the norm of the summed gradient), max of radii
+            torch.testing.assert_close(r[k]["conv"][i], want)
+    for k in range(world):
+        assert r[k]["conv"][3] is None            # no gradient anywhere: stays None (Adam must skip it, as on one GPU)
+        torch.testing.assert_close(r[k]["conv"][4], r[1]["local"][4])  # a gradient on one rank only: the other adds zeros
+    # the slab path, two consecutive steps
+    for step in range(2):
+        for i in range(3):
+            want = r[0]["slab"][step]["local"][i] + r[1]["slab"][step]["local"][i]
+            for k in range(world):
+                torch.testing.assert_close(r[k]["slab"][step]["reduced"][i], want)
+        assert r[0]["slab"][step]["reduced"][3] is None and r[1]["slab"][step]["reduced"][3] is None
+    # statistics: sums of per-view norms (NOT the norm of the summed gradient), max of radii and of the abs term
     vis = [x["radii"] > 0 for x in r]
-    want_accum = sum(torch.where(v[:, None], torch.norm(x["vg"][:, :2], dim=-1, keepdim=True), torch.zeros(1)) for v, x in zip(vis, r))
+    zero = torch.zeros(1)
+    want_accum = sum(torch.where(v[:, None], torch.norm(x["vg"][:, :2], dim=-1, keepdim=True), zero) for v, x in zip(vis, r))
+    abs_xy = [torch.where(v[:, None], x["vg"][:, 0:1].abs() + x["vg"][:, 1:2].abs(), zero) for v, x in zip(vis, r)]
     want_denom = sum(v[:, None].float() for v in vis)
     want_max = torch.maximum(r[0]["radii"], r[1]["radii"]).float()
     for k in range(world):
         torch.testing.assert_close(r[k]["stats"]["xyz_gradient_accum"], want_accum)
+        torch.testing.assert_close(r[k]["stats"]["xyz_gradient_accum_abs"], abs_xy[0] + abs_xy[1])   # gaussian_model.py:941-943
+        torch.testing.assert_close(r[k]["stats"]["xyz_gradient_accum_abs_max"], torch.maximum(abs_xy[0], abs_xy[1]))  # :944
         torch.testing.assert_close(r[k]["stats"]["denom"], want_denom)
         torch.testing.assert_close(r[k]["stats"]["max_radii2D"], want_max)
     summed_norm = torch.norm((r[0]["vg"] + r[1]["vg"])[:, :2], dim=-1, keepdim=True)
     assert not torch.allclose(want_accum, summed_norm)
+    # replicated densification decisions are identical across ranks
+    for n in r[0]["dens"]:
+        assert torch.equal(r[0]["dens"][n], r[1]["dens"][n]), n
     # views are disjoint across ranks within a step and cover the set round-robin
     assert r[0]["views"] == [0, 2, 4, 6, 1] and r[1]["views"] == [1, 3, 5, 0, 2]

@@ -33,8 +33,10 @@ def rel_peak(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-20)
 
 
-@pytest.mark.parametrize("res,level_rough", [(16, 1.0), (32, 0.5), (64, 0.36), (128, 0.22)])
+@pytest.mark.parametrize("res,level_rough", [(16, 1.0), (32, 0.5), (64, 0.36), (128, 0.22), (256, 0.08)])
 def test_cubemap_filters_match_oracle(orc, res, level_rough):
+    """Each level of the 5-level chain bench.py runs (base_res = 256: 256^2 at GGX roughness 0.08 ... 16^2 at 1.0):
+    window bounds bit-exact, forward and backward against the oracle."""
     from pbr.renderutils import ops
     rng = np.random.default_rng(res)
     cm = rng.uniform(0, 1, size=(6, res, res, 3)).astype(np.float32)
@@ -78,13 +80,16 @@ def test_cubemap_mip_matches_oracle(orc):
     np.testing.assert_allclose(x.grad.cpu().numpy(), orc.cubemap_mip_bwd(g), atol=1e-6)
 
 
-@pytest.mark.parametrize("tone,gamma,use_metal", [(False, False, True), (True, True, True), (False, True, False)])
-def test_shade_forward_and_backward(orc, tone, gamma, use_metal):
+@pytest.mark.parametrize("tone,gamma,use_metal,base", [(False, False, True, 64), (True, True, True, 64), (False, True, False, 64),
+                                                        (False, False, True, 256)])
+def test_shade_forward_and_backward(orc, tone, gamma, use_metal, base):
+    """base = 256 is the light bench.py times: five specular levels, the finest ones accumulate their gradient with
+    global float atomics, the coarse ones in LDS."""
     import pbr
     rng = np.random.default_rng(7)
     H, W = 48, 80
     g = make_gbuffer(rng, H, W)
-    diffuse, spec = light_levels(orc, make_light(rng, 64))
+    diffuse, spec = light_levels(orc, make_light(rng, base))
     lut = lut_np()
     bg = rng.uniform(size=(H, W, 3)).astype(np.float32)
     ref = orc.shade_fwd(g["normals"], g["view_dirs"], g["albedo"], g["roughness"], g["mask"], g["occlusion"],

@@ -90,3 +90,45 @@ def test_checkpoint_round_trip_keeps_the_reference_tuple(tmp_path):
     torch.save({"something": 1}, path)
     with pytest.raises(ValueError, match="not a GI-GS checkpoint"):
         scene_io.load_checkpoint(path)
+
+
+def test_fused_adam_checkpoint_resumes_under_torch_adam(tmp_path):
+    """A chkpntN.pth written while training with FusedAdam must load into the reference's torch.optim.Adam
+    (GaussianModel.restore, scene/gaussian_model.py:151-176) AND step there: the saved param_groups carry every
+    key torch's Adam reads (weight_decay, amsgrad, maximize, ...)."""
+    import types
+    import optim
+    p = {n: torch.nn.Parameter(t) for n, t in _params(P=9).items()}
+    lrs = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=0.05, normal=0.05, albedo=0.05, roughness=0.05,
+               metallic=0.05, scaling=5e-3, rotation=1e-3)
+    opt = optim.FusedAdam([{"params": [p[n]], "lr": lrs[n], "name": n} for n in scene_io.NAMES], lr=0.0, eps=1e-15)
+    ref_keys = set(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]).param_groups[0].keys())
+    assert ref_keys <= set(opt.param_groups[0].keys()), ref_keys - set(opt.param_groups[0].keys())
+    # the state FusedAdam.step() leaves behind after two updates (the step itself needs a GPU: tests/test_gpu_losses.py)
+    for t in p.values():
+        opt.state[t] = {"step": torch.tensor(2.0), "exp_avg": torch.full_like(t, 0.01), "exp_avg_sq": torch.full_like(t, 1e-4)}
+    stats = types.SimpleNamespace(max_radii2D=torch.zeros(9), xyz_gradient_accum=torch.zeros(9, 1),
+                                  xyz_gradient_accum_abs=torch.zeros(9, 1), xyz_gradient_accum_abs_max=torch.zeros(9, 1),
+                                  denom=torch.zeros(9, 1))
+    path = os.path.join(tmp_path, "chkpnt7000.pth")
+    scene_io.save_checkpoint(path, scene_io.capture(2, p, stats, opt, 1.0), {"base": torch.rand(6, 4, 4, 3)},
+                             {"state": {}, "param_groups": []}, 7000)
+    _, params, _, opt_dict, _ = scene_io.restore(scene_io.load_checkpoint(path)["gaussians"])
+    q = {n: torch.nn.Parameter(params[n].clone()) for n in scene_io.NAMES}
+    ref = torch.optim.Adam([{"params": [q[n]], "lr": 0.0, "name": n} for n in scene_io.NAMES], lr=0.0, eps=1e-15)
+    ref.load_state_dict(opt_dict)
+    before = q["xyz"].detach().clone()
+    for t in q.values():
+        t.grad = torch.ones_like(t)
+    ref.step()  # KeyError 'weight_decay' before the inert keys were saved
+    assert float(ref.state[q["xyz"]]["step"]) == 3.0 and not torch.equal(q["xyz"].detach(), before)
+    # and the other direction still works; non-default values of the inert keys are refused, not ignored
+    back = optim.FusedAdam([{"params": [q[n]], "lr": 0.0, "name": n} for n in scene_io.NAMES], lr=0.0, eps=1e-15)
+    back.load_state_dict(ref.state_dict())
+    assert back.param_groups[0]["lr"] == 1.6e-4
+    with pytest.raises(ValueError):
+        optim.FusedAdam([torch.nn.Parameter(torch.zeros(1))], weight_decay=0.1)
+    sd = ref.state_dict()
+    sd["param_groups"][0]["amsgrad"] = True
+    with pytest.raises(ValueError):
+        back.load_state_dict(sd)
