@@ -313,7 +313,8 @@ def main():
             raise SystemExit("--config c3 needs the HIP shade")
         hdri = torch.from_numpy(scenes.synthetic_envmap(512, 1024, seed=1)).to(dev)
         light = relight.make_light(hdri, res=256)
-        relighter = relight.Relighter(light, gi, args.sh_degree, metallic=False, fused=(args.fused == "on"), brdf_lut=brdf_lut)
+        relighter = relight.Relighter(light, gi, args.sh_degree, metallic=False, fused=(args.fused == "on"), brdf_lut=brdf_lut,
+                                      graphs=(args.graphs == "on"))
         g_inf = {k: v.detach() for k, v in g.items()}
     elif shade == "hip":
         stepper = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=(args.graphs == "on"),

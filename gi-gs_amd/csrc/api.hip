@@ -6,6 +6,7 @@
 // chunks obtained from the caller through allocation callbacks.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <atomic>
@@ -100,6 +101,15 @@ const char* kStageNames[kNumStages] = {
 
 // optional event recorded on the forward's stream right before the blend kernel is launched (gigs_set_blend_begin_event)
 std::atomic<void*> g_blend_begin_event{nullptr};
+// gigs_set_async_binning: capacity > 0 -> the next forwards bin into a chunk of that many instances, read nothing back
+std::atomic<unsigned> g_async_capacity{0};
+std::atomic<void*> g_async_counters{nullptr};
+
+// GIGS_BINNING=legacy: the reference-shaped scan / duplicate / global radix sort / tile-ranges path
+bool binning_bucketed() {
+  const char* e = getenv("GIGS_BINNING");
+  return !(e && strcmp(e, "legacy") == 0);
+}
 
 struct ProfRec { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -200,6 +210,11 @@ long long gigs_image_offset(int width, int height, int which) {
 
 void gigs_set_blend_begin_event(void* hip_event) { g_blend_begin_event.store(hip_event); }
 
+void gigs_set_async_binning(int r_capacity, unsigned* device_counters) {
+  g_async_capacity.store(r_capacity > 0 ? (unsigned)r_capacity : 0u);
+  g_async_counters.store(r_capacity > 0 ? (void*)device_counters : nullptr);
+}
+
 void gigs_profile_begin(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
@@ -287,24 +302,64 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
     gigs::launch_preprocess_fwd(a, geom, radii, s);
   }
   STAGE_CHECK("preprocess");
+  int num_rendered = 0;
+  gigs::BinningState bin;
+  const unsigned async_cap = g_async_capacity.load();
+  const bool bucket = binning_bucketed() && T <= (size_t)gigs::kBinMaxTiles;
+  if (async_cap > 0 && !bucket) return fail(GIGS_ERR_INVALID, "asynchronous binning needs the tile-bucketed path (GIGS_BINNING, <= %d tiles)", gigs::kBinMaxTiles);
+  if (bucket) {
+    // Tile-bucketed binning (binning.hip): count -> prefix -> scatter -> per-tile sort, the instance count stays on
+    // the device.  Synchronous calls (the reference's API returns num_rendered) read it back once, BEFORE the scatter,
+    // to size the binning chunk exactly; with gigs_set_async_binning the chunk has the caller's capacity and nothing
+    // is read back.
+    {
+      StageScope sc(kDuplicate, s);
+      gigs::launch_bin_count(P, radii, a.gx, a.gy, geom, img, s);
+      gigs::launch_bin_prefix(P, (int)T, async_cap > 0 ? async_cap : 0x7fffffffu, img, (unsigned*)g_async_counters.load(), s);
+    }
+    STAGE_CHECK("bin count / prefix");
+    if (async_cap > 0) {
+      num_rendered = (int)async_cap;
+    } else {
+      uint32_t num_rendered_u = 0;
+      HIP_TRY(hipMemcpyAsync(&num_rendered_u, img.bin_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (num_rendered_u > 0x7fffffffu) return fail(GIGS_ERR_INVALID, "num_rendered overflows int");
+      num_rendered = (int)num_rendered_u;
+    }
+    const size_t sort_sz = sort_size_cached(num_rendered);
+    const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)num_rendered, sort_sz);
+    char* bin_chunk = binningBuffer(bin_bytes, binning_user);
+    if (!bin_chunk) return fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
+    bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, sort_sz);
+    {
+      StageScope sc(kRanges, s);
+      gigs::launch_tile_order((int)T, img.ranges, img.tile_order, s);
+    }
+    {
+      StageScope sc(kSort, s);
+      gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, geom, bin, img, s);
+      if (gigs::launch_bin_sort((int)T, bin, img, s) != 0) return fail(GIGS_ERR_HIP, "bin_sort: cannot raise the LDS limit");
+    }
+    STAGE_CHECK("bin scatter / sort");
+  } else {
   {
     StageScope sc(kScan, s);
     HIP_TRY(gigs::scan_tiles(geom, P, s));
   }
   STAGE_CHECK("scan");
-
   // the one blocking read of the forward (rasterizer_impl.cu:589): sizes the binning chunk
   uint32_t num_rendered_u = 0;
   HIP_TRY(hipMemcpyAsync(&num_rendered_u, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (num_rendered_u > 0x7fffffffu) return fail(GIGS_ERR_INVALID, "num_rendered overflows int");
-  const int num_rendered = (int)num_rendered_u;
+  num_rendered = (int)num_rendered_u;
 
   const size_t sort_sz = sort_size_cached(num_rendered);
   const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)num_rendered, sort_sz);
   char* bin_chunk = binningBuffer(bin_bytes, binning_user);
   if (!bin_chunk) return fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
-  gigs::BinningState bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, sort_sz);
+  bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, sort_sz);
 
   {
     StageScope sc(kDuplicate, s);
@@ -324,6 +379,7 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
     gigs::launch_tile_order((int)T, img.ranges, img.tile_order, s);
   }
   STAGE_CHECK("identifyTileRanges");
+  }
   if (void* ev = g_blend_begin_event.load()) HIP_TRY(hipEventRecord((hipEvent_t)ev, s));
   {
     StageScope sc(kBlendFwd, s);
@@ -389,7 +445,7 @@ int gigs_backward(int P, int D, int M, int R, const float* background, int width
 
   {
     StageScope sc(kBlendBwd, s);
-    HIP_TRY(hipMemsetAsync(geom.grec, 0, (size_t)P * GIGS_GREC * sizeof(float), s));
+    gigs::launch_zero_words(reinterpret_cast<uint32_t*>(geom.grec), (size_t)P * GIGS_GREC, s);  // a kernel, not a memset node: capturable
     gigs::launch_blend_bwd(a, geom, bin, img, s);
   }
   STAGE_CHECK("render backward");

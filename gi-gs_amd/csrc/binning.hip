@@ -10,6 +10,7 @@
 //
 // All stages are integer, HBM-bound work (12 B written per instance by the
 // expansion, 24 B moved per instance per sort pass).
+#include <algorithm>
 #include <cstring>
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -131,6 +132,342 @@ void launch_tile_order(int T, const uint2* ranges, uint32_t* tile_order, hipStre
 void launch_tile_ranges(int R, const BinningState& b, uint2* ranges, hipStream_t s) {
   if (R > 0)
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.keys, ranges);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Tile-bucketed binning (the default; GIGS_BINNING=legacy selects the reference-shaped path above)
+// ------------------------------------------------------------------------------------------
+// The reference expands every Gaussian into (tile | depth, index) pairs in Gaussian order and sorts ALL of them
+// with a global 32+bit-bit radix sort (rasterizer_impl.cu:585-621): six passes over 24 B per instance, plus a host
+// read of the instance count in the middle of the forward.  What the blend needs is only, per tile, the list of its
+// Gaussians ordered by depth with ties in Gaussian-index order (a stable sort of index-ordered input).  Here:
+//   1. bin_count:   <= kBinGroups workgroups, each over a contiguous chunk of Gaussians, histogram their tiles in
+//                   LDS (ds_add; large footprints are expanded by the whole wave) -> bin_hist[g][t];
+//   2. bin_prefix:  per tile, exclusive prefix of the counts over the chunks (in place) and the tile's total; then an
+//                   exclusive scan of the totals = `ranges` (identifyTileRanges' result) and R -- all on the device;
+//   3. bin_scatter: the same walk again; a slot inside the tile's range comes from an LDS cursor, the 64-bit key
+//                   (depth bits << 32 | Gaussian index) goes there.  The order inside a tile is arbitrary here...
+//   4. bin_sort:    ...because each tile's keys are then sorted (one workgroup per tile, bitonic network in LDS, longest
+//                   lists first).  The keys are unique and (depth, index)-ordered = the stable depth sort of
+//                   index-ordered input, so point_list -- and `keys` in the reference's tile|depth format, which is
+//                   written too -- equal the reference's bit for bit.
+// No host read-back anywhere: with a caller-given capacity (gigs_set_async_binning) the forward never synchronises and
+// can be captured into a hipGraph; R and an overflow flag stay in device memory.  Instances beyond the capacity are
+// dropped (ranges are clamped, the flag is raised): memory-safe, and the caller replays the step with a larger capacity.
+__device__ __forceinline__ bool bin_rect(int idx, int end, const int* __restrict__ radii, const float* __restrict__ means2D,
+                                         unsigned gx, unsigned gy, unsigned& minx, unsigned& miny, unsigned& w, unsigned& n) {
+  minx = miny = w = n = 0;
+  if (idx >= end) return false;
+  const int r = radii[idx];
+  if (r <= 0) return false;
+  const float2 xy = reinterpret_cast<const float2*>(means2D)[idx];
+  unsigned maxx, maxy;
+  tile_rect(xy.x, xy.y, r, gx, gy, minx, miny, maxx, maxy);
+  w = maxx - minx;
+  n = w * (maxy - miny);
+  return n > 0;
+}
+
+constexpr unsigned kBinWaveExpand = 12;  // footprints with more tiles than this are expanded by the whole wave
+
+// Walks the tiles of the chunk's Gaussians; f(idx, tile) is called once per (Gaussian, tile) pair.
+template <typename F>
+__device__ __forceinline__ void bin_walk(int P, const int* __restrict__ radii, const float* __restrict__ means2D, unsigned gx,
+                                         unsigned gy, F f) {
+  const int groups = min((int)kBinGroups, (P + 255) / 256);
+  const int chunk = (P + groups - 1) / groups;
+  const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
+  const int lane = threadIdx.x & 63;
+  for (int base = begin; base < end; base += blockDim.x) {
+    const int idx = base + threadIdx.x;
+    unsigned minx, miny, w, n;
+    const bool any = bin_rect(idx, end, radii, means2D, gx, gy, minx, miny, w, n);
+    const bool big = any && n > kBinWaveExpand;
+    if (any && !big) {
+      unsigned x = 0, y = 0;
+      for (unsigned k = 0; k < n; k++) {
+        f(idx, (miny + y) * gx + minx + x);
+        if (++x == w) { x = 0; y++; }
+      }
+    }
+    unsigned long long m = __builtin_amdgcn_ballot_w64(big);
+    while (m) {
+      const int l = __builtin_ctzll(m);
+      m &= m - 1;
+      const unsigned bminx = __shfl(minx, l), bminy = __shfl(miny, l), bw = __shfl(w, l), bn = __shfl(n, l);
+      const int bidx = __shfl(idx, l);
+      const unsigned bh = bn / max(bw, 1u);  // once per large footprint
+      for (unsigned y = 0; y < bh; y++)
+        for (unsigned x = lane; x < bw; x += 64) f(bidx, (bminy + y) * gx + bminx + x);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bin_count_kernel(int P, int T, const int* __restrict__ radii, const float* __restrict__ means2D, unsigned gx, unsigned gy,
+                 uint32_t* __restrict__ bin_hist) {
+  extern __shared__ uint32_t s_hist[];
+  for (int t = threadIdx.x; t < T; t += 256) s_hist[t] = 0;
+  __syncthreads();
+  bin_walk(P, radii, means2D, gx, gy, [&](int, unsigned tile) { atomicAdd(&s_hist[tile], 1u); });
+  __syncthreads();
+  uint32_t* row = bin_hist + (size_t)blockIdx.x * T;
+  for (int t = threadIdx.x; t < T; t += 256) row[t] = s_hist[t];
+}
+
+// per tile: exclusive prefix over the chunk counts (in place) and the total
+__global__ void __launch_bounds__(1024)
+bin_prefix_groups_kernel(int groups, int T, uint32_t* __restrict__ bin_hist, uint32_t* __restrict__ totals) {
+  // 64 tiles x 16 chunk-parts per workgroup: coalesced across tiles, sixteen independent short serial scans per tile
+  __shared__ uint32_t s_q[16][64];
+  const int tl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tl;
+  const int per = (groups + 15) / 16, g0 = min(groups, q * per), g1 = min(groups, g0 + per);
+  uint32_t c[16];
+  uint32_t run = 0;
+  if (t < T) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) c[k] = (g0 + k < g1) ? bin_hist[(size_t)(g0 + k) * T + t] : 0u;  // per <= 16 (kBinGroups = 256)
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const uint32_t v = c[k]; c[k] = run; run += v; }
+  }
+  s_q[q][tl] = run;
+  __syncthreads();
+  uint32_t add = 0;
+  for (int k = 0; k < q; k++) add += s_q[k][tl];
+  if (t < T) {
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      if (g0 + k < g1) bin_hist[(size_t)(g0 + k) * T + t] = c[k] + add;
+    if (q == 15) totals[t] = add + run;
+  }
+}
+
+// exclusive scan of the tile totals -> ranges (clamped to the capacity), R and the overflow flag.  One workgroup.
+__global__ void __launch_bounds__(1024)
+bin_prefix_tiles_kernel(int T, unsigned capacity, const uint32_t* __restrict__ totals, uint2* __restrict__ ranges,
+                        uint32_t* __restrict__ tile_start, uint32_t* __restrict__ counters,
+                        uint32_t* __restrict__ user_counters) {
+  __shared__ uint32_t s_sum[1024];
+  const int per = (T + 1023) / 1024;
+  const int t0 = threadIdx.x * per, t1 = min(T, t0 + per);
+  uint32_t local = 0;
+  for (int t = t0; t < t1; t++) local += totals[t];
+  s_sum[threadIdx.x] = local;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t v = threadIdx.x >= (unsigned)off ? s_sum[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s_sum[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = s_sum[threadIdx.x] - local;
+  for (int t = t0; t < t1; t++) {
+    const uint32_t c = totals[t];
+    // an empty tile keeps (0, 0), what the reference's memset leaves there (rasterizer_impl.cu:621)
+    ranges[t] = c ? make_uint2(min(run, capacity), min(run + c, capacity)) : make_uint2(0u, 0u);
+    tile_start[t] = run;  // unclamped: the scatter's cursors start here even when an overflow clamped the ranges
+    run += c;
+  }
+  if (threadIdx.x == 1023) {
+    const uint32_t R = s_sum[1023];
+    counters[0] = R;
+    counters[1] = R > capacity ? R : 0u;
+    if (user_counters) { user_counters[0] = R; user_counters[1] = R > capacity ? R : 0u; }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bin_scatter_kernel(int P, int T, const int* __restrict__ radii, const float* __restrict__ means2D,
+                   const float* __restrict__ depths, unsigned gx, unsigned gy, unsigned capacity,
+                   const uint32_t* __restrict__ bin_hist, const uint32_t* __restrict__ tile_start,
+                   uint64_t* __restrict__ keys) {
+  extern __shared__ uint32_t s_cur[];
+  const uint32_t* row = bin_hist + (size_t)blockIdx.x * T;
+  for (int t = threadIdx.x; t < T; t += 256) s_cur[t] = tile_start[t] + row[t];
+  __syncthreads();
+  bin_walk(P, radii, means2D, gx, gy, [&](int idx, unsigned tile) {
+    const uint32_t slot = atomicAdd(&s_cur[tile], 1u);
+    if (slot < capacity) keys[slot] = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
+  });
+}
+
+// Bitonic network with every compare-exchange ascending (first substage of a merge mirrors the upper half), so an
+// input padded with +inf at the END stays sorted-to-the-front: indices >= n never need to hold data.
+template <typename Get, typename Put>
+__device__ __forceinline__ void bitonic_sort_asc(unsigned n, unsigned npad_log2, unsigned nthreads, Get get, Put put) {
+  const unsigned half = (1u << npad_log2) >> 1;
+  for (unsigned kb = 1; kb <= npad_log2; kb++) {
+    const unsigned k = 1u << kb;
+    for (unsigned i = threadIdx.x; i < half; i += nthreads) {
+      const unsigned blk = i >> (kb - 1), off = i & ((k >> 1) - 1);
+      const unsigned a = (blk << kb) + off, b = (blk << kb) + (k - 1 - off);
+      if (b < n) {
+        const uint64_t x = get(a), y = get(b);
+        if (x > y) { put(a, y); put(b, x); }
+      }
+    }
+    __syncthreads();
+    for (int jb = (int)kb - 2; jb >= 0; jb--) {
+      const unsigned j = 1u << jb;
+      for (unsigned i = threadIdx.x; i < half; i += nthreads) {
+        const unsigned a = ((i >> jb) << (jb + 1)) + (i & (j - 1)), b = a + j;
+        if (b < n) {
+          const uint64_t x = get(a), y = get(b);
+          if (x > y) { put(a, y); put(b, x); }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// The same sort for a list that fits the LDS buffer, padded there to a power of two with +inf: the classic network
+// (direction alternates with bit kb of the index), whose substages all have plain strides, so THREE consecutive substages
+// are done per phase on 8 keys held in registers (strides 4m, 2m, m: keys base + e*m) -- 35 barrier phases instead of 91
+// for 8192 keys, and each phase issues its 8 LDS reads back to back.
+template <int kThreads>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* __restrict__ s, unsigned npad_log2) {
+  const unsigned npad = 1u << npad_log2;
+  for (unsigned kb = 1; kb <= npad_log2; kb++) {
+    int jb = (int)kb - 1;
+    while (jb >= 0) {
+      const int g = min(3, jb + 1);
+      const int lowpos = jb - g + 1;
+      const unsigned m = 1u << lowpos, cnt = 1u << g;
+      const unsigned items = npad >> g;
+      for (unsigned t = threadIdx.x; t < items; t += kThreads) {
+        const unsigned base = ((t >> lowpos) << (lowpos + g)) | (t & (m - 1));
+        const bool asc = ((base >> kb) & 1u) == 0;
+        uint64_t v[8];
+#pragma unroll
+        for (unsigned e = 0; e < 8; e++)
+          if (e < cnt) v[e] = s[base + e * m];
+#pragma unroll
+        for (int sft = 2; sft >= 0; sft--) {
+          if (sft < g) {
+#pragma unroll
+            for (unsigned e = 0; e < 8; e++) {
+              if (!(e & (1u << sft)) && (e | (1u << sft)) < cnt) {
+                const uint64_t a = v[e], b = v[e | (1u << sft)];
+                const bool sw = asc ? (a > b) : (a < b);
+                v[e] = sw ? b : a;
+                v[e | (1u << sft)] = sw ? a : b;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (unsigned e = 0; e < 8; e++)
+          if (e < cnt) s[base + e * m] = v[e];
+      }
+      __syncthreads();
+      jb -= g;
+    }
+  }
+}
+
+// One workgroup per tile, longest lists first.  kLds = capacity of the LDS buffer in keys; lists of (lo, kLds] keys are
+// sorted in LDS by this instantiation, longer ones (only in the last class) in place in global memory, shorter ones belong
+// to a launch with a smaller LDS footprint (more workgroups per CU).
+template <int kThreads, int kLds, bool kLast>
+__global__ void __launch_bounds__(kThreads)
+bin_sort_kernel(int T, unsigned lo, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+                uint64_t* __restrict__ keys_unsorted, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ point_list) {
+  extern __shared__ uint64_t s_keys[];
+  // tile_order lists the tiles longest first, so a class is one contiguous stretch of it: a small persistent grid
+  // strides over the order, skips the longer lists in front and stops at the first list that is too short (a grid of T
+  // workgroups that mostly return at once costs more in dispatch than the sorting itself when each reserves 128 KB of LDS)
+  for (int ob = blockIdx.x; ob < T; ob += gridDim.x) {
+    const uint32_t tile = tile_order[ob];
+    const uint2 rg = ranges[tile];
+    const unsigned n = rg.y - rg.x;
+    if (n <= lo) break;
+    if (!kLast && n > (unsigned)kLds) continue;
+    uint64_t* src = keys_unsorted + rg.x;
+    unsigned npad = 0;  // log2 of the padded length
+    while ((1u << npad) < n) npad++;
+    const uint64_t tile_hi = (uint64_t)tile << 32;
+    if (n <= (unsigned)kLds) {
+      for (unsigned i = threadIdx.x; i < (1u << npad); i += kThreads) s_keys[i] = i < n ? src[i] : ~0ull;
+      __syncthreads();
+      bitonic_sort_lds<kThreads>(s_keys, npad);
+      for (unsigned i = threadIdx.x; i < n; i += kThreads) {
+        const uint64_t k = s_keys[i];
+        point_list[rg.x + i] = (uint32_t)k;
+        keys_out[rg.x + i] = tile_hi | (k >> 32);
+      }
+      __syncthreads();  // the buffer is reused by the next tile of this workgroup
+    } else {
+      // longer than the LDS buffer: the all-ascending network in place in global memory (L2-resident; rare)
+      bitonic_sort_asc(n, npad, kThreads, [&](unsigned i) { return __builtin_nontemporal_load(src + i); },
+                       [&](unsigned i, uint64_t v) { __builtin_nontemporal_store(v, src + i); });
+      for (unsigned i = threadIdx.x; i < n; i += kThreads) {
+        const uint64_t k = __builtin_nontemporal_load(src + i);
+        point_list[rg.x + i] = (uint32_t)k;
+        keys_out[rg.x + i] = tile_hi | (k >> 32);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+  // n is a multiple of 4 for every caller's layout except a short tail
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
+  uint4* p4 = reinterpret_cast<uint4*>(p);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[4 * n4 + threadIdx.x] = 0;
+}
+void launch_zero_words(uint32_t* p, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, s, p, n);
+}
+
+static int bin_groups(int P) { return std::min((int)kBinGroups, (P + 255) / 256); }
+
+void launch_bin_count(int P, const int* radii, unsigned gx, unsigned gy, const GeomState& g, const ImageState& img, hipStream_t s) {
+  const int T = (int)(gx * gy);
+  hipLaunchKernelGGL(bin_count_kernel, dim3(bin_groups(P)), dim3(256), (size_t)T * sizeof(uint32_t), s, P, T, radii, g.means2D,
+                     gx, gy, img.bin_hist);
+}
+
+// the tile totals and the unclamped tile starts live in the two extra rows of bin_hist (ImageState carves kBinGroups + 2)
+void launch_bin_prefix(int P, int T, unsigned capacity, const ImageState& img, unsigned* user_counters, hipStream_t s) {
+  uint32_t* totals = img.bin_hist + (size_t)(kBinGroups) * T;       // carved with two extra rows (ImageState)
+  uint32_t* tile_start = img.bin_hist + (size_t)(kBinGroups + 1) * T;
+  hipLaunchKernelGGL(bin_prefix_groups_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, bin_groups(P), T, img.bin_hist, totals);
+  hipLaunchKernelGGL(bin_prefix_tiles_kernel, dim3(1), dim3(1024), 0, s, T, capacity, totals, img.ranges, tile_start,
+                     img.bin_counters, user_counters);
+}
+
+void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, const GeomState& g,
+                        const BinningState& b, const ImageState& img, hipStream_t s) {
+  const int T = (int)(gx * gy);
+  const uint32_t* tile_start = img.bin_hist + (size_t)(kBinGroups + 1) * T;
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(bin_groups(P)), dim3(256), (size_t)T * sizeof(uint32_t), s, P, T, radii,
+                     g.means2D, g.depths, gx, gy, capacity, img.bin_hist, tile_start, b.keys_unsorted);
+}
+
+int launch_bin_sort(int T, const BinningState& b, const ImageState& img, hipStream_t s) {
+  // three LDS classes: <= 1024 keys (8 KB: many workgroups per CU), <= 4096 (32 KB), <= 16384 (128 KB; longer lists in
+  // global memory).  A workgroup whose tile belongs to another class returns at once.
+  constexpr int kL2 = 16384;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_sort_kernel<1024, kL2, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kL2 * 8) != hipSuccess)
+      return -1;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bin_sort_kernel<1024, kL2, true>), dim3(std::min(T, 256)), dim3(1024), (size_t)kL2 * 8, s, T, 4096u,
+                     img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
+  hipLaunchKernelGGL((bin_sort_kernel<512, 4096, false>), dim3(std::min(T, 1024)), dim3(512), (size_t)4096 * 8, s, T, 1024u,
+                     img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
+  hipLaunchKernelGGL((bin_sort_kernel<256, 1024, false>), dim3(std::min(T, 4096)), dim3(256), (size_t)1024 * 8, s, T, 0u,
+                     img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
+  return 0;
 }
 
 }  // namespace gigs

@@ -170,17 +170,27 @@ struct GeomState {
   }
 };
 
+// Tile-bucketed binning (binning.hip): the Gaussians are cut into at most kBinGroups contiguous chunks, one workgroup
+// each; bin_hist[g * T + t] holds first the number of instances chunk g contributes to tile t and then (in place)
+// their exclusive prefix over the chunks.
+constexpr int kBinGroups = 256;
+constexpr int kBinMaxTiles = 16384;  // the per-workgroup tile histogram lives in LDS (64 KB at this size)
+
 struct ImageState {
   float* final_T;
   uint32_t* n_contrib;
   uint2* ranges;
   uint32_t* tile_order;  // workgroup b of the blend kernels handles tile tile_order[b]: longest lists first
+  uint32_t* bin_hist;    // [kBinGroups + 2][T]
+  uint32_t* bin_counters;  // [0] = R (instances of this forward), [1] = R if it exceeded the capacity (else 0)
   static ImageState fromChunk(char*& chunk, size_t N, size_t T) {
     ImageState s;
     carve(chunk, s.final_T, N);
     carve(chunk, s.n_contrib, N);
     carve(chunk, s.ranges, T);
     carve(chunk, s.tile_order, T);
+    carve(chunk, s.bin_hist, (size_t)(kBinGroups + 2) * T);  // + the tile totals and the unclamped tile starts
+    carve(chunk, s.bin_counters, 4);
     return s;
   }
 };
@@ -225,6 +235,13 @@ struct FwdArgs {
 };
 
 void launch_preprocess_fwd(const FwdArgs& a, const GeomState& g, int* radii, hipStream_t s);
+void launch_zero_words(uint32_t* p, size_t n, hipStream_t s);
+// tile-bucketed binning: count -> prefix (ranges, R) -> scatter -> per-tile sort
+void launch_bin_count(int P, const int* radii, unsigned gx, unsigned gy, const GeomState& g, const ImageState& img, hipStream_t s);
+void launch_bin_prefix(int P, int T, unsigned capacity, const ImageState& img, unsigned* user_counters, hipStream_t s);
+void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, const GeomState& g,
+                        const BinningState& b, const ImageState& img, hipStream_t s);
+int launch_bin_sort(int T, const BinningState& b, const ImageState& img, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                          hipStream_t s);
 hipError_t scan_tiles(const GeomState& g, int P, hipStream_t s);

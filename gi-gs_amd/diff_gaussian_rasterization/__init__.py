@@ -128,6 +128,61 @@ class after_blend:
 
 
 _grad_sink = None
+_async = None
+
+
+class BinningOverflow(RuntimeError):
+    """An asynchronous forward produced more instances than the binning capacity holds (`.needed` = the count)."""
+
+    def __init__(self, needed: int, capacity: int):
+        super().__init__(f"async binning overflow: {needed} instances, capacity {capacity}")
+        self.needed, self.capacity = int(needed), int(capacity)
+
+
+class AsyncBinning:
+    """`with AsyncBinning(capacity, device):` -- rasterizer forwards inside bin into a persistent buffer of `capacity`
+    instances and read NOTHING back (gigs_set_async_binning; gigs-hip extension, off by default).  The reference reads
+    the instance count in the middle of every forward (rasterizer_impl.cu:589-594), which stalls the host and keeps the
+    forward out of a hipGraph; here the count stays on the device and `num_rendered` is the capacity (the backward
+    carves the same layout from it).  Overflow protocol: `snapshot()` after a forward queues a copy of the device
+    counters to pinned memory, `check()` later waits for that copy only and raises BinningOverflow if the forward had
+    more instances than the capacity (its surplus was dropped) -- the caller grows the capacity and repeats the step."""
+
+    def __init__(self, capacity: int, device):
+        self.capacity = int(capacity)
+        if self.capacity <= 0:
+            raise ValueError("AsyncBinning: capacity must be positive")
+        self.device = torch.device(device)
+        self.counters = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self._snap = False
+
+    def __enter__(self):
+        global _async
+        self._prev, _async = _async, self
+        return self
+
+    def __exit__(self, *exc):
+        global _async
+        _async = self._prev
+        return False
+
+    def snapshot(self) -> None:
+        with torch.cuda.device(self.device):
+            self.host.copy_(self.counters, non_blocking=True)
+            self.event.record()
+        self._snap = True
+
+    def check(self) -> int:
+        """Instance count of the forward before the last snapshot(); raises BinningOverflow if it did not fit."""
+        if not self._snap:
+            return -1
+        self.event.synchronize()
+        r, over = int(self.host[0]), int(self.host[1])
+        if over:
+            raise BinningOverflow(over, self.capacity)
+        return r
 
 
 class grad_sink:
@@ -229,18 +284,24 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
             return ptr
 
         with torch.cuda.device(dev):
-            rendered = _lib.gigs_forward(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(sh_degree), M, p(bg, "bg"), W, H,
-                p(means3D, "means3D"), p(sh, "sh"), p(colors_precomp, "colors_precomp"),
-                p(opacities, "opacities"), p(normal, "normal"), p(albedo, "albedo"),
-                p(roughness, "roughness"), p(metallic, "metallic"), p(scales, "scales"),
-                float(scale_modifier), p(rotations, "rotations"), p(cov3Ds_precomp, "cov3Ds_precomp"),
-                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
-                float(tanfovx), float(tanfovy), int(bool(prefiltered)), int(bool(argmax_depth)),
-                int(bool(inference)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
-                out_normal.data_ptr(), out_normal_view.data_ptr(), out_pos.data_ptr(),
-                out_albedo.data_ptr(), out_roughness.data_ptr(), out_metallic.data_ptr(),
-                radii.data_ptr(), int(debug), _stream())
+            if _async is not None:
+                _lib.gigs_set_async_binning(_async.capacity, _async.counters.data_ptr())
+            try:
+                rendered = _lib.gigs_forward(
+                    geom.cb, None, binning.cb, None, img.cb, None, P, int(sh_degree), M, p(bg, "bg"), W, H,
+                    p(means3D, "means3D"), p(sh, "sh"), p(colors_precomp, "colors_precomp"),
+                    p(opacities, "opacities"), p(normal, "normal"), p(albedo, "albedo"),
+                    p(roughness, "roughness"), p(metallic, "metallic"), p(scales, "scales"),
+                    float(scale_modifier), p(rotations, "rotations"), p(cov3Ds_precomp, "cov3Ds_precomp"),
+                    p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+                    float(tanfovx), float(tanfovy), int(bool(prefiltered)), int(bool(argmax_depth)),
+                    int(bool(inference)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
+                    out_normal.data_ptr(), out_normal_view.data_ptr(), out_pos.data_ptr(),
+                    out_albedo.data_ptr(), out_roughness.data_ptr(), out_metallic.data_ptr(),
+                    radii.data_ptr(), int(debug), _stream())
+            finally:
+                if _async is not None:
+                    _lib.gigs_set_async_binning(0, None)
         gigs_lib.check(rendered, "rasterize_gaussians")
     return (rendered, out_color, radii, geom.t, binning.t, img.t, out_opacity, out_depth, out_normal,
             out_normal_view, out_pos, out_albedo, out_roughness, out_metallic)

@@ -19,8 +19,8 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, Gaussian_SSR,
-                                         OutputPool, after_blend, filters)
+from diff_gaussian_rasterization import (AsyncBinning, BinningOverflow, GaussianRasterizationSettings, GaussianRasterizer,
+                                         Gaussian_SSR, OutputPool, _C as _ops, after_blend, filters)
 
 
 def linear_to_srgb(linear: torch.Tensor) -> torch.Tensor:  # train.py:54-68
@@ -193,6 +193,129 @@ def render(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tens
     }
 
 
+RASTER_KEYS = ("means3D", "opacities", "normal", "albedo", "roughness", "metallic", "shs", "scales", "rotations")
+
+
+class RasterFront(torch.nn.Module):
+    """The operator call of gaussian_renderer.render -- rasterizer, in-op filters, SSAO -- as a static-shape tensor
+    function of the Gaussians and the camera matrices: what torch.cuda.make_graphed_callables needs.  It is capturable
+    only under AsyncBinning (no host read-back, fixed binning capacity); image size, field of view and GI settings are
+    baked into the capture, the camera pose is an input."""
+
+    def __init__(self, H: int, W: int, tanfovx: float, tanfovy: float, gi: Dict, sh_degree: int, inference: bool = False):
+        super().__init__()
+        self.H, self.W, self.tanfovx, self.tanfovy = int(H), int(W), float(tanfovx), float(tanfovy)
+        self.gi, self.sh_degree, self.inference = dict(gi), int(sh_degree), bool(inference)
+
+    def forward(self, means2D, viewmatrix, projmatrix, campos, bg, means3D, opacities, normal, albedo, roughness, metallic,
+                shs, scales, rotations):
+        gi = self.gi
+        st = GaussianRasterizationSettings(
+            image_height=self.H, image_width=self.W, tanfovx=self.tanfovx, tanfovy=self.tanfovy, radius=gi["radius"],
+            bias=gi["bias"], thick=gi["thick"], delta=gi["delta"], step=gi["step"], start=gi["start"], bg=bg,
+            scale_modifier=1.0, viewmatrix=viewmatrix, projmatrix=projmatrix, sh_degree=self.sh_degree, campos=campos,
+            prefiltered=False, debug=False, inference=self.inference, argmax_depth=False)
+        return GaussianRasterizer(st)(means3D=means3D, means2D=means2D, opacities=opacities, normal=normal, shs=shs,
+                                      albedo=albedo, roughness=roughness, metallic=metallic, scales=scales,
+                                      rotations=rotations, derive_normal=True)
+
+
+class GraphedRaster:
+    """RasterFront captured into a hipGraph (forward and backward) under AsyncBinning, with the overflow protocol:
+
+        out = gr(cam, g, means2D, bg)     # replays the graph; queues a snapshot of the device-side instance counters
+        ... the rest of the step ...
+        gr.check()                         # waits for that snapshot only; raises BinningOverflow after growing the capacity
+
+    The capacity starts at twice the instance count of a first, synchronous forward; memory, not time, scales with it."""
+
+    def __init__(self, cam: Dict, g: Dict[str, torch.Tensor], gi: Dict, sh_degree: int, inference: bool = False,
+                 capacity: Optional[int] = None):
+        self.cfg = (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"]))
+        self.gi, self.sh_degree, self.inference = dict(gi), int(sh_degree), bool(inference)
+        self.dev = g["means3D"].device
+        self.capacity = int(capacity) if capacity else 0
+        self.fn = self.bin = None
+        self.recaptures = 0
+
+    def _probe(self, cam, g, bg) -> int:
+        e = torch.Tensor([])
+        H, W, tx, ty = self.cfg
+        with torch.no_grad():
+            res = _ops.rasterize_gaussians(bg, g["means3D"], e, g["opacities"], g["normal"], g["albedo"], g["roughness"],
+                                           g["metallic"], g["scales"], g["rotations"], e, g["shs"], cam["campos"],
+                                           cam["viewmatrix"], cam["projmatrix"], 1.0, tx, ty, H, W, self.sh_degree, False,
+                                           False, self.inference, False)
+        return int(res[0])
+
+    def _args(self, cam, g, means2D, bg):
+        return (means2D, cam["viewmatrix"], cam["projmatrix"], cam["campos"], bg, *[g[k] for k in RASTER_KEYS])
+
+    def _capture(self, cam, g, means2D, bg):
+        if self.capacity <= 0:
+            self.capacity = max(65536, -(-2 * self._probe(cam, g, bg) // 65536) * 65536)
+        self.bin = AsyncBinning(self.capacity, self.dev)
+        H, W, tx, ty = self.cfg
+        mod = RasterFront(H, W, tx, ty, self.gi, self.sh_degree, self.inference)
+        sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in self._args(cam, g, means2D, bg))
+        with self.bin:
+            if self.inference or not any(a.requires_grad for a in sample):
+                self.fn = _graphed_inference(mod, sample)
+            else:
+                self.fn = graphed(mod, sample)
+        self.recaptures += 1
+
+    def __call__(self, cam, g, means2D, bg):
+        if (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"])) != self.cfg:
+            raise ValueError("GraphedRaster: image size / field of view differ from the captured ones")
+        if self.fn is None:
+            self._capture(cam, g, means2D, bg)
+        out = self.fn(*self._args(cam, g, means2D, bg))
+        self.bin.snapshot()
+        return out
+
+    def check(self) -> int:
+        try:
+            return self.bin.check()
+        except BinningOverflow as ex:
+            self.capacity = -(-int(1.5 * ex.needed) // 65536) * 65536
+            self.fn = None  # next call re-captures with the larger buffer
+            raise
+
+
+def _graphed_inference(mod, sample):
+    """A forward-only hipGraph of `mod` (torch.cuda.make_graphed_callables captures a backward and needs inputs that
+    require grad): static inputs, three warm-up runs on a side stream, one capture, replay = copy inputs + launch."""
+    import gc
+    static_in = tuple(a.detach().clone() for a in sample)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(3):
+            mod(*static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            static_out = mod(*static_in)
+    finally:
+        if was:
+            gc.enable()
+
+    def run(*args):
+        for s, a in zip(static_in, args):
+            if s.data_ptr() != a.data_ptr():
+                s.copy_(a)
+        graph.replay()
+        return static_out
+
+    return run
+
+
 def view_dirs_for(cam: Dict, rays: torch.Tensor, device) -> torch.Tensor:
     """train.py:299-308."""
     H, W = cam["image_height"], cam["image_width"]
@@ -265,7 +388,7 @@ class Stage2Step:
         self.gi, self.sh_degree, self.metallic = gi, sh_degree, metallic
         self.fused, self.light, self.brdf_lut = fused, light, brdf_lut
         self.flags = dict(metallic=metallic, indirect=indirect, gamma=gamma, tone=tone)
-        self.back = self.mips = self.side = self.step_begin = self.blend_begin = None
+        self.back = self.mips = self.side = self.step_begin = self.blend_begin = self.graster = None
         # fused + graphs: the rasterizer's planes live at fixed addresses, the graph reads them in place
         self.pool = OutputPool() if (fused and graphs and os.environ.get("GIGS_OUTPUT_POOL", "1") == "1") else None
         self.front = Stage2Front(light, brdf_lut, metallic=metallic, indirect=indirect, tone=tone, gamma=gamma)
@@ -285,6 +408,8 @@ class Stage2Step:
         """extra_loss(normal_map, albedo_map, roughness_map, metallic_map) -> scalar added to the loss before
         backward (the BRDF / envmap regularisers of train.py:387-420; see gi-gs_amd/losses.py)."""
         dev = g["means3D"].device
+        if self.fused and self.graphs and os.environ.get("GIGS_RASTER_GRAPH", "1") == "1":
+            return self._graphed_step(cam, g, gt_image, view_dirs, extra_loss)
         background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
         if self.fused:
             if self.step_begin is None:
@@ -335,7 +460,38 @@ class Stage2Step:
                     IRR=IRR.detach(), viewspace_points=screenspace_points, radii=radii)
 
 
-def _fused_begin(self):
+def _graphed_step(self, cam, g, gt_image, view_dirs, extra_loss=None):
+    """fused + graphs: the WHOLE step replays from hipGraphs -- the rasterizer with its in-op filters and SSAO too
+    (GraphedRaster: asynchronous binning, no host read-back), the light filter on the side stream from the start of the
+    step, the fused stage-2 node -- six graph launches per iteration.  The binning overflow flag of this step is
+    checked after loss.backward() has been queued (the host then waits for the forward only); on overflow the
+    capacity grows, the graphs are re-captured and the step is repeated on cleared gradients."""
+    from types import SimpleNamespace
+    dev = g["means3D"].device
+    if self.step_begin is None:
+        self.step_begin = torch.cuda.Event()
+        self._bg = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
+    for attempt in range(4):
+        self.step_begin.record()
+        lights = list(self._fused_begin(self.step_begin))
+        if self.graster is None:
+            self.graster = GraphedRaster(cam, g, self.gi, self.sh_degree)
+        screenspace_points = torch.zeros_like(g["means3D"], requires_grad=True)
+        out = self.graster(cam, g, screenspace_points, self._bg)
+        (_, radii, _, _, _, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map, out_normal_view, depth_pos) = out
+        res = self._fused_step(cam, gt_image, view_dirs, SimpleNamespace(viewmatrix=cam["viewmatrix"]), radii,
+                               screenspace_points, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
+                               occlusion_map, depth_pos, lights, extra_loss)
+        try:
+            res["num_rendered"] = self.graster.check()
+            return res
+        except BinningOverflow:
+            for t in list(g.values()) + list(self.light.parameters()):
+                t.grad = None
+    raise RuntimeError("Stage2Step: the binning capacity kept overflowing")
+
+
+def _fused_begin(self, start_event=None):
     """Starts light.build_mips() on a side stream, called from inside the rasterizer's forward as soon as its
     kernels up to the blend are queued (diff_gaussian_rasterization.after_blend; the host call returns after
     the binning read-back, while the GPU is still sorting): the GGX pre-filter is independent of the G-buffer
@@ -359,7 +515,9 @@ def _fused_begin(self):
     # a few long serial walks with most CUs idle.  Measured alternatives: starting at once (next to the sort passes,
     # which then take 0.3-0.5 instead of 0.22 ms) and starting after the blend kernel (next to the VALU-bound SSAO
     # march only: 4 % slower overall).  GIGS_LIGHT_START=step selects the former.
-    if os.environ.get("GIGS_LIGHT_START", "blend") == "step":
+    if start_event is not None:
+        self.side.wait_event(start_event)
+    elif os.environ.get("GIGS_LIGHT_START", "blend") == "step":
         self.side.wait_event(self.step_begin)
     else:
         self.side.wait_event(self.blend_begin)
@@ -396,6 +554,7 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
                 viewspace_points=screenspace_points, radii=radii)
 
 
+Stage2Step._graphed_step = _graphed_step
 Stage2Step._fused_begin = _fused_begin
 Stage2Step._fused_step = _fused_step
 

@@ -60,10 +60,18 @@ class Relighter:
     """render_set (relight.py:113-251) without the file I/O: build_mips once, then one call per view."""
 
     def __init__(self, light: CubemapLight, gi: Dict, sh_degree: int, metallic: bool = False, tone: bool = False,
-                 gamma: bool = False, fused: bool = True, pad_normal: bool = False, brdf_lut: Optional[torch.Tensor] = None):
+                 gamma: bool = False, fused: bool = True, pad_normal: bool = False, brdf_lut: Optional[torch.Tensor] = None,
+                 graphs: bool = False):
+        """graphs=True (with fused): the whole view -- rasterizer under asynchronous binning, filters, SSAO, shade, SSR,
+        sRGB / median / sum -- is captured once into ONE hipGraph and replayed per view (camera pose and view
+        directions are its inputs; image size, field of view, GI settings and the Gaussian tensors are baked in).  The
+        tensors it returns are the graph's static outputs: consume them before the next call."""
         self.light, self.gi, self.sh_degree = light, gi, sh_degree
         self.metallic, self.tone, self.gamma = bool(metallic), bool(tone), bool(gamma)
         self.fused, self.pad_normal = bool(fused) and not pad_normal, bool(pad_normal)
+        self.graphs = bool(graphs) and self.fused
+        self._graph = self._graph_key = self._bin = None
+        self._capacity = 0
         dev = light.base.device
         self.brdf_lut = (brdf_lut if brdf_lut is not None else get_brdf_lut()).to(dev)
         with torch.no_grad():
@@ -79,9 +87,45 @@ class Relighter:
     @torch.no_grad()
     def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], view_dirs: torch.Tensor,
                  alpha_mask: Optional[torch.Tensor] = None, albedo_ratio: Optional[Sequence[float]] = None) -> Dict:
+        if self.graphs:
+            return self._graphed(cam, g, view_dirs, alpha_mask, albedo_ratio)
         if self.fused:
             return self._fused(cam, g, view_dirs, alpha_mask, albedo_ratio)
         return self._unfused(cam, g, view_dirs, alpha_mask, albedo_ratio)
+
+    # -- the fused sequence replayed from one hipGraph --------------------------------------------------------------
+    def _graphed(self, cam, g, view_dirs, alpha_mask, albedo_ratio):
+        from diff_gaussian_rasterization import AsyncBinning, BinningOverflow
+        names = ("render_rgb", "render_direct", "IRR", "occlusion", "depth_map", "normal_map", "normal_mask", "radii")
+        key = (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"]),
+               tuple(sorted((k, v.data_ptr()) for k, v in g.items())), None if albedo_ratio is None else tuple(albedo_ratio))
+        for _ in range(4):
+            if self._graph is None or self._graph_key != key:
+                if self._capacity <= 0:
+                    probe = pipeline.GraphedRaster(cam, g, self.gi, self.sh_degree, inference=True)
+                    self._capacity = max(65536, -(-2 * probe._probe(cam, g, torch.zeros(3, device=g["means3D"].device)) // 65536) * 65536)
+                self._bin = AsyncBinning(self._capacity, g["means3D"].device)
+                scalars = {k: v for k, v in cam.items() if not isinstance(v, torch.Tensor)}
+
+                def core(viewmatrix, projmatrix, campos, vd):
+                    c = dict(scalars, viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos)
+                    o = self._fused(c, g, vd, None, albedo_ratio)
+                    return tuple(o[n] for n in names)
+
+                with self._bin:
+                    self._graph = pipeline._graphed_inference(core, (cam["viewmatrix"], cam["projmatrix"], cam["campos"], view_dirs))
+                self._graph_key = key
+            out = dict(zip(names, self._graph(cam["viewmatrix"], cam["projmatrix"], cam["campos"], view_dirs)))
+            self._bin.snapshot()
+            if alpha_mask is not None:
+                out["render_rgb"] = out["render_rgb"] * alpha_mask
+            try:
+                out["num_rendered"] = self._bin.check()
+                return out
+            except BinningOverflow as ex:
+                self._capacity = -(-int(1.5 * ex.needed) // 65536) * 65536
+                self._graph = None
+        raise RuntimeError("Relighter: the binning capacity kept overflowing")
 
     # -- the reference's op sequence, operator by operator ------------------------------------------------------
     def _unfused(self, cam, g, view_dirs, alpha_mask, albedo_ratio):

@@ -402,6 +402,17 @@ int gigs_selftest_round(unsigned long long* mismatches, void* stream);
  * Process-wide; set it before the forward that should record it. */
 void gigs_set_blend_begin_event(void* hip_event);
 
+/* Asynchronous binning (gigs-hip extension).  The reference's forward reads the instance count back in the middle
+ * (rasterizer_impl.cu:589-594) to size the binning buffer, which serialises host and device and keeps the forward out
+ * of a hipGraph.  After gigs_set_async_binning(r_capacity > 0, counters) every gigs_forward asks the binning callback
+ * for gigs_required_binning(r_capacity) bytes, bins at most r_capacity instances, reads nothing back and RETURNS
+ * r_capacity (pass it to gigs_backward as R: both carve the same layout).  `counters` (device, 2 x u32, may be NULL)
+ * receives {actual instance count, the count again if it exceeded the capacity else 0}; on overflow the surplus
+ * instances are dropped (memory-safe, wrong image): the caller checks the flag when convenient, grows the capacity
+ * and repeats the step.  r_capacity = 0 restores the synchronous behaviour.  Needs the tile-bucketed binning path
+ * (the default; GIGS_BINNING=legacy selects scan / duplicate / global radix sort) and <= 16384 tiles. */
+void gigs_set_async_binning(int r_capacity, unsigned* device_counters);
+
 /* In-library stage timing for bench.py.  Between gigs_profile_begin() and gigs_profile_end()
  * every kernel stage launched by this library records a hipEvent pair on its own stream (no
  * synchronisation is added).  gigs_profile_end() waits for the recorded events, writes the

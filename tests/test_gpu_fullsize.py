@@ -9,6 +9,8 @@ stage-2 image -- and so is a ragged 611x403 view; beyond that, size-independent 
     shape do not change a bit;
   * the backward is linear in the incoming gradients.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -24,11 +26,19 @@ def _structure_checks(sv, hp, R, P, W, H):
     keys = sv["keys"].astype(np.uint64)
     assert np.all(keys[1:] >= keys[:-1]), "tile|depth keys are not sorted"
     assert int(sv["tiles_touched"].astype(np.int64).sum()) == R
-    assert int(sv["point_offsets"][-1]) == R
-    # the sorted list is a permutation of the unsorted (key, value) pairs
-    order = np.lexsort((sv["vals_unsorted"], sv["keys_unsorted"]))
-    np.testing.assert_array_equal(sv["keys_unsorted"][order], keys)
-    assert np.array_equal(np.sort(sv["vals_unsorted"]), np.sort(sv["point_list"]))
+    if os.environ.get("GIGS_BINNING", "") == "legacy":
+        assert int(sv["point_offsets"][-1]) == R
+        # the sorted list is a permutation of the unsorted (key, value) pairs
+        order = np.lexsort((sv["vals_unsorted"], sv["keys_unsorted"]))
+        np.testing.assert_array_equal(sv["keys_unsorted"][order], keys)
+        assert np.array_equal(np.sort(sv["vals_unsorted"]), np.sort(sv["point_list"]))
+    else:
+        # tile-bucketed path: keys_unsorted holds (depth << 32 | index) grouped by tile; within a tile the sorted list is
+        # ordered by (depth, index) and every Gaussian appears once per tile it touches
+        depth_idx = (keys & np.uint64(0xFFFFFFFF)) << np.uint64(32) | sv["point_list"].astype(np.uint64)
+        same_tile = (keys[1:] >> np.uint64(32)) == (keys[:-1] >> np.uint64(32))
+        assert np.all(depth_idx[1:][same_tile] > depth_idx[:-1][same_tile]), "a tile's list is not strictly (depth, index)-ordered"
+        assert np.array_equal(np.bincount(sv["point_list"], minlength=P), sv["tiles_touched"])
     # ranges: tile t owns exactly the instances whose key's high word is t
     tiles = (keys >> np.uint64(32)).astype(np.int64)
     ranges = sv["ranges"].reshape(T, 2).astype(np.int64)

@@ -272,6 +272,44 @@ def test_stage2_fused_matches_unfused(orc, metallic):
     assert abs(results["fused_graph"][0][0] - results["fused_graph"][1][0]) > 1e-6
 
 
+def test_graphed_step_survives_a_binning_overflow():
+    """The whole-step hipGraph bins into a fixed-capacity buffer; a view with more instances than the capacity raises
+    the device-side overflow flag, the capacity grows, the graph is re-captured and the step repeated: same loss,
+    image and gradients as the eager step."""
+    import pbr
+    import pipeline
+    sc = scenes.surface_scene(P=20_000, sh_degree=2, seed=4, scale_mu=0.03)
+    gi = scenes.GI_DEFAULTS
+    H, W = 160, 208
+    cam = scenes.orbit_camera(2, 6, W, H, radius=3.5)
+    camt = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    torch.manual_seed(3)
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    vd = pipeline.view_dirs_for(camt, pipeline.canonical_rays(cam, DEV), DEV)
+    res = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)
+        light = pbr.CubemapLight(base_res=64, device=DEV)
+        g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        step = pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=(mode == "graph"))
+        if mode == "graph":
+            step.graster = pipeline.GraphedRaster(camt, g, gi, 2, capacity=65536)  # far below this view's instance count
+        o = step(camt, g, gt, vd)
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert step.graster.recaptures == 2 and step.graster.capacity > 65536
+            assert o["num_rendered"] > 65536
+        res[mode] = (float(o["loss"]), o["render_rgb"].clone(), {k: g[k].grad.clone() for k in ("albedo", "roughness", "metallic")},
+                     light.base.grad.clone())
+    (le, re_, ge, be), (lg, rg, gg, bg_) = res["eager"], res["graph"]
+    assert abs(le - lg) <= 2e-6 * max(1.0, abs(le))
+    torch.testing.assert_close(rg, re_, rtol=0, atol=2e-6)
+    for k in ge:
+        assert rel_peak(gg[k].cpu().numpy(), ge[k].cpu().numpy()) < 2e-3, k
+    assert rel_peak(bg_.cpu().numpy(), be.cpu().numpy()) < 2e-3
+
+
 @pytest.mark.gpu
 def test_fused_gbuffer_post_matches_torch_chain_forward_and_backward():
     """pipeline.gbuffer_post (torch ops, gaussian_renderer/__init__.py:157-199) vs the fused kernels incl. the

@@ -117,6 +117,17 @@ def test_relight_fused_equals_unfused_c3_size():
     for k in ("render_direct", "IRR", "render_rgb"):
         x, y = oa[k].nan_to_num(), ob[k].nan_to_num()
         assert float((x - y).abs().max()) <= 2e-6, k
+    # the whole view replayed from ONE hipGraph (asynchronous binning): the same image, also for a second camera pose
+    c = relight.Relighter(light, gi, 2, metallic=False, fused=True, graphs=True)
+    keep = {k: oa[k].clone() for k in ("render_direct", "IRR", "render_rgb")}
+    cam2 = scenes.orbit_camera(30, 64, W, H, radius=3.5)
+    vd2 = view_dirs(cam2)
+    want2 = {k: v.clone() for k, v in a(cam_t(cam2), g, vd2, alpha_mask=tt(alpha)).items() if k in keep}
+    for cm, v, want in ((cam, vd, keep), (cam2, vd2, want2), (cam, vd, keep)):
+        oc = c(cam_t(cm), g, v, alpha_mask=tt(alpha))
+        assert oc["num_rendered"] > 1_000_000
+        for k in want:
+            assert float((oc[k].nan_to_num() - want[k].nan_to_num()).abs().max()) <= 2e-6, k
     rgb = oa["render_rgb"]
     assert float(rgb[:, tt(alpha)[0] == 0].abs().max()) == 0.0
     assert torch.isfinite(rgb).all()
