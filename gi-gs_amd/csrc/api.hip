@@ -306,6 +306,7 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
   gigs::BinningState bin;
   const unsigned async_cap = g_async_capacity.load();
   const bool bucket = binning_bucketed() && T <= (size_t)gigs::kBinMaxTiles;
+  bool dense = false;
   if (async_cap > 0 && !bucket) return fail(GIGS_ERR_INVALID, "asynchronous binning needs the tile-bucketed path (GIGS_BINNING, <= %d tiles)", gigs::kBinMaxTiles);
   if (bucket) {
     // Tile-bucketed binning (binning.hip): count -> prefix -> scatter -> per-tile sort, the instance count stays on
@@ -326,7 +327,13 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
       HIP_TRY(hipStreamSynchronize(s));
       if (num_rendered_u > 0x7fffffffu) return fail(GIGS_ERR_INVALID, "num_rendered overflows int");
       num_rendered = (int)num_rendered_u;
+      // The per-tile LDS sort is O(n log^2 n) in the list length: for dense scenes (mean list above kBucketMaxMeanList
+      // instances; 3 M Gaussians at 1237x822 average 7000) the global radix sort of the reference-shaped path wins
+      // (measured: 9.2 vs 1.6 ms at that size), so a synchronous call -- which knows R here -- switches over.
+      if ((size_t)num_rendered > (size_t)gigs::kBucketMaxMeanList * T) dense = true;
     }
+  }
+  if (bucket && !dense) {
     const size_t sort_sz = sort_size_cached(num_rendered);
     const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)num_rendered, sort_sz);
     char* bin_chunk = binningBuffer(bin_bytes, binning_user);
@@ -490,34 +497,53 @@ int gigs_derive_normal(int width, int height, float focal_x, float focal_y, cons
   return 0;
 }
 
-int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius, float bias,
-              float thick, float delta, int step, int start, const float* normal_view,
-              const float* pos, float* occlusion, void* stream) {
+size_t gigs_gi_scratch_bytes(int width, int height) {
+  if (width <= 0 || height <= 0) return 0;
+  return gigs::gi_scratch_bytes(width, height);
+}
+
+int gigs_ssao_ex(int width, int height, float focal_x, float focal_y, float radius, float bias,
+                 float thick, float delta, int step, int start, const float* normal_view,
+                 const float* pos, float* occlusion, void* scratch, void* stream) {
   if (width <= 0 || height <= 0 || !normal_view || !pos || !occlusion) return fail(GIGS_ERR_INVALID, "bad argument");
   if (width >= (1 << 15) || height >= (1 << 15)) return fail(GIGS_ERR_INVALID, "image side above 32767 pixels");
   StageScope sc(kSsao, (hipStream_t)stream);
   const int rc = gigs::launch_ssao(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
-                                   normal_view, pos, occlusion, (hipStream_t)stream);
+                                   normal_view, pos, occlusion, scratch, (hipStream_t)stream);
   if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
   if (rc) return fail(GIGS_ERR_HIP, "ray table upload failed");
   HIP_TRY(hipGetLastError());
   return 0;
 }
+int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius, float bias,
+              float thick, float delta, int step, int start, const float* normal_view,
+              const float* pos, float* occlusion, void* stream) {
+  return gigs_ssao_ex(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, normal_view, pos,
+                      occlusion, nullptr, stream);
+}
 
-int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, float bias,
-             float thick, float delta, int step, int start, const float* normal_view,
-             const float* pos, const float* rgb, const float* albedo, const float* roughness,
-             const float* metallic, const float* F0, float* color, float* abd, void* stream) {
+int gigs_ssr_ex(int width, int height, float focal_x, float focal_y, float radius, float bias,
+                float thick, float delta, int step, int start, const float* normal_view,
+                const float* pos, const float* rgb, const float* albedo, const float* roughness,
+                const float* metallic, const float* F0, float* color, float* abd, void* scratch, void* stream) {
   if (width <= 0 || height <= 0 || !normal_view || !pos || !rgb || !albedo || !metallic || !F0 || !color || !abd)
     return fail(GIGS_ERR_INVALID, "bad argument");
   if (width >= (1 << 15) || height >= (1 << 15)) return fail(GIGS_ERR_INVALID, "image side above 32767 pixels");
   StageScope sc(kSsr, (hipStream_t)stream);
   const int rc = gigs::launch_ssr(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
-                                  normal_view, pos, rgb, albedo, roughness, metallic, F0, color, abd, (hipStream_t)stream);
+                                  normal_view, pos, rgb, albedo, roughness, metallic, F0, color, abd, scratch,
+                                  (hipStream_t)stream);
   if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
   if (rc) return fail(GIGS_ERR_HIP, "ray table upload failed");
   HIP_TRY(hipGetLastError());
   return 0;
+}
+int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, float bias,
+             float thick, float delta, int step, int start, const float* normal_view,
+             const float* pos, const float* rgb, const float* albedo, const float* roughness,
+             const float* metallic, const float* F0, float* color, float* abd, void* stream) {
+  return gigs_ssr_ex(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, normal_view, pos, rgb,
+                     albedo, roughness, metallic, F0, color, abd, nullptr, stream);
 }
 
 int gigs_median3x3(int channels, int height, int width, const float* in, float* out, void* stream) {

@@ -327,6 +327,11 @@ __device__ __forceinline__ void bitonic_sort_asc(unsigned n, unsigned npad_log2,
 // (direction alternates with bit kb of the index), whose substages all have plain strides, so THREE consecutive substages
 // are done per phase on 8 keys held in registers (strides 4m, 2m, m: keys base + e*m) -- 35 barrier phases instead of 91
 // for 8192 keys, and each phase issues its 8 LDS reads back to back.
+// LDS layout of the keys: one pad slot after every 16 keys (a 128-byte bank row).  The fused phases read runs of 2^lowpos
+// consecutive keys that start 2^(lowpos+3) keys apart -- unpadded, the runs of a wave all start in the same bank
+// (32-way conflicts at lowpos = 1, measured as 2.5 us per phase); padded, consecutive runs shift by one 8-byte bank pair.
+__device__ __forceinline__ unsigned lds_slot(unsigned i) { return i + (i >> 4); }
+
 template <int kThreads>
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* __restrict__ s, unsigned npad_log2) {
   const unsigned npad = 1u << npad_log2;
@@ -343,7 +348,7 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* __restrict__ s, unsig
         uint64_t v[8];
 #pragma unroll
         for (unsigned e = 0; e < 8; e++)
-          if (e < cnt) v[e] = s[base + e * m];
+          if (e < cnt) v[e] = s[lds_slot(base + e * m)];
 #pragma unroll
         for (int sft = 2; sft >= 0; sft--) {
           if (sft < g) {
@@ -360,7 +365,7 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* __restrict__ s, unsig
         }
 #pragma unroll
         for (unsigned e = 0; e < 8; e++)
-          if (e < cnt) s[base + e * m] = v[e];
+          if (e < cnt) s[lds_slot(base + e * m)] = v[e];
       }
       __syncthreads();
       jb -= g;
@@ -390,11 +395,11 @@ bin_sort_kernel(int T, unsigned lo, const uint32_t* __restrict__ tile_order, con
     while ((1u << npad) < n) npad++;
     const uint64_t tile_hi = (uint64_t)tile << 32;
     if (n <= (unsigned)kLds) {
-      for (unsigned i = threadIdx.x; i < (1u << npad); i += kThreads) s_keys[i] = i < n ? src[i] : ~0ull;
+      for (unsigned i = threadIdx.x; i < (1u << npad); i += kThreads) s_keys[lds_slot(i)] = i < n ? src[i] : ~0ull;
       __syncthreads();
       bitonic_sort_lds<kThreads>(s_keys, npad);
       for (unsigned i = threadIdx.x; i < n; i += kThreads) {
-        const uint64_t k = s_keys[i];
+        const uint64_t k = s_keys[lds_slot(i)];
         point_list[rg.x + i] = (uint32_t)k;
         keys_out[rg.x + i] = tile_hi | (k >> 32);
       }
@@ -457,15 +462,15 @@ int launch_bin_sort(int T, const BinningState& b, const ImageState& img, hipStre
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_sort_kernel<1024, kL2, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kL2 * 8) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kL2 * 8 / 16 * 17) != hipSuccess)
       return -1;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bin_sort_kernel<1024, kL2, true>), dim3(std::min(T, 256)), dim3(1024), (size_t)kL2 * 8, s, T, 4096u,
+  hipLaunchKernelGGL((bin_sort_kernel<1024, kL2, true>), dim3(std::min(T, 256)), dim3(1024), (size_t)kL2 * 8 / 16 * 17, s, T, 4096u,
                      img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL((bin_sort_kernel<512, 4096, false>), dim3(std::min(T, 1024)), dim3(512), (size_t)4096 * 8, s, T, 1024u,
+  hipLaunchKernelGGL((bin_sort_kernel<512, 4096, false>), dim3(std::min(T, 1024)), dim3(512), (size_t)4096 * 8 / 16 * 17, s, T, 1024u,
                      img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL((bin_sort_kernel<256, 1024, false>), dim3(std::min(T, 4096)), dim3(256), (size_t)1024 * 8, s, T, 0u,
+  hipLaunchKernelGGL((bin_sort_kernel<256, 1024, false>), dim3(std::min(T, 4096)), dim3(256), (size_t)1024 * 8 / 16 * 17, s, T, 0u,
                      img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
   return 0;
 }

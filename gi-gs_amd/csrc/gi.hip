@@ -173,6 +173,8 @@ struct GiParams {
   float inv_step;  // exact 1/step when step is a power of two
   int nrays;
   int tile_log2w;  // the 64 pixels of a workgroup form a (1 << tile_log2w) x (64 >> tile_log2w) rectangle
+  int cert_shift;  // certification blocks are (1 << cert_shift)^2 pixels; 0 = no certification table
+  int cert_w;      // blocks per row of the table
   // j / step for j = start .. start + 63 (exact for a power-of-two step): the fast path reads its per-step factor from
   // here with a scalar load instead of converting and multiplying on the vector ALU for every group (marches of more
   // than kFjTable - kGiGroup steps take the general path)
@@ -544,15 +546,26 @@ __device__ __forceinline__ int cvt_flr(float t) {  // (int)floor(t), saturating,
   return r;
 }
 
-template <int kMode, int kGroup>
+// Conservative certification (kCert): the z plane's min / max over square blocks (gi_minmax_kernel) sit in LDS; a sample
+// whose hit interval, widened by 2^-16 relative + 1e-6 absolute, lies entirely above the block's maximum or entirely
+// below its non-zero minimum (and above zero: empty pixels hold 0) cannot hit whichever pixel of the block it selects,
+// so its gather and depth test are skipped -- for the whole wave when no lane needs them, which is the case for ~92 %
+// of the wave-samples of the bench view (tools/gi_cert_rate.py).  Skipped samples would have failed the exact test by a
+// margin far above its rounding error, so the outcome of every ray -- and every output bit -- is unchanged
+// (tests/test_gpu_parity.py::test_gi_certification_is_exact).  Once the march's arithmetic was down to ~12 instructions
+// per sample the kernel was bound by the texture-address path (~30 cycles per scattered wave-gather,
+// tools/microbench/gather_rate.hip); this removes most gathers from it.
+template <int kMode, int kGroup, bool kCert>
 __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c, const f32x2* Bxy, f32x2 Bz2,
-                                            __amdgpu_buffer_rsrc_t pos_z, int* hit) {
+                                            __amdgpu_buffer_rsrc_t pos_z, const float2* __restrict__ s_tab, int* hit) {
+  static_assert(!kCert || kMode >= 3, "certification is wired into the projective marches");
   bool open[2] = {true, true};
   hit[0] = hit[1] = -1;
   const f32x2 Dz2 = {c.Dz, c.Dz};
   for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
     unsigned off[2][kGroup];
     bool inb[2][kGroup];
+    bool need[2][kGroup];          // kCert: this lane's sample must be looked up
     f32x2 ta[kGroup], tb[kGroup];  // modes 1/2: spz + bias, spz - thick; modes 3/4: mid (ta only)
 #pragma unroll
     for (int g = 0; g < kGroup; g++) {
@@ -561,6 +574,7 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
       const bool in_range = (j0 + g) < p.step;
       f32x2 r;
       f32x2 den;
+      f32x2 lo_c = {0.0f, 0.0f}, hi_c = {0.0f, 0.0f};
       if constexpr (kMode >= 3) {
         den = __builtin_elementwise_fma(Bz2, fj2, Dz2);
         ta[g] = den + c.cm;
@@ -568,6 +582,10 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
         if constexpr (kMode == 3) {
           const f32x2 e0 = __builtin_elementwise_fma(-den, r, f32x2{1.0f, 1.0f});
           r = __builtin_elementwise_fma(e0, r, r);
+        }
+        if constexpr (kCert) {
+          lo_c = __builtin_elementwise_fma(ta[g], f32x2{1.0f - 0x1p-16f, 1.0f - 0x1p-16f}, f32x2{-c.hh - 1e-6f, -c.hh - 1e-6f});
+          hi_c = __builtin_elementwise_fma(ta[g], f32x2{1.0f + 0x1p-16f, 1.0f + 0x1p-16f}, f32x2{c.hh + 1e-6f, c.hh + 1e-6f});
         }
       } else {
         const f32x2 spz = (kMode == 2) ? __builtin_elementwise_fma(Bz2, fj2, Dz2) : Dz2 + Bz2 * fj2;
@@ -601,10 +619,28 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
         const int iy = cvt_flr(t.y);
         inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
         off[k][g] = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;
+        if constexpr (kCert) {
+          const unsigned b = __umul24((unsigned)iy >> p.cert_shift, (unsigned)p.cert_w) + ((unsigned)ix >> p.cert_shift);
+          const float2 mm = s_tab[inb[k][g] ? b : 0u];  // {non-zero minimum, max(maximum, 0)}
+          const float lo = k == 0 ? lo_c.x : lo_c.y, hi = k == 0 ? hi_c.x : hi_c.y;
+          const bool cert = (lo > mm.y) || (hi < mm.x && lo > 0.0f);
+          need[k][g] = open[k] && inb[k][g] && !cert;
+        }
       }
     }
     float zn[2 * kGroup];
-    {
+    if constexpr (kCert) {
+      // only the samples some lane of the wave still needs are looked up (all in flight, then one wait)
+#pragma unroll
+      for (int g = 0; g < kGroup; g++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          zn[2 * g + k] = 0.0f;  // 0 fails every test that can be skipped (lo > 0)
+          if (__builtin_amdgcn_ballot_w64(need[k][g]) != 0) zn[2 * g + k] = gather_idx_issue(need[k][g] ? off[k][g] : 0xffffffffu, pos_z);
+        }
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(zn[0]), "+v"(zn[1]), "+v"(zn[2]), "+v"(zn[3]), "+v"(zn[4]), "+v"(zn[5]), "+v"(zn[6]), "+v"(zn[7]));
+    } else {
       unsigned in[2 * kGroup];
 #pragma unroll
       for (int g = 0; g < kGroup; g++) { in[2 * g] = off[0][g]; in[2 * g + 1] = off[1][g]; }
@@ -619,6 +655,7 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
         bool h;
         if constexpr (kMode >= 3) {
           h = inb[k][g] && fabsf(z - (k == 0 ? ta[g].x : ta[g].y)) <= c.hh;
+          if constexpr (kCert) h = h && need[k][g];
         } else {
           h = inb[k][g] && (z <= (k == 0 ? ta[g].x : ta[g].y)) && (z >= (k == 0 ? tb[g].x : tb[g].y));
         }
@@ -711,12 +748,18 @@ __device__ __forceinline__ bool gi_pixel(const GiParams& p, int& x, int& y, int&
 #define GIGS_GI_OCC
 #endif
 
-template <bool kPow2, int kMode>
+template <bool kPow2, int kMode, bool kCert>
 __global__ void __launch_bounds__(256) GIGS_GI_OCC
 ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             const float* __restrict__ nrm, const float* __restrict__ pos_map,
-            float* __restrict__ occlusion) {
+            float* __restrict__ occlusion, const float2* __restrict__ cert_tab) {
   __shared__ float s_part[kGiWaves][64];
+  extern __shared__ float2 s_cert[];
+  if constexpr (kCert) {
+    const int nb = p.cert_w * ((p.H + (1 << p.cert_shift) - 1) >> p.cert_shift);
+    for (int i = threadIdx.x; i < nb; i += 256) s_cert[i] = cert_tab[i];
+    __syncthreads();
+  }
   int x, y, wave;
   const bool inside = gi_pixel(p, x, y, wave);
   const int lane = threadIdx.x & 63;
@@ -746,7 +789,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             fast_ray<kMode>(p, tbn, ft, a, rays[2 * rb], Bxy[1], bz1);
             Bz2 = f32x2{bz0, bz1};
             int hit[2];
-            march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
+            march2_fast<kMode, kGiGroup, kCert>(p, c, Bxy, Bz2, pos_z, s_cert, hit);
             occ += hit[0] >= 0 ? rays[2 * r + 1].y : 0.0f;
             occ += (hit[1] >= 0 && rb != r) ? rays[2 * rb + 1].y : 0.0f;
           }
@@ -789,13 +832,20 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
   }
 }
 
-template <bool kPow2, int kMode>
+template <bool kPow2, int kMode, bool kCert>
 __global__ void __launch_bounds__(256) GIGS_GI_OCC
 ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict__ nrm,
            const float* __restrict__ pos_map, const float* __restrict__ rgb,
            const float* __restrict__ albedo_map, const float* __restrict__ metallic_map,
-           const float* __restrict__ F0_map, float* __restrict__ color, float* __restrict__ abd) {
+           const float* __restrict__ F0_map, float* __restrict__ color, float* __restrict__ abd,
+           const float2* __restrict__ cert_tab) {
   __shared__ float s_part[kGiWaves][3][64];
+  extern __shared__ float2 s_cert[];
+  if constexpr (kCert) {
+    const int nb = p.cert_w * ((p.H + (1 << p.cert_shift) - 1) >> p.cert_shift);
+    for (int i = threadIdx.x; i < nb; i += 256) s_cert[i] = cert_tab[i];
+    __syncthreads();
+  }
   int x, y, wave;
   const bool inside = gi_pixel(p, x, y, wave);
   const int lane = threadIdx.x & 63;
@@ -832,7 +882,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
           fast_ray<kMode>(p, tbn, ft, a, ra1, Bxy[1], bz1);
           Bz2 = f32x2{bz0, bz1};
           int hit[2];
-          march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
+          march2_fast<kMode, kGiGroup, kCert>(p, c, Bxy, Bz2, pos_z, s_cert, hit);
           if (rb == r) hit[1] = -1;
           if (__any(hit[0] >= 0 || hit[1] >= 0)) {
             add_hit(hit[0], ra0.w, rays[2 * r + 1].x);
@@ -928,6 +978,58 @@ static GiParams make_params(int W, int H, float fx, float fy, float radius, floa
   p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
   return p;
 }
+// Certification table: per (1 << shift)^2 block of the z plane {minimum over its non-zero pixels (+inf if none),
+// max(maximum, 0)}; NaN pixels are ignored (a NaN never passes the depth test).  One wave per block.
+__global__ void __launch_bounds__(64)
+gi_minmax_kernel(int W, int H, int shift, int tab_w, const float* __restrict__ z, float2* __restrict__ tab) {
+  const int bx = blockIdx.x, by = blockIdx.y, B = 1 << shift;
+  float mn = __builtin_inff(), mx = 0.0f;
+  for (int i = threadIdx.x; i < B * B; i += 64) {
+    const int x = (bx << shift) + (i & (B - 1)), y = (by << shift) + (i >> shift);
+    if (x < W && y < H) {
+      const float v = z[(size_t)y * W + x];
+      if (v != 0.0f) mn = fminf(mn, v);  // false for NaN too: fminf would ignore it anyway
+      mx = fmaxf(mx, v);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if (threadIdx.x == 0) tab[by * tab_w + bx] = make_float2(mn, mx);
+}
+
+// block size of the certification table: the smallest of 16 / 32 / 64 pixels whose table fits kCertMaxBytes of LDS
+constexpr int kCertMaxBytes = 40 * 1024;
+static int cert_shift_for(int W, int H) {
+  for (int sh = 4; sh <= 6; sh++) {
+    const size_t nb = (size_t)((W + (1 << sh) - 1) >> sh) * ((H + (1 << sh) - 1) >> sh);
+    if (nb * sizeof(float2) <= (size_t)kCertMaxBytes) return sh;
+  }
+  return 0;
+}
+size_t gi_scratch_bytes(int W, int H) {
+  const int sh = cert_shift_for(W, H);
+  if (!sh) return 0;
+  return (size_t)((W + (1 << sh) - 1) >> sh) * ((H + (1 << sh) - 1) >> sh) * sizeof(float2);
+}
+// fills p.cert_*; returns the table's byte size (0 = run without certification)
+static size_t prepare_cert(GiParams& p, int mode, const float* pos, void* scratch, hipStream_t s) {
+  p.cert_shift = 0;
+  p.cert_w = 0;
+  const char* e = getenv("GIGS_GI_CERT");
+  if (!scratch || mode < 3 || (e && e[0] == '0')) return 0;
+  const int sh = cert_shift_for(p.W, p.H);
+  if (!sh) return 0;
+  p.cert_shift = sh;
+  p.cert_w = (p.W + (1 << sh) - 1) >> sh;
+  const int bh = (p.H + (1 << sh) - 1) >> sh;
+  hipLaunchKernelGGL(gi_minmax_kernel, dim3(p.cert_w, bh), dim3(64), 0, s, p.W, p.H, sh, p.cert_w,
+                     pos + 2 * (size_t)p.H * p.W, (float2*)scratch);
+  return (size_t)p.cert_w * bh * sizeof(float2);
+}
+
 // GIGS_GI_MARCH: exact | hoist | hoist_fma | proj_nr | proj (see the block comment above march2_fast).  The fast
 // marches read the j/step table, so marches of more than 64 - kGiGroup steps take the exact path.
 #ifndef GIGS_GI_DEFAULT_MODE
@@ -949,24 +1051,27 @@ static dim3 gi_grid(const GiParams& p) {
 
 int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, float thick,
                 float delta, int step, int start, const float* normal, const float* pos,
-                float* occlusion, hipStream_t s) {
+                float* occlusion, void* scratch, hipStream_t s) {
   RayTable t;
   const int rc = get_ray_table(delta, s, t);
   if (rc) return rc;
   bool pow2;
-  const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
+  GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
   if (W >= (1 << 15) || H >= (1 << 15)) return -2;  // rejected with a message by the C-ABI wrapper
   const dim3 grid = gi_grid(p);
-#define GIGS_SSAO_LAUNCH(POW2, MODE) \
-  hipLaunchKernelGGL((ssao_kernel<POW2, MODE>), grid, dim3(256), 0, s, p, t.dev, t.sum_w, normal, pos, occlusion)
-  switch (gi_march_mode(step, start)) {
-    case 1: GIGS_SSAO_LAUNCH(false, 1); break;
-    case 2: GIGS_SSAO_LAUNCH(false, 2); break;
-    case 3: GIGS_SSAO_LAUNCH(false, 3); break;
-    case 4: GIGS_SSAO_LAUNCH(false, 4); break;
+  const int mode = gi_march_mode(step, start);
+  const size_t cert = (start < step) ? prepare_cert(p, mode, pos, scratch, s) : 0;
+  const float2* tab = (const float2*)scratch;
+#define GIGS_SSAO_LAUNCH(POW2, MODE, CERT, LDS) \
+  hipLaunchKernelGGL((ssao_kernel<POW2, MODE, CERT>), grid, dim3(256), LDS, s, p, t.dev, t.sum_w, normal, pos, occlusion, tab)
+  switch (mode) {
+    case 1: GIGS_SSAO_LAUNCH(false, 1, false, 0); break;
+    case 2: GIGS_SSAO_LAUNCH(false, 2, false, 0); break;
+    case 3: if (cert) GIGS_SSAO_LAUNCH(false, 3, true, cert); else GIGS_SSAO_LAUNCH(false, 3, false, 0); break;
+    case 4: if (cert) GIGS_SSAO_LAUNCH(false, 4, true, cert); else GIGS_SSAO_LAUNCH(false, 4, false, 0); break;
     default:
-      if (pow2) GIGS_SSAO_LAUNCH(true, 0);
-      else GIGS_SSAO_LAUNCH(false, 0);
+      if (pow2) GIGS_SSAO_LAUNCH(true, 0, false, 0);
+      else GIGS_SSAO_LAUNCH(false, 0, false, 0);
   }
 #undef GIGS_SSAO_LAUNCH
   return 0;
@@ -975,25 +1080,28 @@ int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, floa
 int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float thick,
                float delta, int step, int start, const float* normal, const float* pos,
                const float* rgb, const float* albedo, const float* /*roughness*/,
-               const float* metallic, const float* F0, float* color, float* abd, hipStream_t s) {
+               const float* metallic, const float* F0, float* color, float* abd, void* scratch, hipStream_t s) {
   RayTable t;
   const int rc = get_ray_table(delta, s, t);
   if (rc) return rc;
   bool pow2;
-  const GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
+  GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
   if (W >= (1 << 15) || H >= (1 << 15)) return -2;  // rejected with a message by the C-ABI wrapper
   const dim3 grid = gi_grid(p);
-#define GIGS_SSR_LAUNCH(POW2, MODE)                                                                                   \
-  hipLaunchKernelGGL((ssr_kernel<POW2, MODE>), grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, \
-                     color, abd)
-  switch (gi_march_mode(step, start)) {
-    case 1: GIGS_SSR_LAUNCH(false, 1); break;
-    case 2: GIGS_SSR_LAUNCH(false, 2); break;
-    case 3: GIGS_SSR_LAUNCH(false, 3); break;
-    case 4: GIGS_SSR_LAUNCH(false, 4); break;
+  const int mode = gi_march_mode(step, start);
+  const size_t cert = (start < step) ? prepare_cert(p, mode, pos, scratch, s) : 0;
+  const float2* tab = (const float2*)scratch;
+#define GIGS_SSR_LAUNCH(POW2, MODE, CERT, LDS)                                                                          \
+  hipLaunchKernelGGL((ssr_kernel<POW2, MODE, CERT>), grid, dim3(256), LDS, s, p, t.dev, normal, pos, rgb, albedo, metallic, \
+                     F0, color, abd, tab)
+  switch (mode) {
+    case 1: GIGS_SSR_LAUNCH(false, 1, false, 0); break;
+    case 2: GIGS_SSR_LAUNCH(false, 2, false, 0); break;
+    case 3: if (cert) GIGS_SSR_LAUNCH(false, 3, true, cert); else GIGS_SSR_LAUNCH(false, 3, false, 0); break;
+    case 4: if (cert) GIGS_SSR_LAUNCH(false, 4, true, cert); else GIGS_SSR_LAUNCH(false, 4, false, 0); break;
     default:
-      if (pow2) GIGS_SSR_LAUNCH(true, 0);
-      else GIGS_SSR_LAUNCH(false, 0);
+      if (pow2) GIGS_SSR_LAUNCH(true, 0, false, 0);
+      else GIGS_SSR_LAUNCH(false, 0, false, 0);
   }
 #undef GIGS_SSR_LAUNCH
   return 0;

@@ -174,7 +174,8 @@ struct GeomState {
 // each; bin_hist[g * T + t] holds first the number of instances chunk g contributes to tile t and then (in place)
 // their exclusive prefix over the chunks.
 constexpr int kBinGroups = 256;
-constexpr int kBinMaxTiles = 16384;  // the per-workgroup tile histogram lives in LDS (64 KB at this size)
+constexpr int kBinMaxTiles = 16384;
+constexpr int kBucketMaxMeanList = 2500;  // mean instances per tile above which synchronous calls use the global radix sort  // the per-workgroup tile histogram lives in LDS (64 KB at this size)
 
 struct ImageState {
   float* final_T;
@@ -278,11 +279,12 @@ void launch_depth_to_normal(int W, int H, float fx, float fy, const float* viewm
                             const float* depth, float* normal, float* depth_pos, hipStream_t s);
 int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, float thick,
                 float delta, int step, int start, const float* normal, const float* pos,
-                float* occlusion, hipStream_t s);
+                float* occlusion, void* scratch, hipStream_t s);
+size_t gi_scratch_bytes(int W, int H);
 int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float thick,
                float delta, int step, int start, const float* normal, const float* pos,
                const float* rgb, const float* albedo, const float* roughness,
-               const float* metallic, const float* F0, float* color, float* abd, hipStream_t s);
+               const float* metallic, const float* F0, float* color, float* abd, void* scratch, hipStream_t s);
 void launch_median3x3(int C, int H, int W, const float* in, float* out, hipStream_t s);
 void launch_median3x3_bwd(int C, int H, int W, const float* in, const float* gout, float* gin,
                           hipStream_t s);

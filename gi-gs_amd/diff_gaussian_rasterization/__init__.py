@@ -405,11 +405,19 @@ def _SSAO(width, height, focal_x, focal_y, radius, bias, thick, delta, step, sta
     occlusion = _new("occlusion", (1, height, width), dev)  # every pixel is written
     n, k0 = _fptr(out_normal, "out_normal")
     ps, k1 = _fptr(out_pos, "out_pos")
+    scratch = _gi_scratch(int(width), int(height), dev)
     with torch.cuda.device(dev):
-        gigs_lib.check(_lib.gigs_ssao(int(width), int(height), float(focal_x), float(focal_y), float(radius),
-                                      float(bias), float(thick), float(delta), int(step), int(start), n, ps,
-                                      occlusion.data_ptr(), _stream()), "SSAO")
+        gigs_lib.check(_lib.gigs_ssao_ex(int(width), int(height), float(focal_x), float(focal_y), float(radius),
+                                         float(bias), float(thick), float(delta), int(step), int(start), n, ps,
+                                         occlusion.data_ptr(), None if scratch is None else scratch.data_ptr(), _stream()),
+                       "SSAO")
     return occlusion
+
+
+def _gi_scratch(width: int, height: int, dev):
+    """Scratch for the march's certification table (gigs_gi_scratch_bytes): a stream-ordered torch allocation."""
+    nbytes = int(_lib.gigs_gi_scratch_bytes(width, height))
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
 
 
 def _SSR(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, out_normal, out_pos,
@@ -425,10 +433,12 @@ def _SSR(width, height, focal_x, focal_y, radius, bias, thick, delta, step, star
         ptr, k = _fptr(t, name)
         ptrs.append(ptr)
         keep.append(k)
+    scratch = _gi_scratch(int(width), int(height), dev)
     with torch.cuda.device(dev):
-        gigs_lib.check(_lib.gigs_ssr(int(width), int(height), float(focal_x), float(focal_y), float(radius),
-                                     float(bias), float(thick), float(delta), int(step), int(start), *ptrs,
-                                     color.data_ptr(), abd.data_ptr(), _stream()), "SSR")
+        gigs_lib.check(_lib.gigs_ssr_ex(int(width), int(height), float(focal_x), float(focal_y), float(radius),
+                                        float(bias), float(thick), float(delta), int(step), int(start), *ptrs,
+                                        color.data_ptr(), abd.data_ptr(), None if scratch is None else scratch.data_ptr(),
+                                        _stream()), "SSR")
     return color, abd
 
 

@@ -47,6 +47,10 @@ SIGNATURES = {
     "gigs_ssao": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_ssr": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f,
                       C.c_void_p]),
+    "gigs_gi_scratch_bytes": (C.c_size_t, [_i, _i]),
+    "gigs_ssao_ex": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_ssr_ex": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,
+                         C.c_void_p]),
     "gigs_median3x3": (_i, [_i, _i, _i, _f, _f, C.c_void_p]),
     "gigs_median3x3_backward": (_i, [_i, _i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_bilateral3x3": (_i, [_i, _i, _i, _fl, _fl, _fl, _f, _f, C.c_void_p]),

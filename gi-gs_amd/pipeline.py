@@ -220,6 +220,15 @@ class RasterFront(torch.nn.Module):
                                       rotations=rotations, derive_normal=True)
 
 
+BUCKET_MAX_MEAN_LIST = 2500  # csrc/gigs_common.h kBucketMaxMeanList
+
+
+class DenseScene(RuntimeError):
+    """The scene averages more instances per tile than the tile-bucketed binning sorts efficiently (its per-tile sort is
+    O(n log^2 n)); asynchronous binning / graph capture of the rasterizer is declined and the caller keeps the
+    synchronous path, which switches to the global radix sort for such scenes."""
+
+
 class GraphedRaster:
     """RasterFront captured into a hipGraph (forward and backward) under AsyncBinning, with the overflow protocol:
 
@@ -252,8 +261,13 @@ class GraphedRaster:
         return (means2D, cam["viewmatrix"], cam["projmatrix"], cam["campos"], bg, *[g[k] for k in RASTER_KEYS])
 
     def _capture(self, cam, g, means2D, bg):
+        H_, W_ = self.cfg[0], self.cfg[1]
+        tiles = ((H_ + 15) // 16) * ((W_ + 15) // 16)
         if self.capacity <= 0:
-            self.capacity = max(65536, -(-2 * self._probe(cam, g, bg) // 65536) * 65536)
+            probe = self._probe(cam, g, bg)
+            if probe > BUCKET_MAX_MEAN_LIST * tiles:
+                raise DenseScene(f"{probe} instances over {tiles} tiles")
+            self.capacity = max(65536, -(-2 * probe // 65536) * 65536)
         self.bin = AsyncBinning(self.capacity, self.dev)
         H, W, tx, ty = self.cfg
         mod = RasterFront(H, W, tx, ty, self.gi, self.sh_degree, self.inference)
@@ -408,8 +422,12 @@ class Stage2Step:
         """extra_loss(normal_map, albedo_map, roughness_map, metallic_map) -> scalar added to the loss before
         backward (the BRDF / envmap regularisers of train.py:387-420; see gi-gs_amd/losses.py)."""
         dev = g["means3D"].device
-        if self.fused and self.graphs and os.environ.get("GIGS_RASTER_GRAPH", "1") == "1":
-            return self._graphed_step(cam, g, gt_image, view_dirs, extra_loss)
+        if self.fused and self.graphs and os.environ.get("GIGS_RASTER_GRAPH", "1") == "1" and not getattr(self, "_dense", False):
+            try:
+                return self._graphed_step(cam, g, gt_image, view_dirs, extra_loss)
+            except DenseScene:
+                self._dense = True  # keep the rasterizer eager (synchronous binning, global radix sort); the rest stays graphed
+                self.step_begin = None
         background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
         if self.fused:
             if self.step_begin is None:

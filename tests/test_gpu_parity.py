@@ -620,3 +620,44 @@ def test_async_binning_capacity_and_overflow(orc):
     assert int(sv["ranges"].max()) <= small and torch.all(guard == 0x5A)
     for k, v in hip_planes(over).items():
         assert np.isfinite(np.nan_to_num(v)).all(), k
+
+
+@pytest.mark.parametrize("case", ["c2ish", "ragged", "gi_settings"])
+def test_gi_certification_is_exact(case, monkeypatch):
+    """The march's conservative coarse-depth certification (LDS min/max table of the z plane) only skips lookups that
+    cannot hit: SSAO and SSR outputs are bit-identical with it switched off (GIGS_GI_CERT=0), on smooth and ragged
+    views, with empty regions, at several GI settings."""
+    import pipeline
+    dgr = _dgr()
+    if case == "c2ish":
+        sc, cam, gis = scenes.surface_scene(P=120_000, sh_degree=1, seed=8, scale_mu=0.012), scenes.orbit_camera(9, 32, 640, 512, radius=3.4), [scenes.GI_DEFAULTS]
+    elif case == "ragged":
+        sc, cam, gis = scenes.surface_scene(P=50_000, sh_degree=1, seed=2, scale_mu=0.02), scenes.orbit_camera(3, 16, 611, 403, radius=3.2), [scenes.GI_DEFAULTS]
+    else:
+        sc, cam = scenes.surface_scene(P=30_000, sh_degree=1, seed=3, scale_mu=0.02), scenes.orbit_camera(0, 4, 208, 160, radius=3.5)
+        gis = [dict(scenes.GI_DEFAULTS, radius=1.6, start=4), dict(scenes.GI_DEFAULTS, step=12, start=5, delta=0.125),
+               dict(scenes.GI_DEFAULTS, bias=0.2, thick=0.5), dict(scenes.GI_DEFAULTS, start=0)]
+    g = {k: tt(sc[k]) for k in GAUSS_KEYS}
+    camt = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    W, H = cam["image_width"], cam["image_height"]
+    fx, fy = focal(cam)
+    with torch.no_grad():
+        res = pipeline.render(camt, g, 1, torch.zeros(3, device=DEV), dict(scenes.GI_DEFAULTS, start=16))
+        out, _, _ = pipeline.rasterize(camt, g, 1, torch.zeros(3, device=DEV), dict(scenes.GI_DEFAULTS, start=16))
+    raw_nview, posf = out[10].contiguous(), out[11].contiguous()
+    F0 = torch.full((3, H, W), 0.04, device=DEV)
+    rgb = res["albedo_map"].clamp(0, 1).contiguous()
+    hits = 0
+    for gi in gis:
+        a = (gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
+        got = {}
+        for cert in ("1", "0"):
+            monkeypatch.setenv("GIGS_GI_CERT", cert)
+            occ = dgr._C.SSAO(W, H, fx, fy, *a, raw_nview, posf)
+            col, abd = dgr._C.SSR(W, H, fx, fy, *a, res["out_normal_view"].contiguous(), posf, rgb, res["albedo_map"].contiguous(),
+                                  res["roughness_map"].contiguous(), res["metallic_map"].contiguous(), F0)
+            got[cert] = (occ.clone(), col.clone(), abd.clone())
+        for x, y in zip(got["1"], got["0"]):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (case, gi)
+        hits += int((got["1"][0] < 1.0).sum())
+    assert hits > 0, "no ray of the test views hits anything: the comparison would be vacuous"

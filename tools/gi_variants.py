@@ -140,6 +140,9 @@ def main():
             for mode in ("exact", "hoist_fma", "proj"):
                 _, t = run_mode(mode, gb, cam, gi, args.reps)
                 row[mode] = t
+            os.environ["GIGS_GI_CERT"] = "0"
+            _, row["proj_nocert"] = run_mode("proj", gb, cam, gi, args.reps)
+            os.environ.pop("GIGS_GI_CERT")
             report["tile_sweep"]["%dx%d" % (1 << log2w, 64 >> log2w)] = row
             print("tile %2dx%-2d " % (1 << log2w, 64 >> log2w) + "  ".join("%s %.3f/%.3f ms" % (m, v["ssao_ms"], v["ssr_ms"]) for m, v in row.items()), flush=True)
         os.environ.pop("GIGS_GI_TILE_LOG2W", None)
