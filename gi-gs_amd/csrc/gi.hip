@@ -173,8 +173,8 @@ struct GiParams {
   float inv_step;  // exact 1/step when step is a power of two
   int nrays;
   int tile_log2w;  // the 64 pixels of a workgroup form a (1 << tile_log2w) x (64 >> tile_log2w) rectangle
-  int cert_shift;  // certification blocks are (1 << cert_shift)^2 pixels; 0 = no certification table
-  int cert_w;      // blocks per row of the table
+  int cert_shift;      // certification blocks are (1 << cert_shift)^2 pixels; 0 = no certification table
+  int cert_w, cert_h;  // blocks per row / column of the image; the table is (cert_w + 2) x (cert_h + 2) with its border
   // j / step for j = start .. start + 63 (exact for a power-of-two step): the fast path reads its per-step factor from
   // here with a scalar load instead of converting and multiplying on the vector ALU for every group (marches of more
   // than kFjTable - kGiGroup steps take the general path)
@@ -546,26 +546,15 @@ __device__ __forceinline__ int cvt_flr(float t) {  // (int)floor(t), saturating,
   return r;
 }
 
-// Conservative certification (kCert): the z plane's min / max over square blocks (gi_minmax_kernel) sit in LDS; a sample
-// whose hit interval, widened by 2^-16 relative + 1e-6 absolute, lies entirely above the block's maximum or entirely
-// below its non-zero minimum (and above zero: empty pixels hold 0) cannot hit whichever pixel of the block it selects,
-// so its gather and depth test are skipped -- for the whole wave when no lane needs them, which is the case for ~92 %
-// of the wave-samples of the bench view (tools/gi_cert_rate.py).  Skipped samples would have failed the exact test by a
-// margin far above its rounding error, so the outcome of every ray -- and every output bit -- is unchanged
-// (tests/test_gpu_parity.py::test_gi_certification_is_exact).  Once the march's arithmetic was down to ~12 instructions
-// per sample the kernel was bound by the texture-address path (~30 cycles per scattered wave-gather,
-// tools/microbench/gather_rate.hip); this removes most gathers from it.
-template <int kMode, int kGroup, bool kCert>
+template <int kMode, int kGroup>
 __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c, const f32x2* Bxy, f32x2 Bz2,
-                                            __amdgpu_buffer_rsrc_t pos_z, const float2* __restrict__ s_tab, int* hit) {
-  static_assert(!kCert || kMode >= 3, "certification is wired into the projective marches");
+                                            __amdgpu_buffer_rsrc_t pos_z, int* hit) {
   bool open[2] = {true, true};
   hit[0] = hit[1] = -1;
   const f32x2 Dz2 = {c.Dz, c.Dz};
   for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
     unsigned off[2][kGroup];
     bool inb[2][kGroup];
-    bool need[2][kGroup];          // kCert: this lane's sample must be looked up
     f32x2 ta[kGroup], tb[kGroup];  // modes 1/2: spz + bias, spz - thick; modes 3/4: mid (ta only)
 #pragma unroll
     for (int g = 0; g < kGroup; g++) {
@@ -574,7 +563,6 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
       const bool in_range = (j0 + g) < p.step;
       f32x2 r;
       f32x2 den;
-      f32x2 lo_c = {0.0f, 0.0f}, hi_c = {0.0f, 0.0f};
       if constexpr (kMode >= 3) {
         den = __builtin_elementwise_fma(Bz2, fj2, Dz2);
         ta[g] = den + c.cm;
@@ -582,10 +570,6 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
         if constexpr (kMode == 3) {
           const f32x2 e0 = __builtin_elementwise_fma(-den, r, f32x2{1.0f, 1.0f});
           r = __builtin_elementwise_fma(e0, r, r);
-        }
-        if constexpr (kCert) {
-          lo_c = __builtin_elementwise_fma(ta[g], f32x2{1.0f - 0x1p-16f, 1.0f - 0x1p-16f}, f32x2{-c.hh - 1e-6f, -c.hh - 1e-6f});
-          hi_c = __builtin_elementwise_fma(ta[g], f32x2{1.0f + 0x1p-16f, 1.0f + 0x1p-16f}, f32x2{c.hh + 1e-6f, c.hh + 1e-6f});
         }
       } else {
         const f32x2 spz = (kMode == 2) ? __builtin_elementwise_fma(Bz2, fj2, Dz2) : Dz2 + Bz2 * fj2;
@@ -619,28 +603,10 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
         const int iy = cvt_flr(t.y);
         inb[k][g] = in_range && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
         off[k][g] = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;
-        if constexpr (kCert) {
-          const unsigned b = __umul24((unsigned)iy >> p.cert_shift, (unsigned)p.cert_w) + ((unsigned)ix >> p.cert_shift);
-          const float2 mm = s_tab[inb[k][g] ? b : 0u];  // {non-zero minimum, max(maximum, 0)}
-          const float lo = k == 0 ? lo_c.x : lo_c.y, hi = k == 0 ? hi_c.x : hi_c.y;
-          const bool cert = (lo > mm.y) || (hi < mm.x && lo > 0.0f);
-          need[k][g] = open[k] && inb[k][g] && !cert;
-        }
       }
     }
     float zn[2 * kGroup];
-    if constexpr (kCert) {
-      // only the samples some lane of the wave still needs are looked up (all in flight, then one wait)
-#pragma unroll
-      for (int g = 0; g < kGroup; g++)
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-          zn[2 * g + k] = 0.0f;  // 0 fails every test that can be skipped (lo > 0)
-          if (__builtin_amdgcn_ballot_w64(need[k][g]) != 0) zn[2 * g + k] = gather_idx_issue(need[k][g] ? off[k][g] : 0xffffffffu, pos_z);
-        }
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(zn[0]), "+v"(zn[1]), "+v"(zn[2]), "+v"(zn[3]), "+v"(zn[4]), "+v"(zn[5]), "+v"(zn[6]), "+v"(zn[7]));
-    } else {
+    {
       unsigned in[2 * kGroup];
 #pragma unroll
       for (int g = 0; g < kGroup; g++) { in[2 * g] = off[0][g]; in[2 * g + 1] = off[1][g]; }
@@ -655,12 +621,103 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
         bool h;
         if constexpr (kMode >= 3) {
           h = inb[k][g] && fabsf(z - (k == 0 ? ta[g].x : ta[g].y)) <= c.hh;
-          if constexpr (kCert) h = h && need[k][g];
         } else {
           h = inb[k][g] && (z <= (k == 0 ? ta[g].x : ta[g].y)) && (z >= (k == 0 ? tb[g].x : tb[g].y));
         }
         hit[k] = (open[k] && h) ? (int)off[k][g] : hit[k];
         open[k] = open[k] && inb[k][g] && !h;
+      }
+      any_open = any_open || open[k];
+    }
+    if (!__any(any_open)) break;
+  }
+}
+
+// Conservative certification in front of the projective march.  The z plane's {non-zero minimum, max(maximum, 0)} over
+// square blocks of 2^cert_shift pixels (gi_minmax_kernel) sit in LDS, with a border of "never certify" entries around
+// the image and on blocks the image only partly covers.  A sample is projected in BLOCK units first (the per-pixel
+// constants are pre-scaled by the exact factor 2^-shift); if its hit interval, widened by 2^-16 relative + 1e-6, lies
+// entirely above the block's maximum, or entirely below its non-zero minimum and above zero (empty pixels hold 0), then
+// whichever pixel of that -- fully in-image -- block the sample selects, the reference's test fails by a margin far above
+// its rounding error: the sample neither hits nor leaves the image, the ray simply stays open, and nothing else has to
+// be computed for it.  Only when some lane of the wave is NOT certified for a sample does the wave run the exact part
+// (pixel coordinates = block coordinates * 2^shift exactly, bounds test, gather, depth test).  ~92 % of the wave-samples
+// of the bench view skip it (tools/gi_cert_rate.py); every ray's outcome, hence every output bit, is unchanged
+// (tests/test_gpu_parity.py::test_gi_certification_is_exact).
+struct CertPix {
+  f32x2 Axy, cxy;  // FastPix::Axy / cxy scaled by 2^-shift
+  float scale;     // 2^shift
+  int bw, bh;      // blocks per row / column of the image (the table has a border of one block all around)
+};
+
+__device__ __forceinline__ int clamp_m1(int v, int hi) {  // median(v, -1, hi): one VOP3 instruction (the compiler emits min + max)
+  int r;
+  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(hi));
+  return r;
+}
+
+template <int kMode, int kGroup>
+__device__ __forceinline__ void march2_cert(const GiParams& p, const FastPix& c, const CertPix& cp, const f32x2* Bxy16,
+                                            f32x2 Bz2, __amdgpu_buffer_rsrc_t pos_z, const float2* __restrict__ s_tab,
+                                            int* hit) {
+  static_assert(kMode >= 3, "certification is wired into the projective marches");
+  bool open[2] = {true, true};
+  hit[0] = hit[1] = -1;
+  const f32x2 Dz2 = {c.Dz, c.Dz};
+  const int row8 = (cp.bw + 2) * 8;
+  const char* tab0 = reinterpret_cast<const char*>(s_tab) + row8 + 8;  // entry of block (0, 0): the border sits at -1
+  for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
+    f32x2 tb[2][kGroup];  // sample position in block units (+ the rounding addend, scaled)
+    f32x2 mid[kGroup];
+    bool need[2][kGroup];
+    // phase A: every sample of the group up to its table entry and the certification decision; no branches
+#pragma unroll
+    for (int g = 0; g < kGroup; g++) {
+      const float fj = p.fjt[j0 - p.start + g];  // j / step
+      const f32x2 fj2 = {fj, fj};
+      const bool in_range = (j0 + g) < p.step;
+      const f32x2 den = __builtin_elementwise_fma(Bz2, fj2, Dz2);
+      mid[g] = den + c.cm;
+      f32x2 r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+      if constexpr (kMode == 3) {
+        const f32x2 e0 = __builtin_elementwise_fma(-den, r, f32x2{1.0f, 1.0f});
+        r = __builtin_elementwise_fma(e0, r, r);
+      }
+      const f32x2 lo_c = __builtin_elementwise_fma(mid[g], f32x2{1.0f - 0x1p-16f, 1.0f - 0x1p-16f}, f32x2{-c.hh - 1e-6f, -c.hh - 1e-6f});
+      const f32x2 hi_c = __builtin_elementwise_fma(mid[g], f32x2{1.0f + 0x1p-16f, 1.0f + 0x1p-16f}, f32x2{c.hh + 1e-6f, c.hh + 1e-6f});
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const float rk = k == 0 ? r.x : r.y;
+        const f32x2 n = __builtin_elementwise_fma(Bxy16[k], fj2, cp.Axy);
+        tb[k][g] = __builtin_elementwise_fma(n, f32x2{rk, rk}, cp.cxy);
+        const int bx = clamp_m1(cvt_flr(tb[k][g].x), cp.bw);
+        const int by = clamp_m1(cvt_flr(tb[k][g].y), cp.bh);
+        const float2 mm = *reinterpret_cast<const float2*>(tab0 + (__mul24(by, row8) + (bx << 3)));
+        const float lo = k == 0 ? lo_c.x : lo_c.y, hi = k == 0 ? hi_c.x : hi_c.y;
+        const bool cert = (lo > mm.y) | ((hi < mm.x) & (lo > 0.0f));
+        need[k][g] = open[k] & in_range & !cert;
+      }
+    }
+    // phase B: in ray order, the exact part for the samples some lane of the wave still needs (~8 % of them: the
+    // lookup is waited for on the spot, other waves cover the latency)
+    bool any_open = false;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+      for (int g = 0; g < kGroup; g++) {
+        if (__builtin_amdgcn_ballot_w64(need[k][g]) != 0) {
+          const f32x2 t = tb[k][g] * cp.scale;  // exact: the pixel coordinates the uncertified march computes
+          const int ix = cvt_flr(t.x);
+          const int iy = cvt_flr(t.y);
+          const bool inb = (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+          const unsigned off = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;
+          const bool live = open[k] && need[k][g];
+          float z = gather_idx_issue((live && inb) ? off : 0xffffffffu, pos_z);
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(z));
+          const bool h = live && inb && fabsf(z - (k == 0 ? mid[g].x : mid[g].y)) <= c.hh;
+          hit[k] = h ? (int)off : hit[k];
+          open[k] = open[k] && !(live && (!inb || h));
+        }
       }
       any_open = any_open || open[k];
     }
@@ -689,10 +746,20 @@ __device__ __forceinline__ FastPix make_fast(const GiParams& p, v3 pos, float cx
 }
 // rows of the tangent frame pre-scaled so that B = M * ts is the per-ray step vector (times j/step per sample)
 struct FastTbn { v3 mx, my, mz; };
+__device__ __forceinline__ CertPix make_cert(const GiParams& p, const FastPix& c, float inv_scale) {
+  CertPix cp;
+  cp.Axy = c.Axy * inv_scale;  // exact power-of-two scalings
+  cp.cxy = c.cxy * inv_scale;
+  cp.scale = 1.0f / inv_scale;
+  cp.bw = p.cert_w;
+  cp.bh = p.cert_h;
+  return cp;
+}
+// xy_scale = 2^-cert_shift when the march runs in block units (exact), else 1
 template <int kMode>
-__device__ __forceinline__ FastTbn make_fast_tbn(const GiParams& p, const Tbn& m, float a) {
+__device__ __forceinline__ FastTbn make_fast_tbn(const GiParams& p, const Tbn& m, float a, float xy_scale = 1.0f) {
   const float s = a * a * p.radius;
-  const float sx = kMode >= 3 ? s * p.fx : s, sy = kMode >= 3 ? s * p.fy : s;
+  const float sx = (kMode >= 3 ? s * p.fx : s) * xy_scale, sy = (kMode >= 3 ? s * p.fy : s) * xy_scale;
   FastTbn r;
   r.mx = {m.t.x * sx, m.b.x * sx, m.n.x * sx};
   r.my = {m.t.y * sy, m.b.y * sy, m.n.y * sy};
@@ -756,7 +823,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
   __shared__ float s_part[kGiWaves][64];
   extern __shared__ float2 s_cert[];
   if constexpr (kCert) {
-    const int nb = p.cert_w * ((p.H + (1 << p.cert_shift) - 1) >> p.cert_shift);
+    const int nb = (p.cert_w + 2) * (p.cert_h + 2);
     for (int i = threadIdx.x; i < nb; i += 256) s_cert[i] = cert_tab[i];
     __syncthreads();
   }
@@ -780,7 +847,9 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
         // absurd magnitudes (|pos| >= 2^59) are outside the fast marches' contract: such a pixel takes no hits
         if (mag_ok) {
           const FastPix c = make_fast<kMode>(p, pos, cx, cy);
-          const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a);
+          const float inv_scale = kCert ? __uint_as_float((127u - (unsigned)p.cert_shift) << 23) : 1.0f;  // 2^-shift
+          const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a, inv_scale);
+          const CertPix cp = make_cert(p, c, inv_scale);
           for (int r = r0; r < r1; r += 2) {
             const int rb = min(r + 1, r1 - 1);  // an odd chunk marches its last ray twice and counts it once
             f32x2 Bxy[2], Bz2;
@@ -789,7 +858,8 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             fast_ray<kMode>(p, tbn, ft, a, rays[2 * rb], Bxy[1], bz1);
             Bz2 = f32x2{bz0, bz1};
             int hit[2];
-            march2_fast<kMode, kGiGroup, kCert>(p, c, Bxy, Bz2, pos_z, s_cert, hit);
+            if constexpr (kCert) march2_cert<kMode, kGiGroup>(p, c, cp, Bxy, Bz2, pos_z, s_cert, hit);
+            else march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
             occ += hit[0] >= 0 ? rays[2 * r + 1].y : 0.0f;
             occ += (hit[1] >= 0 && rb != r) ? rays[2 * rb + 1].y : 0.0f;
           }
@@ -842,7 +912,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
   __shared__ float s_part[kGiWaves][3][64];
   extern __shared__ float2 s_cert[];
   if constexpr (kCert) {
-    const int nb = p.cert_w * ((p.H + (1 << p.cert_shift) - 1) >> p.cert_shift);
+    const int nb = (p.cert_w + 2) * (p.cert_h + 2);
     for (int i = threadIdx.x; i < nb; i += 256) s_cert[i] = cert_tab[i];
     __syncthreads();
   }
@@ -872,7 +942,9 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
     if constexpr (kMode > 0) {
       if (mag_ok) {  // see ssao_kernel
         const FastPix c = make_fast<kMode>(p, pos, cx, cy);
-        const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a);
+        const float inv_scale = kCert ? __uint_as_float((127u - (unsigned)p.cert_shift) << 23) : 1.0f;  // 2^-shift
+        const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a, inv_scale);
+        const CertPix cp = make_cert(p, c, inv_scale);
         for (int r = r0; r < r1; r += 2) {
           const int rb = min(r + 1, r1 - 1);
           const float4 ra0 = rays[2 * r], ra1 = rays[2 * rb];
@@ -882,7 +954,8 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
           fast_ray<kMode>(p, tbn, ft, a, ra1, Bxy[1], bz1);
           Bz2 = f32x2{bz0, bz1};
           int hit[2];
-          march2_fast<kMode, kGiGroup, kCert>(p, c, Bxy, Bz2, pos_z, s_cert, hit);
+          if constexpr (kCert) march2_cert<kMode, kGiGroup>(p, c, cp, Bxy, Bz2, pos_z, s_cert, hit);
+          else march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
           if (rb == r) hit[1] = -1;
           if (__any(hit[0] >= 0 || hit[1] >= 0)) {
             add_hit(hit[0], ra0.w, rays[2 * r + 1].x);
@@ -978,56 +1051,60 @@ static GiParams make_params(int W, int H, float fx, float fy, float radius, floa
   p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
   return p;
 }
-// Certification table: per (1 << shift)^2 block of the z plane {minimum over its non-zero pixels (+inf if none),
-// max(maximum, 0)}; NaN pixels are ignored (a NaN never passes the depth test).  One wave per block.
+// Certification table, (bw + 2) x (bh + 2) entries: per (1 << shift)^2 block of the z plane {minimum over its non-zero
+// pixels (+inf if none), max(maximum, 0)}; NaN pixels are ignored (a NaN never passes the depth test).  Blocks of the
+// border ring and blocks the image covers only partly hold {-inf, +inf}: nothing is ever certified there, so samples
+// that may lie outside the image always take the exact path.  One wave per entry.
 __global__ void __launch_bounds__(64)
-gi_minmax_kernel(int W, int H, int shift, int tab_w, const float* __restrict__ z, float2* __restrict__ tab) {
-  const int bx = blockIdx.x, by = blockIdx.y, B = 1 << shift;
+gi_minmax_kernel(int W, int H, int shift, int bw, int bh, const float* __restrict__ z, float2* __restrict__ tab) {
+  const int bx = (int)blockIdx.x - 1, by = (int)blockIdx.y - 1, B = 1 << shift;
   float mn = __builtin_inff(), mx = 0.0f;
-  for (int i = threadIdx.x; i < B * B; i += 64) {
-    const int x = (bx << shift) + (i & (B - 1)), y = (by << shift) + (i >> shift);
-    if (x < W && y < H) {
-      const float v = z[(size_t)y * W + x];
+  const bool full = bx >= 0 && by >= 0 && ((bx + 1) << shift) <= W && ((by + 1) << shift) <= H;
+  if (full) {
+    for (int i = threadIdx.x; i < B * B; i += 64) {
+      const float v = z[(size_t)((by << shift) + (i >> shift)) * W + (bx << shift) + (i & (B - 1))];
       if (v != 0.0f) mn = fminf(mn, v);  // false for NaN too: fminf would ignore it anyway
       mx = fmaxf(mx, v);
     }
-  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, o));
-    mx = fmaxf(mx, __shfl_xor(mx, o));
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, o));
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+  } else {
+    mn = -__builtin_inff();
+    mx = __builtin_inff();
   }
-  if (threadIdx.x == 0) tab[by * tab_w + bx] = make_float2(mn, mx);
+  if (threadIdx.x == 0) tab[(size_t)blockIdx.y * (bw + 2) + blockIdx.x] = make_float2(mn, mx);
 }
 
 // block size of the certification table: the smallest of 16 / 32 / 64 pixels whose table fits kCertMaxBytes of LDS
 constexpr int kCertMaxBytes = 40 * 1024;
+static size_t cert_table_bytes(int W, int H, int sh) {
+  return (size_t)(((W + (1 << sh) - 1) >> sh) + 2) * (((H + (1 << sh) - 1) >> sh) + 2) * sizeof(float2);
+}
 static int cert_shift_for(int W, int H) {
-  for (int sh = 4; sh <= 6; sh++) {
-    const size_t nb = (size_t)((W + (1 << sh) - 1) >> sh) * ((H + (1 << sh) - 1) >> sh);
-    if (nb * sizeof(float2) <= (size_t)kCertMaxBytes) return sh;
-  }
+  for (int sh = 4; sh <= 6; sh++)
+    if (cert_table_bytes(W, H, sh) <= (size_t)kCertMaxBytes) return sh;
   return 0;
 }
 size_t gi_scratch_bytes(int W, int H) {
   const int sh = cert_shift_for(W, H);
-  if (!sh) return 0;
-  return (size_t)((W + (1 << sh) - 1) >> sh) * ((H + (1 << sh) - 1) >> sh) * sizeof(float2);
+  return sh ? cert_table_bytes(W, H, sh) : 0;
 }
 // fills p.cert_*; returns the table's byte size (0 = run without certification)
 static size_t prepare_cert(GiParams& p, int mode, const float* pos, void* scratch, hipStream_t s) {
-  p.cert_shift = 0;
-  p.cert_w = 0;
+  p.cert_shift = p.cert_w = p.cert_h = 0;
   const char* e = getenv("GIGS_GI_CERT");
   if (!scratch || mode < 3 || (e && e[0] == '0')) return 0;
   const int sh = cert_shift_for(p.W, p.H);
   if (!sh) return 0;
   p.cert_shift = sh;
   p.cert_w = (p.W + (1 << sh) - 1) >> sh;
-  const int bh = (p.H + (1 << sh) - 1) >> sh;
-  hipLaunchKernelGGL(gi_minmax_kernel, dim3(p.cert_w, bh), dim3(64), 0, s, p.W, p.H, sh, p.cert_w,
+  p.cert_h = (p.H + (1 << sh) - 1) >> sh;
+  hipLaunchKernelGGL(gi_minmax_kernel, dim3(p.cert_w + 2, p.cert_h + 2), dim3(64), 0, s, p.W, p.H, sh, p.cert_w, p.cert_h,
                      pos + 2 * (size_t)p.H * p.W, (float2*)scratch);
-  return (size_t)p.cert_w * bh * sizeof(float2);
+  return cert_table_bytes(p.W, p.H, sh);
 }
 
 // GIGS_GI_MARCH: exact | hoist | hoist_fma | proj_nr | proj (see the block comment above march2_fast).  The fast
