@@ -76,32 +76,41 @@ def pmc_traffic(stage: str):
     profiles/ (separate FETCH_SIZE / WRITE_SIZE passes; (2*FETCH_SIZE + WRITE_SIZE) * 1024 per
     MI355X_MICROARCH.md -- the x2 is calibrated for wide streaming reads only, so for the
     gather-dominated GI kernels this is an upper estimate).  None if no summary is committed."""
-    import glob
-    names = {"ssao": "ssao_kernel<true>", "ssr": "ssr_kernel<true>", "blend_fwd": "blend_fwd_kernel",
-             "blend_bwd": "blend_bwd_kernel", "shade_bwd": "shade_bwd_kernel", "shade_fwd": "shade_fwd_kernel",
-             "preprocess_fwd": "preprocess_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel", "sort": "rocprim_sort"}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")), key=os.path.getmtime)
-    if not files or stage not in names:
-        return None
+    k = _pmc_entry(stage)
     try:
-        k = json.load(open(files[-1])).get(names[stage], {})
         return int((2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024)
     except Exception:  # noqa: BLE001
         return None
+
+
+_PMC_NAMES = {"ssao": "ssao_kernel", "ssr": "ssr_kernel", "blend_fwd": "blend_fwd_kernel", "blend_bwd": "blend_bwd_kernel",
+              "shade_bwd": "shade_bwd_kernel", "shade_fwd": "shade_fwd_kernel", "preprocess_fwd": "preprocess_fwd_kernel",
+              "preprocess_bwd": "preprocess_bwd_kernel", "sort": "bin_sort_kernel"}
+
+
+def _pmc_entry(stage: str):
+    """Counters of `stage`'s kernel from the newest committed summary (profiles/rNN/pmc_summary*.json, by name order);
+    template instantiations of one kernel are matched by prefix and the one with the most launches is taken."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")))
+    if not files or stage not in _PMC_NAMES:
+        return {}
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:  # noqa: BLE001
+        return {}
+    cands = [v for k, v in d.items() if k.startswith(_PMC_NAMES[stage])]
+    if not cands:
+        return {}
+    return max(cands, key=lambda v: max((c.get("launches", 0) for c in v.values()), default=0))
 
 
 def pmc_valu_busy(stage: str):
     """Fraction of the kernel's cycles in which the VALU pipes were issuing, from the same committed PMC
     summary: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles
     summed over the 8 XCDs.  This -- not the HBM fraction -- is the roofline that binds the GI march."""
-    import glob
-    names = {"ssao": "ssao_kernel<true>", "ssr": "ssr_kernel<true>", "blend_fwd": "blend_fwd_kernel",
-             "blend_bwd": "blend_bwd_kernel"}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")), key=os.path.getmtime)
-    if not files or stage not in names:
-        return None
+    k = _pmc_entry(stage)
     try:
-        k = json.load(open(files[-1])).get(names[stage], {})
         cycles = k["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
         return round(4.0 * k["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / (1024.0 * cycles), 3)
     except Exception:  # noqa: BLE001
@@ -409,18 +418,22 @@ def main():
                     eager(cams_t[(2 + i) % n_views], g, gt_image, view_dirs[(2 + i) % n_views])
                 torch.cuda.synchronize()
             add_stages(prof2.stages, extra, "eager-extra")
-        # the roofline entry is taken from stages timed live over the timed region
-        with_bytes = [k for k in kernels if "achieved_GBs" in kernels[k] and kernels[k]["timed"] == "live"]
+        # the roofline entry: the kernel with the largest time per step among those with an event timing -- taken live
+        # over the timed region where the stage is launched eagerly, otherwise from the eager steps right after it (a
+        # step replayed from hipGraphs, the default, has no events inside its kernel nodes)
+        live = [k for k in kernels if "achieved_GBs" in kernels[k] and kernels[k]["timed"] == "live"]
+        with_bytes = live or [k for k in kernels if "achieved_GBs" in kernels[k]]
         dom = max(with_bytes, key=lambda k: kernels[k]["ms_per_step"]) if with_bytes else None
         roofline = None
         if dom is not None and "achieved_GBs" in kernels[dom]:
             a = kernels[dom]["achieved_GBs"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(a / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
-                        "valu_busy": pmc_valu_busy(dom),
-                        "note": "dominant kernel by time; its per-sample z-plane gathers are served by L2/L1 (the plane is "
-                                "2.5 MB), so it is bound by the texture-address / L1 path and VALU issue, not by HBM "
-                                "(valu_busy from the committed PMC pass; DESIGN.md section 5)"}
+                        "valu_busy": pmc_valu_busy(dom), "timed": kernels[dom]["timed"],
+                        "note": "dominant kernel by time; its z-plane lookups are served by L2/L1 (the plane is 2.5 MB) and "
+                                "most of them are skipped by the certification table in LDS, so it is bound by fp32 VALU "
+                                "issue, not by HBM (valu_busy = share of its cycles with the vector ALUs issuing, from the "
+                                "committed PMC pass; DESIGN.md section 5)"}
         cpu = parity_rep = None
         vi0 = args.warmup % n_views
         if not args.no_cpu_baseline and world == 1 and shade == "hip":

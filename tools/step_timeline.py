@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--marker", default="preprocess_fwd_kernel")
     ap.add_argument("--step", type=int, default=-2, help="which step (index into the marker launches; -2 = last complete one)")
     ap.add_argument("--min-us", type=float, default=8.0)
+    ap.add_argument("--all-queues", action="store_true")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -44,6 +45,12 @@ def main():
         if q == main_q:
             continue
         print("queue %s spans +%.1f .. +%.1f us" % (q, min(s for s, _, _ in ks) / 1e3, max(e for _, e, _ in ks) / 1e3))
+        if a.all_queues:
+            prev_end = 0
+            for s, e, name in sorted(ks):
+                if (e - s) / 1e3 >= a.min_us or (s - prev_end) / 1e3 >= a.min_us:
+                    print("  +%8.1f us  dur %8.1f us  gap-before %7.1f us  %s" % (s / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name[:70]))
+                prev_end = max(prev_end, e)
 
 
 if __name__ == "__main__":
