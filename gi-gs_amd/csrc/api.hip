@@ -346,7 +346,7 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
     {
       StageScope sc(kSort, s);
       gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, geom, bin, img, s);
-      if (gigs::launch_bin_sort((int)T, bin, img, s) != 0) return fail(GIGS_ERR_HIP, "bin_sort: cannot raise the LDS limit");
+      if (gigs::launch_bin_sort((int)T, P, bin, img, s) != 0) return fail(GIGS_ERR_HIP, "bin_sort: cannot fork the sort streams");
     }
     STAGE_CHECK("bin scatter / sort");
   } else {
@@ -452,7 +452,7 @@ int gigs_backward(int P, int D, int M, int R, const float* background, int width
 
   {
     StageScope sc(kBlendBwd, s);
-    gigs::launch_zero_words(reinterpret_cast<uint32_t*>(geom.grec), (size_t)P * GIGS_GREC, s);  // a kernel, not a memset node: capturable
+    // geom.grec is zero here: preprocess_fwd clears it and preprocess_bwd clears it again after reading (no fill launch)
     gigs::launch_blend_bwd(a, geom, bin, img, s);
   }
   STAGE_CHECK("render backward");

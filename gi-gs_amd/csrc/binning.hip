@@ -11,8 +11,11 @@
 // All stages are integer, HBM-bound work (12 B written per instance by the
 // expansion, 24 B moved per instance per sort pass).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string.h>
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -147,7 +150,7 @@ void launch_tile_ranges(int R, const BinningState& b, uint2* ranges, hipStream_t
 //   2. bin_prefix:  per tile, exclusive prefix of the counts over the chunks (in place) and the tile's total; then an
 //                   exclusive scan of the totals = `ranges` (identifyTileRanges' result) and R -- all on the device;
 //   3. bin_scatter: the same walk again; a slot inside the tile's range comes from an LDS cursor, the 64-bit key
-//                   (depth bits << 32 | Gaussian index) goes there.  The order inside a tile is arbitrary here...
+//                   (depth bits << idx_bits | Gaussian index, idx_bits = bits of P - 1) goes there.  The order inside a tile is arbitrary here...
 //   4. bin_sort:    ...because each tile's keys are then sorted (one workgroup per tile, bitonic network in LDS, longest
 //                   lists first).  The keys are unique and (depth, index)-ordered = the stable depth sort of
 //                   index-ordered input, so point_list -- and `keys` in the reference's tile|depth format, which is
@@ -280,7 +283,7 @@ bin_prefix_tiles_kernel(int T, unsigned capacity, const uint32_t* __restrict__ t
 
 __global__ void __launch_bounds__(256)
 bin_scatter_kernel(int P, int T, const int* __restrict__ radii, const float* __restrict__ means2D,
-                   const float* __restrict__ depths, unsigned gx, unsigned gy, unsigned capacity,
+                   const float* __restrict__ depths, unsigned gx, unsigned gy, unsigned capacity, unsigned idx_bits,
                    const uint32_t* __restrict__ bin_hist, const uint32_t* __restrict__ tile_start,
                    uint64_t* __restrict__ keys) {
   extern __shared__ uint32_t s_cur[];
@@ -289,7 +292,7 @@ bin_scatter_kernel(int P, int T, const int* __restrict__ radii, const float* __r
   __syncthreads();
   bin_walk(P, radii, means2D, gx, gy, [&](int idx, unsigned tile) {
     const uint32_t slot = atomicAdd(&s_cur[tile], 1u);
-    if (slot < capacity) keys[slot] = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
+    if (slot < capacity) keys[slot] = ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint32_t)idx;
   });
 }
 
@@ -323,95 +326,57 @@ __device__ __forceinline__ void bitonic_sort_asc(unsigned n, unsigned npad_log2,
   }
 }
 
-// The same sort for a list that fits the LDS buffer, padded there to a power of two with +inf: the classic network
-// (direction alternates with bit kb of the index), whose substages all have plain strides, so THREE consecutive substages
-// are done per phase on 8 keys held in registers (strides 4m, 2m, m: keys base + e*m) -- 35 barrier phases instead of 91
-// for 8192 keys, and each phase issues its 8 LDS reads back to back.
-// LDS layout of the keys: one pad slot after every 16 keys (a 128-byte bank row).  The fused phases read runs of 2^lowpos
-// consecutive keys that start 2^(lowpos+3) keys apart -- unpadded, the runs of a wave all start in the same bank
-// (32-way conflicts at lowpos = 1, measured as 2.5 us per phase); padded, consecutive runs shift by one 8-byte bank pair.
-__device__ __forceinline__ unsigned lds_slot(unsigned i) { return i + (i >> 4); }
-
-template <int kThreads>
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t* __restrict__ s, unsigned npad_log2) {
-  const unsigned npad = 1u << npad_log2;
-  for (unsigned kb = 1; kb <= npad_log2; kb++) {
-    int jb = (int)kb - 1;
-    while (jb >= 0) {
-      const int g = min(3, jb + 1);
-      const int lowpos = jb - g + 1;
-      const unsigned m = 1u << lowpos, cnt = 1u << g;
-      const unsigned items = npad >> g;
-      for (unsigned t = threadIdx.x; t < items; t += kThreads) {
-        const unsigned base = ((t >> lowpos) << (lowpos + g)) | (t & (m - 1));
-        const bool asc = ((base >> kb) & 1u) == 0;
-        uint64_t v[8];
-#pragma unroll
-        for (unsigned e = 0; e < 8; e++)
-          if (e < cnt) v[e] = s[lds_slot(base + e * m)];
-#pragma unroll
-        for (int sft = 2; sft >= 0; sft--) {
-          if (sft < g) {
-#pragma unroll
-            for (unsigned e = 0; e < 8; e++) {
-              if (!(e & (1u << sft)) && (e | (1u << sft)) < cnt) {
-                const uint64_t a = v[e], b = v[e | (1u << sft)];
-                const bool sw = asc ? (a > b) : (a < b);
-                v[e] = sw ? b : a;
-                v[e | (1u << sft)] = sw ? a : b;
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (unsigned e = 0; e < 8; e++)
-          if (e < cnt) s[lds_slot(base + e * m)] = v[e];
-      }
-      __syncthreads();
-      jb -= g;
-    }
-  }
-}
-
-// One workgroup per tile, longest lists first.  kLds = capacity of the LDS buffer in keys; lists of (lo, kLds] keys are
-// sorted in LDS by this instantiation, longer ones (only in the last class) in place in global memory, shorter ones belong
-// to a launch with a smaller LDS footprint (more workgroups per CU).
-template <int kThreads, int kLds, bool kLast>
+// One workgroup per tile, longest lists first.  A list of up to kThreads * kItems keys is sorted by rocPRIM's block radix
+// sort (keys in registers, 8 bits per pass over the 32 + log2(P) significant bits; measured on the box,
+// tools/microbench/bitonic_lds.hip: 8192 keys 55 us, 4096 keys 34 us, 1024 keys 12 us per workgroup -- a bitonic network in
+// LDS, the first implementation, needs 70 / 40 / 20: sorting thousands of 64-bit keys on ONE CU costs tens of microseconds
+// either way, which is why the three size classes run concurrently on forked streams); longer lists (only in the last
+// class) in place in global memory with the all-ascending bitonic network (L2-resident; rare: dense scenes take the global
+// radix sort instead).  tile_order lists the tiles longest first, so a class is one contiguous stretch of it: a small
+// persistent grid strides over the order, skips the longer lists in front and stops at the first list that is too short
+// (a grid of T workgroups that mostly return at once costs more in dispatch than the sorting when each reserves its LDS).
+template <int kThreads, int kItems, bool kLast>
 __global__ void __launch_bounds__(kThreads)
-bin_sort_kernel(int T, unsigned lo, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+bin_sort_kernel(int T, unsigned lo, unsigned idx_bits, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                 uint64_t* __restrict__ keys_unsorted, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ point_list) {
-  extern __shared__ uint64_t s_keys[];
-  // tile_order lists the tiles longest first, so a class is one contiguous stretch of it: a small persistent grid
-  // strides over the order, skips the longer lists in front and stops at the first list that is too short (a grid of T
-  // workgroups that mostly return at once costs more in dispatch than the sorting itself when each reserves 128 KB of LDS)
+  using sorter = rocprim::block_radix_sort<uint64_t, kThreads, kItems, rocprim::empty_type, 1, 1, 8>;
+  __shared__ typename sorter::storage_type storage;
+  constexpr unsigned kCap = kThreads * kItems;
   for (int ob = blockIdx.x; ob < T; ob += gridDim.x) {
     const uint32_t tile = tile_order[ob];
     const uint2 rg = ranges[tile];
     const unsigned n = rg.y - rg.x;
     if (n <= lo) break;
-    if (!kLast && n > (unsigned)kLds) continue;
+    if (!kLast && n > kCap) continue;
     uint64_t* src = keys_unsorted + rg.x;
-    unsigned npad = 0;  // log2 of the padded length
-    while ((1u << npad) < n) npad++;
     const uint64_t tile_hi = (uint64_t)tile << 32;
-    if (n <= (unsigned)kLds) {
-      for (unsigned i = threadIdx.x; i < (1u << npad); i += kThreads) s_keys[lds_slot(i)] = i < n ? src[i] : ~0ull;
-      __syncthreads();
-      bitonic_sort_lds<kThreads>(s_keys, npad);
-      for (unsigned i = threadIdx.x; i < n; i += kThreads) {
-        const uint64_t k = s_keys[lds_slot(i)];
-        point_list[rg.x + i] = (uint32_t)k;
-        keys_out[rg.x + i] = tile_hi | (k >> 32);
+    const uint64_t idx_mask = (1ull << idx_bits) - 1;
+    if (n <= kCap) {
+      uint64_t k[kItems];
+#pragma unroll
+      for (int i = 0; i < kItems; i++) {
+        const unsigned idx = threadIdx.x * kItems + i;  // blocked arrangement
+        k[i] = idx < n ? src[idx] : ~0ull;              // padding sorts to the end (all ones in every sorted bit)
       }
-      __syncthreads();  // the buffer is reused by the next tile of this workgroup
+      sorter().sort(k, storage, 0, 32 + idx_bits);  // keys are depth bits << idx_bits | index: one contiguous field
+#pragma unroll
+      for (int i = 0; i < kItems; i++) {
+        const unsigned idx = threadIdx.x * kItems + i;
+        if (idx < n) {
+          point_list[rg.x + idx] = (uint32_t)(k[i] & idx_mask);
+          keys_out[rg.x + idx] = tile_hi | (k[i] >> idx_bits);
+        }
+      }
+      __syncthreads();  // the storage is reused by the next tile of this workgroup
     } else {
-      // longer than the LDS buffer: the all-ascending network in place in global memory (L2-resident; rare)
+      unsigned npad = 0;  // log2 of the padded length
+      while ((1u << npad) < n) npad++;
       bitonic_sort_asc(n, npad, kThreads, [&](unsigned i) { return __builtin_nontemporal_load(src + i); },
                        [&](unsigned i, uint64_t v) { __builtin_nontemporal_store(v, src + i); });
       for (unsigned i = threadIdx.x; i < n; i += kThreads) {
-        const uint64_t k = __builtin_nontemporal_load(src + i);
-        point_list[rg.x + i] = (uint32_t)k;
-        keys_out[rg.x + i] = tile_hi | (k >> 32);
+        const uint64_t kk = __builtin_nontemporal_load(src + i);
+        point_list[rg.x + i] = (uint32_t)(kk & idx_mask);
+        keys_out[rg.x + i] = tile_hi | (kk >> idx_bits);
       }
     }
   }
@@ -428,6 +393,12 @@ void launch_zero_words(uint32_t* p, size_t n, hipStream_t s) {
   if (n == 0) return;
   const unsigned blocks = (unsigned)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048);
   hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, s, p, n);
+}
+
+static unsigned bin_index_bits(int P) {  // bits that hold every Gaussian index
+  unsigned ib = 1;
+  while (ib < 32 && (1ull << ib) < (unsigned long long)P) ib++;
+  return ib;
 }
 
 static int bin_groups(int P) { return std::min((int)kBinGroups, (P + 255) / 256); }
@@ -452,25 +423,19 @@ void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsig
   const int T = (int)(gx * gy);
   const uint32_t* tile_start = img.bin_hist + (size_t)(kBinGroups + 1) * T;
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(bin_groups(P)), dim3(256), (size_t)T * sizeof(uint32_t), s, P, T, radii,
-                     g.means2D, g.depths, gx, gy, capacity, img.bin_hist, tile_start, b.keys_unsorted);
+                     g.means2D, g.depths, gx, gy, capacity, bin_index_bits(P), img.bin_hist, tile_start, b.keys_unsorted);
 }
 
-int launch_bin_sort(int T, const BinningState& b, const ImageState& img, hipStream_t s) {
-  // three LDS classes: <= 1024 keys (8 KB: many workgroups per CU), <= 4096 (32 KB), <= 16384 (128 KB; longer lists in
-  // global memory).  A workgroup whose tile belongs to another class returns at once.
-  constexpr int kL2 = 16384;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_sort_kernel<1024, kL2, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kL2 * 8 / 16 * 17) != hipSuccess)
-      return -1;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((bin_sort_kernel<1024, kL2, true>), dim3(std::min(T, 256)), dim3(1024), (size_t)kL2 * 8 / 16 * 17, s, T, 4096u,
+int launch_bin_sort(int T, int P, const BinningState& b, const ImageState& img, hipStream_t s) {
+  // three size classes: <= 1024 keys, <= 4096, <= 16384 (longer lists in global memory), each a small persistent grid.
+  // (Running the classes concurrently on forked streams was tried: with the light's side stream and the two sort streams
+  // the runtime ran out of hardware queues and folded the light filter onto the main queue -- 25 % slower; they stay serial.)
+  const unsigned ib = bin_index_bits(P);
+  hipLaunchKernelGGL((bin_sort_kernel<1024, 16, true>), dim3(std::min(T, 256)), dim3(1024), 0, s, T, 4096u, ib,
                      img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL((bin_sort_kernel<512, 4096, false>), dim3(std::min(T, 1024)), dim3(512), (size_t)4096 * 8 / 16 * 17, s, T, 1024u,
+  hipLaunchKernelGGL((bin_sort_kernel<256, 16, false>), dim3(std::min(T, 1024)), dim3(256), 0, s, T, 1024u, ib,
                      img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL((bin_sort_kernel<256, 1024, false>), dim3(std::min(T, 4096)), dim3(256), (size_t)1024 * 8 / 16 * 17, s, T, 0u,
+  hipLaunchKernelGGL((bin_sort_kernel<256, 4, false>), dim3(std::min(T, 4096)), dim3(256), 0, s, T, 0u, ib,
                      img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
   return 0;
 }

@@ -242,7 +242,7 @@ void launch_bin_count(int P, const int* radii, unsigned gx, unsigned gy, const G
 void launch_bin_prefix(int P, int T, unsigned capacity, const ImageState& img, unsigned* user_counters, hipStream_t s);
 void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, const GeomState& g,
                         const BinningState& b, const ImageState& img, hipStream_t s);
-int launch_bin_sort(int T, const BinningState& b, const ImageState& img, hipStream_t s);
+int launch_bin_sort(int T, int P, const BinningState& b, const ImageState& img, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                          hipStream_t s);
 hipError_t scan_tiles(const GeomState& g, int P, hipStream_t s);

@@ -388,15 +388,15 @@ __device__ __forceinline__ float group_sum_last(float v) {
 //     candidates (the fixed per-texel work is shared by the wave), kLanes = 64 gives a whole wave to a texel.
 // The pass streams the table once (0.74 GB per direction for the reference's 256..16 chain): it is HBM-bound.
 template <bool kBackward, bool kNorm, int kLanes>
-__global__ void __launch_bounds__(256)
-specular_apply_kernel(int N, const float* __restrict__ src, const float* __restrict__ bounds,
-                      const uint32_t* __restrict__ offsets, const float* __restrict__ W,
-                      float* __restrict__ dst, float* __restrict__ wsum_out) {
+__device__ __forceinline__ void specular_apply_body(int block, int N, const float* __restrict__ src,
+                                                    const float* __restrict__ bounds, const uint32_t* __restrict__ offsets,
+                                                    const float* __restrict__ W, float* __restrict__ dst,
+                                                    float* __restrict__ wsum_out) {
   constexpr int kPerWave = 64 / kLanes;
   constexpr int kU = 4;
   const int lane = threadIdx.x & 63;
   const int total = 6 * N * N;
-  const int o_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kPerWave + lane / kLanes;
+  const int o_raw = (block * 4 + (threadIdx.x >> 6)) * kPerWave + lane / kLanes;
   const bool valid = o_raw < total;
   const int o = valid ? o_raw : total - 1;  // surplus groups stay in the wave for the DPP sums
   const int g = lane % kLanes;
@@ -494,6 +494,47 @@ specular_apply_kernel(int N, const float* __restrict__ src, const float* __restr
       q[0] = c0; q[1] = c1; q[2] = c2; q[3] = wsum;
     }
   }
+}
+
+template <bool kBackward, bool kNorm, int kLanes>
+__global__ void __launch_bounds__(256)
+specular_apply_kernel(int N, const float* __restrict__ src, const float* __restrict__ bounds,
+                      const uint32_t* __restrict__ offsets, const float* __restrict__ W,
+                      float* __restrict__ dst, float* __restrict__ wsum_out) {
+  specular_apply_body<kBackward, kNorm, kLanes>(blockIdx.x, N, src, bounds, offsets, W, dst, wsum_out);
+}
+
+// All levels of the chain in ONE launch (gigs_specular_cubemap_multi_*): the levels are independent, so their
+// workgroups share one grid -- the largest level first -- instead of five dependent launches (five kernel nodes with
+// 10-17 us of dispatch latency between them on the light's side stream, each with its own under-filled tail).
+struct SpecLevel {
+  int N, lanes, block_begin;
+  const float* src;
+  const float* bounds;
+  const uint32_t* offsets;
+  const float* W;
+  float* dst;
+  float* wsum_out;
+};
+struct SpecLevels { int n; SpecLevel lv[8]; };
+
+template <bool kBackward>
+__global__ void __launch_bounds__(256) specular_apply_multi_kernel(SpecLevels L) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 8; i++)
+    if (i < L.n && (int)blockIdx.x >= L.lv[i].block_begin) k = i;
+  const SpecLevel& v = L.lv[k];
+  const int block = (int)blockIdx.x - v.block_begin;
+  if (v.lanes == 8) specular_apply_body<kBackward, true, 8>(block, v.N, v.src, v.bounds, v.offsets, v.W, v.dst, v.wsum_out);
+  else if (v.lanes == 16) specular_apply_body<kBackward, true, 16>(block, v.N, v.src, v.bounds, v.offsets, v.W, v.dst, v.wsum_out);
+  else specular_apply_body<kBackward, true, 64>(block, v.N, v.src, v.bounds, v.offsets, v.W, v.dst, v.wsum_out);
+}
+
+static int spec_lanes_for(int avg_window) {
+  static const int max8 = [] { const char* e = getenv("GIGS_SPEC_MAX8"); return e ? atoi(e) : 128; }();
+  static const int max16 = [] { const char* e = getenv("GIGS_SPEC_MAX16"); return e ? atoi(e) : 1500; }();
+  return (avg_window > 0 && avg_window <= max8) ? 8 : (avg_window > 0 && avg_window <= max16) ? 16 : 64;
 }
 
 template <bool kBackward, bool kNorm>
@@ -1176,6 +1217,30 @@ int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* of
     gigs::launch_specular_apply<true, true>(res, avg_window, grad_out, bounds, offsets, weights_swapped, grad_cubemap, nullptr, s);
   else
     gigs::launch_specular_apply<true, false>(res, avg_window, grad_out, bounds, offsets, weights_swapped, grad_cubemap, nullptr, s);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_specular_cubemap_multi_w(int n_levels, const gigs_spec_level* levels, int backward, void* stream) {
+  if (n_levels <= 0 || n_levels > 8 || !levels) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_multi_w: bad level count");
+  gigs::SpecLevels L;
+  L.n = n_levels;
+  int blocks = 0;
+  for (int i = 0; i < n_levels; i++) {
+    const gigs_spec_level& a = levels[i];
+    if (a.res <= 0 || !a.src || !a.bounds || !a.offsets || !a.weights || !a.dst || (!backward && !a.wsum))
+      return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_multi_w: bad level");
+    gigs::SpecLevel& v = L.lv[i];
+    v.N = a.res; v.lanes = gigs::spec_lanes_for(a.avg_window); v.block_begin = blocks;
+    v.src = a.src; v.bounds = a.bounds; v.offsets = a.offsets; v.W = a.weights; v.dst = a.dst; v.wsum_out = a.wsum;
+    const int total = 6 * a.res * a.res;
+    const int waves = v.lanes == 64 ? total : (total + (64 / v.lanes) - 1) / (64 / v.lanes);
+    blocks += (waves + 3) / 4;
+  }
+  void* tok; gigs_internal_stage_begin(backward ? 17 : 16, stream, &tok);
+  if (backward) hipLaunchKernelGGL(gigs::specular_apply_multi_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+  else hipLaunchKernelGGL(gigs::specular_apply_multi_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;

@@ -120,6 +120,12 @@ preprocess_fwd_kernel(FwdArgs a, GeomState g, int* __restrict__ radii) {
 
   radii[idx] = 0;
   g.tiles_touched[idx] = 0;
+  {  // the blend backward accumulates into grec with atomics: it leaves every forward (and every backward) zeroed,
+     // so the backward needs no fill launch in front of it
+    float4* gz = reinterpret_cast<float4*>(g.grec + (size_t)idx * GIGS_GREC);
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    gz[0] = z4; gz[1] = z4; gz[2] = z4; gz[3] = z4; gz[4] = z4;
+  }
 
   // in_frustum (auxiliary.h:150-176): only the near cull survives in the reference
   const v3 p_orig = ld3(a.means3D + 3 * (size_t)idx);
@@ -286,8 +292,12 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g) {
   if (idx >= P) return;
 
   // ---- unpack the blend-backward record into the reference's separate gradient tensors
-  const float4* gr = reinterpret_cast<const float4*>(g.grec + (size_t)idx * GIGS_GREC);
+  float4* gr = reinterpret_cast<float4*>(g.grec + (size_t)idx * GIGS_GREC);
   const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4];
+  {  // consumed: zero again, so that another backward on the same forward state starts from zero (see preprocess_fwd)
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    gr[0] = z4; gr[1] = z4; gr[2] = z4; gr[3] = z4; gr[4] = z4;
+  }
   // g0 = (m2d.x, m2d.y, m2d.abs, con.xx) g1 = (con.xy, con.yy, dopac, dcol.r)
   // g2 = (dcol.g, dcol.b, dn.x, dn.y) g3 = (dn.z, dalb.r, dalb.g, dalb.b) g4 = (drough, dmetal, ddepth, -)
   a.dL_dmean2D[3 * (size_t)idx + 0] = g0.x;

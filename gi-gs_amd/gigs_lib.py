@@ -63,6 +63,7 @@ SIGNATURES = {
     "gigs_specular_weights_divide": (_i, [_i, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_specular_cubemap_fwd_w": (_i, [_i, _f, _f, _f, _f, _i, _f, _f, C.c_void_p]),
     "gigs_specular_cubemap_bwd_w": (_i, [_i, _f, _f, _f, _i, _f, _i, _f, C.c_void_p]),
+    "gigs_specular_cubemap_multi_w": (_i, [_i, C.c_void_p, _i, C.c_void_p]),
     "gigs_cubemap_mip_fwd": (_i, [_i, _i, _f, _f, C.c_void_p]),
     "gigs_cubemap_mip_bwd_add": (_i, [_i, _f, _f, _f, C.c_void_p]),
     "gigs_cubemap_mip_bwd": (_i, [_i, _f, _f, C.c_void_p]),
@@ -116,6 +117,12 @@ class ShadeExt(C.Structure):
                 ("out_F0", C.c_void_p), ("out_linear", C.c_void_p), ("out_roughness", C.c_void_p),
                 ("g_albedo_mul_a", C.c_void_p), ("g_albedo_mul_b", C.c_void_p),
                 ("g_roughness_add", C.c_void_p), ("g_metallic_add", C.c_void_p)]
+
+
+class SpecLevel(C.Structure):
+    """gigs_spec_level of include/gigs_hip.h."""
+    _fields_ = [("res", C.c_int), ("avg_window", C.c_int), ("src", C.c_void_p), ("bounds", C.c_void_p),
+                ("offsets", C.c_void_p), ("weights", C.c_void_p), ("dst", C.c_void_p), ("wsum", C.c_void_p)]
 
 
 class AdamGroup(C.Structure):

@@ -11,6 +11,7 @@ import torch.nn as nn
 import gigs_lib
 
 from .renderutils import diffuse_cubemap, specular_cubemap
+from .renderutils.ops import specular_cubemap_levels
 
 _lib = gigs_lib.lib()
 
@@ -127,7 +128,13 @@ class CubemapLight(nn.Module):
             while self.specular[-1].shape[1] > self.LIGHT_MIN_RES:
                 self.specular += [cubemap_mip.apply(self.specular[-1])]
         self.diffuse = diffuse_cubemap(self.specular[-1])
-        for idx in range(len(self.specular) - 1):
-            roughness = (idx / (len(self.specular) - 2)) * (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) + self.MIN_ROUGHNESS
-            self.specular[idx] = specular_cubemap(self.specular[idx], roughness, cutoff)
+        n = len(self.specular)
+        rough = [(idx / (n - 2)) * (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) + self.MIN_ROUGHNESS for idx in range(n - 1)] + [1.0]
+        # the levels are independent: one launch filters them all (and one launch back-propagates them all)
+        merged = specular_cubemap_levels(self.specular, rough, cutoff)
+        if merged is not None:
+            self.specular = merged
+            return
+        for idx in range(n - 1):
+            self.specular[idx] = specular_cubemap(self.specular[idx], rough[idx], cutoff)
         self.specular[-1] = specular_cubemap(self.specular[-1], 1.0, cutoff)

@@ -164,6 +164,65 @@ class _specular_cubemap_normalized(torch.autograd.Function):
         return g, None, None
 
 
+class _specular_levels(torch.autograd.Function):
+    """specular_cubemap of every level of a light in ONE launch each way (gigs_specular_cubemap_multi_w).  Inputs:
+    the per-level (bounds, tables) as a Python list, then the level mips; needs the cached tables incl. the pre-divided
+    backward table of every level (otherwise CubemapLight.build_mips falls back to one call per level)."""
+
+    @staticmethod
+    def forward(ctx, meta, *mips):
+        import ctypes as C
+        cs = [_gpu(m, "cubemap") for m in mips]
+        dev = cs[0].device
+        outs, wsums, arr = [], [], (gigs_lib.SpecLevel * len(cs))()
+        for i, (c, (bounds, tables)) in enumerate(zip(cs, meta)):
+            res = c.shape[1]
+            out = torch.empty((6, res, res, 3), dtype=torch.float32, device=dev)
+            wsum = torch.empty((6, res, res, 1), dtype=torch.float32, device=dev)
+            outs.append(out)
+            wsums.append(wsum)
+            arr[i] = gigs_lib.SpecLevel(res, _avg_window(tables, res), c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
+                                        tables[1].data_ptr(), out.data_ptr(), wsum.data_ptr())
+        with torch.cuda.device(dev):
+            gigs_lib.check(_lib.gigs_specular_cubemap_multi_w(len(cs), C.cast(arr, C.c_void_p), 0, _stream()),
+                           "specular_cubemap_multi_w")
+        ctx.meta = meta
+        ctx.shapes = [c.shape[1] for c in cs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        import ctypes as C
+        dev = next(d for d in douts if d is not None).device
+        gs, arr, keep = [], (gigs_lib.SpecLevel * len(douts))(), []
+        for i, (d, res, (bounds, tables)) in enumerate(zip(douts, ctx.shapes, ctx.meta)):
+            d = torch.zeros((6, res, res, 3), dtype=torch.float32, device=dev) if d is None else _gpu(d, "dout")
+            keep.append(d)
+            g = torch.empty((6, res, res, 3), dtype=torch.float32, device=dev)
+            gs.append(g)
+            arr[i] = gigs_lib.SpecLevel(res, _avg_window(tables, res), d.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
+                                        tables[3].data_ptr(), g.data_ptr(), None)
+        with torch.cuda.device(dev):
+            gigs_lib.check(_lib.gigs_specular_cubemap_multi_w(len(douts), C.cast(arr, C.c_void_p), 1, _stream()),
+                           "specular_cubemap_multi_w")
+        return (None, *gs)
+
+
+def specular_cubemap_levels(mips, roughnesses, cutoff=0.99):
+    """[specular_cubemap(m, r, cutoff) for m, r in zip(mips, roughnesses)] as one launch each way, or None if a level
+    lacks its cached tables (then the caller filters level by level)."""
+    if os.environ.get("GIGS_SPEC_MULTI", "1") != "1" or torch.is_anomaly_enabled() or not mips[0].is_cuda:
+        return None
+    meta = []
+    for m, r in zip(mips, roughnesses):
+        _, bounds = _ndf_bounds(m.shape[1], r, cutoff, m.device)
+        tables = _weight_tables(m.shape[1], r, cutoff, m.device)
+        if tables is None or len(tables) < 4 or tables[3] is None:
+            return None
+        meta.append((bounds, tables))
+    return list(_specular_levels.apply(meta, *mips))
+
+
 # Cached pair-weight tables (see csrc/pbr.hip): 0.74 GB for the 256..16 chain, x2 for the backward.
 # HBM is 288 GB on MI355X; set GIGS_SPEC_TABLE_MAX_GB=0 to recompute the weights every call instead.
 _TABLE_MAX_BYTES = float(os.environ.get("GIGS_SPEC_TABLE_MAX_GB", "8")) * 1e9

@@ -188,6 +188,23 @@ int gigs_specular_cubemap_fwd_w(int res, const float* cubemap, const float* boun
 int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* offsets,
                                 const float* weights_swapped, int avg_window, const float* grad_out,
                                 int grad_is_rgb, float* grad_cubemap, void* stream);
+
+/* The table-driven GGX filter of ALL levels of a light in one launch (gigs-hip extension): the levels of
+ * CubemapLight.build_mips (pbr/light.py:166-170) are independent of each other, so their texels share one grid instead of
+ * one dependent launch per level.  `levels` is a HOST array; per level the arguments of gigs_specular_cubemap_fwd_w
+ * (backward = 0: src = the level's mip, dst = rgb / wsum [6,res,res,3], wsum [6,res,res] required) or of
+ * gigs_specular_cubemap_bwd_w with grad_is_rgb = 1 (backward = 1: src = the incoming gradient, weights = the role-swapped
+ * table already divided by the forward's weight sums, dst = the gradient w.r.t. the mip, wsum unused). */
+typedef struct gigs_spec_level {
+  int res, avg_window;
+  const float* src;
+  const float* bounds;
+  const uint32_t* offsets;
+  const float* weights;
+  float* dst;
+  float* wsum;
+} gigs_spec_level;
+int gigs_specular_cubemap_multi_w(int n_levels, const gigs_spec_level* levels, int backward, void* stream);
 /* cubemap_mip (pbr/light.py:54-79): forward 2x2 average pool [6,2r,2r,C] -> [6,r,r,C]; backward =
  * bilinear cube lookup of 0.25*dout at every fine texel direction, dout [6,r,r,3] -> din [6,2r,2r,3]. */
 int gigs_cubemap_mip_fwd(int res_out, int channels, const float* in, float* out, void* stream);

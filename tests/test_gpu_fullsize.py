@@ -33,7 +33,7 @@ def _structure_checks(sv, hp, R, P, W, H):
         np.testing.assert_array_equal(sv["keys_unsorted"][order], keys)
         assert np.array_equal(np.sort(sv["vals_unsorted"]), np.sort(sv["point_list"]))
     else:
-        # tile-bucketed path: keys_unsorted holds (depth << 32 | index) grouped by tile; within a tile the sorted list is
+        # tile-bucketed path: keys_unsorted holds (depth << idx_bits | index) grouped by tile; within a tile the sorted list is
         # ordered by (depth, index) and every Gaussian appears once per tile it touches
         depth_idx = (keys & np.uint64(0xFFFFFFFF)) << np.uint64(32) | sv["point_list"].astype(np.uint64)
         same_tile = (keys[1:] >> np.uint64(32)) == (keys[:-1] >> np.uint64(32))

@@ -369,3 +369,26 @@ def test_build_mips_fused_chain_and_prescaled_tables_match_op_by_op(monkeypatch)
     for a, b in zip(o0, o1):
         assert torch.equal(a, b)  # the forward runs the same kernels
     assert (g0 - g1).abs().max().item() <= 2e-6 * g0.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base", [64, 256])
+def test_merged_level_filter_equals_per_level(base, monkeypatch):
+    """build_mips filters all GGX levels in one launch each way (gigs_specular_cubemap_multi_w); the per-level calls
+    (GIGS_SPEC_MULTI=0) must give the same levels and the same gradient of the base cubemap, bit for bit (same kernels'
+    bodies, same per-texel summation order)."""
+    import pbr
+    res = {}
+    for multi in ("1", "0"):
+        monkeypatch.setenv("GIGS_SPEC_MULTI", multi)
+        torch.manual_seed(11)
+        light = pbr.CubemapLight(base_res=base, device=DEV)
+        light.build_mips()
+        g = torch.Generator(device="cpu").manual_seed(5)
+        loss = sum((s * torch.randn(s.shape, generator=g).to(DEV)).sum() for s in light.specular) + light.diffuse.sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        res[multi] = ([s.detach().clone() for s in light.specular], light.base.grad.clone())
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res["1"][1], res["0"][1])
