@@ -455,6 +455,9 @@ def main():
                                       gi["delta"]),
                        "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade, "hip_graphs": args.graphs, "fused_glue": args.fused,
                        "gi_march": os.environ.get("GIGS_GI_MARCH", "proj (default)"),
+                       "rasterizer": ("one hipGraph per view" if inference and args.graphs == "on" else
+                                      "hipGraph (GIGS_RASTER_GRAPH=1)" if os.environ.get("GIGS_RASTER_GRAPH", "0") == "1"
+                                      else "eager launches, asynchronous binning (no host read-back)"),
                        "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

@@ -271,7 +271,11 @@ class GraphedRaster:
         self.bin = AsyncBinning(self.capacity, self.dev)
         H, W, tx, ty = self.cfg
         mod = RasterFront(H, W, tx, ty, self.gi, self.sh_degree, self.inference)
-        sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in self._args(cam, g, means2D, bg))
+        # static inputs: the Gaussian tensors and means2D THEMSELVES (aliases: a replay then finds its inputs in place and
+        # copies nothing -- 40 MB and ten launches per step otherwise); the small per-view camera tensors are copied in
+        args = self._args(cam, g, means2D, bg)
+        sample = tuple((a.detach() if i == 0 or i >= 5 else a.detach().clone()).requires_grad_(a.requires_grad)
+                       for i, a in enumerate(args))
         with self.bin:
             if self.inference or not any(a.requires_grad for a in sample):
                 self.fn = _graphed_inference(mod, sample)
@@ -422,7 +426,7 @@ class Stage2Step:
         """extra_loss(normal_map, albedo_map, roughness_map, metallic_map) -> scalar added to the loss before
         backward (the BRDF / envmap regularisers of train.py:387-420; see gi-gs_amd/losses.py)."""
         dev = g["means3D"].device
-        if self.fused and self.graphs and os.environ.get("GIGS_RASTER_GRAPH", "1") == "1" and not getattr(self, "_dense", False):
+        if self.fused and self.graphs and os.environ.get("GIGS_RASTER_GRAPH", "0") == "1" and not getattr(self, "_dense", False):
             try:
                 return self._graphed_step(cam, g, gt_image, view_dirs, extra_loss)
             except DenseScene:
@@ -439,13 +443,20 @@ class Stage2Step:
             self._set_blend_event(self.blend_begin.cuda_event)  # only for this forward: cleared again below
         lights = []
         hook = after_blend((lambda: lights.extend(self._fused_begin())) if self.fused else None)
+        # eager rasterizer without the host read-back: asynchronous binning into a fixed-capacity buffer (sized from one
+        # synchronous probe), the overflow flag checked after the backward has been queued (GIGS_RASTER_ASYNC=0: read back)
+        abin = None
+        if self.fused and self.graphs and os.environ.get("GIGS_RASTER_ASYNC", "1") == "1" and not getattr(self, "_dense", False):
+            abin = self._eager_async(cam, g, background)
         try:
-            with hook:
+            with hook, (abin if abin is not None else _NULLCTX):
                 if self.pool is not None:
                     with self.pool:
                         out = rasterize(cam, g, self.sh_degree, background, self.gi)
                 else:
                     out = rasterize(cam, g, self.sh_degree, background, self.gi)
+            if abin is not None:
+                abin.snapshot()
         finally:
             if self.fused:
                 self._set_blend_event(None)
@@ -454,9 +465,18 @@ class Stage2Step:
         H, W = cam["image_height"], cam["image_width"]
         gi = self.gi
         if self.fused:
-            return self._fused_step(cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view,
-                                    albedo_map, roughness_map, metallic_map, occlusion_map, depth_pos, lights,
-                                    extra_loss)
+            res = self._fused_step(cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view,
+                                   albedo_map, roughness_map, metallic_map, occlusion_map, depth_pos, lights,
+                                   extra_loss)
+            if abin is not None:
+                try:
+                    res["num_rendered"] = abin.check()
+                except BinningOverflow as ex:
+                    self._abin = AsyncBinning(-(-int(1.5 * ex.needed) // 65536) * 65536, dev)
+                    for t in list(g.values()) + list(self.light.parameters()):
+                        t.grad = None
+                    return self.__call__(cam, g, gt_image, view_dirs, extra_loss)
+            return res
         front_args = (normal_map_from_depth, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
                       occlusion_map.detach(), st.viewmatrix, view_dirs)
         if self.graphs and not self._captured:
@@ -478,6 +498,28 @@ class Stage2Step:
                     IRR=IRR.detach(), viewspace_points=screenspace_points, radii=radii)
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULLCTX = _NullCtx()
+
+
+def _eager_async(self, cam, g, background):
+    if getattr(self, "_abin", None) is None:
+        probe = GraphedRaster(cam, g, self.gi, self.sh_degree)._probe(cam, g, background)
+        tiles = ((int(cam["image_height"]) + 15) // 16) * ((int(cam["image_width"]) + 15) // 16)
+        if probe > BUCKET_MAX_MEAN_LIST * tiles:
+            self._dense = True
+            return None
+        self._abin = AsyncBinning(max(65536, -(-2 * probe // 65536) * 65536), g["means3D"].device)
+    return self._abin
+
+
 def _graphed_step(self, cam, g, gt_image, view_dirs, extra_loss=None):
     """fused + graphs: the WHOLE step replays from hipGraphs -- the rasterizer with its in-op filters and SSAO too
     (GraphedRaster: asynchronous binning, no host read-back), the light filter on the side stream from the start of the
@@ -494,12 +536,20 @@ def _graphed_step(self, cam, g, gt_image, view_dirs, extra_loss=None):
         lights = list(self._fused_begin(self.step_begin))
         if self.graster is None:
             self.graster = GraphedRaster(cam, g, self.gi, self.sh_degree)
-        screenspace_points = torch.zeros_like(g["means3D"], requires_grad=True)
+        if getattr(self, "_m2d", None) is None or self._m2d.shape != g["means3D"].shape:
+            self._m2d = torch.zeros_like(g["means3D"], requires_grad=True)  # persistent: the graph's static input
+        screenspace_points = self._m2d
+        screenspace_points.grad = None
         out = self.graster(cam, g, screenspace_points, self._bg)
+        self._static_storages = set(t.untyped_storage().data_ptr() for t in out)
         (_, radii, _, _, _, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map, out_normal_view, depth_pos) = out
         res = self._fused_step(cam, gt_image, view_dirs, SimpleNamespace(viewmatrix=cam["viewmatrix"]), radii,
                                screenspace_points, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
                                occlusion_map, depth_pos, lights, extra_loss)
+        if os.environ.get("GIGS_ASYNC_CHECK", "step") == "lazy":
+            # diagnostic: do not wait for this step's forward here; an overflow of step k is then only noticed at step k + 1
+            res["num_rendered"] = -1
+            return res
         try:
             res["num_rendered"] = self.graster.check()
             return res
@@ -561,6 +611,7 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
         if self.graphs:
             # pooled rasterizer planes (fixed addresses) become the graph's static inputs themselves: no staging copies
             pooled = set(t.untyped_storage().data_ptr() for t in self.pool.buffers.values()) if self.pool else set()
+            pooled |= getattr(self, "_static_storages", set())  # outputs of the graphed rasterizer: fixed addresses too
             sample = tuple(a.detach().requires_grad_(a.requires_grad) if a.untyped_storage().data_ptr() in pooled
                            else a.detach().clone().requires_grad_(a.requires_grad) for a in args)
             self.back = graphed(self.back, sample)
@@ -572,6 +623,7 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
                 viewspace_points=screenspace_points, radii=radii)
 
 
+Stage2Step._eager_async = _eager_async
 Stage2Step._graphed_step = _graphed_step
 Stage2Step._fused_begin = _fused_begin
 Stage2Step._fused_step = _fused_step

@@ -244,12 +244,15 @@ def test_stage2_fused_matches_unfused(orc, metallic):
     rays = pipeline.canonical_rays(cams[0], DEV)
     vds = [pipeline.view_dirs_for(c, rays, DEV) for c in camts]
     results = {}
-    for mode in ("unfused", "fused", "fused_graph"):
+    for mode in ("unfused", "fused", "fused_graph", "fused_graph_raster"):
         torch.manual_seed(2)
         light = pbr.CubemapLight(base_res=64, device=DEV)
         g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        # fused_graph: glue replayed from hipGraphs, rasterizer launched eagerly with asynchronous binning (the default);
+        # fused_graph_raster: the rasterizer captured too (GIGS_RASTER_GRAPH=1)
+        os.environ["GIGS_RASTER_GRAPH"] = "1" if mode == "fused_graph_raster" else "0"
         step = pipeline.Stage2Step(light, lut, gi, 2, metallic=metallic, fused=mode != "unfused",
-                                   graphs=mode == "fused_graph")
+                                   graphs=mode.startswith("fused_graph"))
         outs = []
         for ci in (0, 1, 0):
             for t in list(g.values()) + [light.base]:
@@ -259,7 +262,8 @@ def test_stage2_fused_matches_unfused(orc, metallic):
             outs.append((float(o["loss"]), {k: g[k].grad.clone() for k in ("albedo", "roughness", "metallic")},
                          light.base.grad.clone(), o["render_rgb"].clone(), o["IRR"].clone()))
         results[mode] = outs
-    for mode in ("fused", "fused_graph"):
+    os.environ.pop("GIGS_RASTER_GRAPH", None)
+    for mode in ("fused", "fused_graph", "fused_graph_raster"):
         for (lu, gu, bu, ru, iu), (lf, gf, bf, rf, irf) in zip(results["unfused"], results[mode]):
             assert abs(lu - lf) <= 2e-6 * max(1.0, abs(lu)), (mode, lu, lf)
             torch.testing.assert_close(irf, iu, rtol=0, atol=2e-6)
@@ -272,12 +276,15 @@ def test_stage2_fused_matches_unfused(orc, metallic):
     assert abs(results["fused_graph"][0][0] - results["fused_graph"][1][0]) > 1e-6
 
 
-def test_graphed_step_survives_a_binning_overflow():
+@pytest.mark.parametrize("raster", ["graph", "eager_async"])
+def test_graphed_step_survives_a_binning_overflow(raster, monkeypatch):
     """The whole-step hipGraph bins into a fixed-capacity buffer; a view with more instances than the capacity raises
     the device-side overflow flag, the capacity grows, the graph is re-captured and the step repeated: same loss,
     image and gradients as the eager step."""
     import pbr
     import pipeline
+    from diff_gaussian_rasterization import AsyncBinning
+    monkeypatch.setenv("GIGS_RASTER_GRAPH", "1" if raster == "graph" else "0")
     sc = scenes.surface_scene(P=20_000, sh_degree=2, seed=4, scale_mu=0.03)
     gi = scenes.GI_DEFAULTS
     H, W = 160, 208
@@ -293,12 +300,17 @@ def test_graphed_step_survives_a_binning_overflow():
         light = pbr.CubemapLight(base_res=64, device=DEV)
         g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
         step = pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=(mode == "graph"))
-        if mode == "graph":
+        if mode == "graph" and raster == "graph":
             step.graster = pipeline.GraphedRaster(camt, g, gi, 2, capacity=65536)  # far below this view's instance count
+        elif mode == "graph":
+            step._abin = AsyncBinning(65536, DEV)  # the eager rasterizer's asynchronous binning, same protocol
         o = step(camt, g, gt, vd)
         torch.cuda.synchronize()
-        if mode == "graph":
+        if mode == "graph" and raster == "graph":
             assert step.graster.recaptures == 2 and step.graster.capacity > 65536
+        elif mode == "graph":
+            assert step._abin.capacity > 65536
+        if mode == "graph":
             assert o["num_rendered"] > 65536
         res[mode] = (float(o["loss"]), o["render_rgb"].clone(), {k: g[k].grad.clone() for k in ("albedo", "roughness", "metallic")},
                      light.base.grad.clone())
