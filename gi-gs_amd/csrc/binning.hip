@@ -335,49 +335,80 @@ __device__ __forceinline__ void bitonic_sort_asc(unsigned n, unsigned npad_log2,
 // radix sort instead).  tile_order lists the tiles longest first, so a class is one contiguous stretch of it: a small
 // persistent grid strides over the order, skips the longer lists in front and stops at the first list that is too short
 // (a grid of T workgroups that mostly return at once costs more in dispatch than the sorting when each reserves its LDS).
-template <int kThreads, int kItems, bool kLast>
-__global__ void __launch_bounds__(kThreads)
-bin_sort_kernel(int T, unsigned lo, unsigned idx_bits, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+// one tile of up to 1024 * kItems keys: rocPRIM block radix sort, keys in registers (blocked arrangement)
+template <int kItems, typename Storage>
+__device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t* __restrict__ src, unsigned n, unsigned idx_bits,
+                                                uint64_t tile_hi, uint32_t base, uint64_t* __restrict__ keys_out,
+                                                uint32_t* __restrict__ point_list) {
+  using sorter = rocprim::block_radix_sort<uint64_t, 1024, kItems, rocprim::empty_type, 1, 1, 8>;
+  const uint64_t idx_mask = (1ull << idx_bits) - 1;
+  uint64_t k[kItems];
+#pragma unroll
+  for (int i = 0; i < kItems; i++) {
+    const unsigned idx = threadIdx.x * kItems + i;
+    k[i] = idx < n ? src[idx] : ~0ull;  // padding sorts to the end (all ones in every sorted bit)
+  }
+  sorter().sort(k, storage, 0, 32 + idx_bits);  // keys are depth bits << idx_bits | index: one contiguous field
+#pragma unroll
+  for (int i = 0; i < kItems; i++) {
+    const unsigned idx = threadIdx.x * kItems + i;
+    if (idx < n) {
+      point_list[base + idx] = (uint32_t)(k[i] & idx_mask);
+      keys_out[base + idx] = tile_hi | (k[i] >> idx_bits);
+    }
+  }
+  __syncthreads();  // the storage is reused by the next tile of this workgroup
+}
+
+// One workgroup (1024 lanes) per tile, longest lists first (tile_order), on a small persistent grid.  A list is sorted by
+// rocPRIM's block radix sort with 1, 4, 8 (kernel A: 64 KB of LDS, two workgroups per CU) or 16 (kernel B: 132 KB) keys per
+// lane -- measured on the box, tools/microbench/bitonic_lds.hip: 8192 keys 55 us, 4096 keys 34 us, 1024 keys 12 us per
+// workgroup; a bitonic network in LDS, the first implementation, needs 70 / 40 / 20: sorting thousands of 64-bit keys on ONE
+// CU costs tens of microseconds either way, so what matters is that long and short lists are in flight together (one launch
+// per size class, the first layout, ran them one after the other: 190 us at C2).  Lists beyond 16384 keys are sorted in
+// place in global memory with the all-ascending bitonic network (L2-resident; rare: dense scenes take the global radix sort).
+using SortS1 = rocprim::block_radix_sort<uint64_t, 1024, 1, rocprim::empty_type, 1, 1, 8>::storage_type;
+using SortS4 = rocprim::block_radix_sort<uint64_t, 1024, 4, rocprim::empty_type, 1, 1, 8>::storage_type;
+using SortS8 = rocprim::block_radix_sort<uint64_t, 1024, 8, rocprim::empty_type, 1, 1, 8>::storage_type;
+using SortS16 = rocprim::block_radix_sort<uint64_t, 1024, 16, rocprim::empty_type, 1, 1, 8>::storage_type;
+
+template <bool kBig>
+__global__ void __launch_bounds__(1024)
+bin_sort_kernel(int T, unsigned idx_bits, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                 uint64_t* __restrict__ keys_unsorted, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ point_list) {
-  using sorter = rocprim::block_radix_sort<uint64_t, kThreads, kItems, rocprim::empty_type, 1, 1, 8>;
-  __shared__ typename sorter::storage_type storage;
-  constexpr unsigned kCap = kThreads * kItems;
+  __shared__ union SortStorage {
+    SortS1 s1; SortS4 s4; SortS8 s8;
+    char big[kBig ? sizeof(SortS16) : 8];
+    __device__ SortStorage() {}
+  } storage;
+  constexpr unsigned kSplit = 8192;  // kernel A: lists of 1 .. kSplit keys; kernel B: longer ones
   for (int ob = blockIdx.x; ob < T; ob += gridDim.x) {
     const uint32_t tile = tile_order[ob];
     const uint2 rg = ranges[tile];
     const unsigned n = rg.y - rg.x;
-    if (n <= lo) break;
-    if (!kLast && n > kCap) continue;
+    if (kBig ? n <= kSplit : n == 0) break;  // tile_order is descending: nothing further for this kernel
+    if (!kBig && n > kSplit) continue;
     uint64_t* src = keys_unsorted + rg.x;
     const uint64_t tile_hi = (uint64_t)tile << 32;
-    const uint64_t idx_mask = (1ull << idx_bits) - 1;
-    if (n <= kCap) {
-      uint64_t k[kItems];
-#pragma unroll
-      for (int i = 0; i < kItems; i++) {
-        const unsigned idx = threadIdx.x * kItems + i;  // blocked arrangement
-        k[i] = idx < n ? src[idx] : ~0ull;              // padding sorts to the end (all ones in every sorted bit)
-      }
-      sorter().sort(k, storage, 0, 32 + idx_bits);  // keys are depth bits << idx_bits | index: one contiguous field
-#pragma unroll
-      for (int i = 0; i < kItems; i++) {
-        const unsigned idx = threadIdx.x * kItems + i;
-        if (idx < n) {
-          point_list[rg.x + idx] = (uint32_t)(k[i] & idx_mask);
-          keys_out[rg.x + idx] = tile_hi | (k[i] >> idx_bits);
+    if constexpr (kBig) {
+      if (n <= 16384) {
+        sort_tile_radix<16>(*reinterpret_cast<SortS16*>(storage.big), src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
+      } else {
+        const uint64_t idx_mask = (1ull << idx_bits) - 1;
+        unsigned npad = 0;  // log2 of the padded length
+        while ((1u << npad) < n) npad++;
+        bitonic_sort_asc(n, npad, 1024u, [&](unsigned i) { return __builtin_nontemporal_load(src + i); },
+                         [&](unsigned i, uint64_t v) { __builtin_nontemporal_store(v, src + i); });
+        for (unsigned i = threadIdx.x; i < n; i += 1024) {
+          const uint64_t kk = __builtin_nontemporal_load(src + i);
+          point_list[rg.x + i] = (uint32_t)(kk & idx_mask);
+          keys_out[rg.x + i] = tile_hi | (kk >> idx_bits);
         }
       }
-      __syncthreads();  // the storage is reused by the next tile of this workgroup
     } else {
-      unsigned npad = 0;  // log2 of the padded length
-      while ((1u << npad) < n) npad++;
-      bitonic_sort_asc(n, npad, kThreads, [&](unsigned i) { return __builtin_nontemporal_load(src + i); },
-                       [&](unsigned i, uint64_t v) { __builtin_nontemporal_store(v, src + i); });
-      for (unsigned i = threadIdx.x; i < n; i += kThreads) {
-        const uint64_t kk = __builtin_nontemporal_load(src + i);
-        point_list[rg.x + i] = (uint32_t)(kk & idx_mask);
-        keys_out[rg.x + i] = tile_hi | (kk >> idx_bits);
-      }
+      if (n <= 1024) sort_tile_radix<1>(storage.s1, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
+      else if (n <= 4096) sort_tile_radix<4>(storage.s4, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
+      else sort_tile_radix<8>(storage.s8, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
     }
   }
 }
@@ -427,16 +458,14 @@ void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsig
 }
 
 int launch_bin_sort(int T, int P, const BinningState& b, const ImageState& img, hipStream_t s) {
-  // three size classes: <= 1024 keys, <= 4096, <= 16384 (longer lists in global memory), each a small persistent grid.
-  // (Running the classes concurrently on forked streams was tried: with the light's side stream and the two sort streams
-  // the runtime ran out of hardware queues and folded the light filter onto the main queue -- 25 % slower; they stay serial.)
+  // (Running size classes concurrently on forked streams was tried: with the light's side stream and two sort streams
+  // the runtime ran out of hardware queues and folded the light filter onto the main queue -- 25 % slower.  Hence one
+  // kernel that holds lists of every length up to 8192 keys, and a second, usually empty-handed, for the longer ones.)
   const unsigned ib = bin_index_bits(P);
-  hipLaunchKernelGGL((bin_sort_kernel<1024, 16, true>), dim3(std::min(T, 256)), dim3(1024), 0, s, T, 4096u, ib,
-                     img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL((bin_sort_kernel<256, 16, false>), dim3(std::min(T, 1024)), dim3(256), 0, s, T, 1024u, ib,
-                     img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL((bin_sort_kernel<256, 4, false>), dim3(std::min(T, 4096)), dim3(256), 0, s, T, 0u, ib,
-                     img.tile_order, img.ranges, b.keys_unsorted, b.keys, b.point_list);
+  hipLaunchKernelGGL(bin_sort_kernel<true>, dim3(std::min(T, 256)), dim3(1024), 0, s, T, ib, img.tile_order, img.ranges,
+                     b.keys_unsorted, b.keys, b.point_list);
+  hipLaunchKernelGGL(bin_sort_kernel<false>, dim3(std::min(T, 512)), dim3(1024), 0, s, T, ib, img.tile_order, img.ranges,
+                     b.keys_unsorted, b.keys, b.point_list);
   return 0;
 }
 

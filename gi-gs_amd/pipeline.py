@@ -612,6 +612,8 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
             # pooled rasterizer planes (fixed addresses) become the graph's static inputs themselves: no staging copies
             pooled = set(t.untyped_storage().data_ptr() for t in self.pool.buffers.values()) if self.pool else set()
             pooled |= getattr(self, "_static_storages", set())  # outputs of the graphed rasterizer: fixed addresses too
+            # ... and so are the filtered light levels (static outputs of the light's own graph): read in place, not staged
+            pooled |= set(t.untyped_storage().data_ptr() for t in lights)
             sample = tuple(a.detach().requires_grad_(a.requires_grad) if a.untyped_storage().data_ptr() in pooled
                            else a.detach().clone().requires_grad_(a.requires_grad) for a in args)
             self.back = graphed(self.back, sample)
