@@ -457,6 +457,8 @@ def main():
                        "gi_march": os.environ.get("GIGS_GI_MARCH", "proj (default)"),
                        "rasterizer": ("one hipGraph per view" if inference and args.graphs == "on" else
                                       "hipGraph (GIGS_RASTER_GRAPH=1)" if os.environ.get("GIGS_RASTER_GRAPH", "0") == "1"
+                                      else "whole step = 2 hand-captured hipGraphs (fwd, bwd), asynchronous binning"
+                                      if (stepper is not None and getattr(stepper, "whole", None) is not None)
                                       else "eager launches, asynchronous binning (no host read-back)"),
                        "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,

@@ -210,6 +210,19 @@ long long gigs_image_offset(int width, int height, int which) {
 
 void gigs_set_blend_begin_event(void* hip_event) { g_blend_begin_event.store(hip_event); }
 
+__global__ void __launch_bounds__(64) stream_delay_kernel(unsigned ticks) {
+  // wall_clock64: constant 100 MHz counter; every wave reaches the exit after at most `ticks` (<= 100 000) ticks
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+int gigs_stream_delay(unsigned nanoseconds, void* stream) {
+  if (nanoseconds == 0) return 0;
+  const unsigned ns = nanoseconds > 1000000u ? 1000000u : nanoseconds;
+  hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (ns + 9u) / 10u);
+  return hipGetLastError() == hipSuccess ? 0 : gigs_internal_fail(GIGS_ERR_HIP, "stream_delay: launch failed");
+}
+
 void gigs_set_async_binning(int r_capacity, unsigned* device_counters) {
   g_async_capacity.store(r_capacity > 0 ? (unsigned)r_capacity : 0u);
   g_async_counters.store(r_capacity > 0 ? (void*)device_counters : nullptr);

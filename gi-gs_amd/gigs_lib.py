@@ -105,6 +105,7 @@ SIGNATURES = {
     "gigs_selftest_div2": (_i, [_i, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_selftest_round": (_i, [_f, C.c_void_p]),
     "gigs_set_blend_begin_event": (None, [C.c_void_p]),
+    "gigs_stream_delay": (_i, [C.c_uint, C.c_void_p]),
     "gigs_set_async_binning": (None, [_i, C.c_void_p]),
     "gigs_profile_begin": (None, []),
     "gigs_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),

@@ -164,6 +164,9 @@ class _specular_cubemap_normalized(torch.autograd.Function):
         return g, None, None
 
 
+bwd_head_start_ns = 0
+
+
 class _specular_levels(torch.autograd.Function):
     """specular_cubemap of every level of a light in ONE launch each way (gigs_specular_cubemap_multi_w).  Inputs:
     the per-level (bounds, tables) as a Python list, then the level mips; needs the cached tables incl. the pre-divided
@@ -203,6 +206,8 @@ class _specular_levels(torch.autograd.Function):
             arr[i] = gigs_lib.SpecLevel(res, _avg_window(tables, res), d.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
                                         tables[3].data_ptr(), g.data_ptr(), None)
         with torch.cuda.device(dev):
+            if bwd_head_start_ns > 0:  # see gigs_stream_delay: set by pipeline.WholeStepGraph while it captures the backward
+                gigs_lib.check(_lib.gigs_stream_delay(int(bwd_head_start_ns), _stream()), "stream_delay")
             gigs_lib.check(_lib.gigs_specular_cubemap_multi_w(len(douts), C.cast(arr, C.c_void_p), 1, _stream()),
                            "specular_cubemap_multi_w")
         return (None, *gs)

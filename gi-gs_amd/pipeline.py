@@ -334,6 +334,159 @@ def _graphed_inference(mod, sample):
     return run
 
 
+class WholeStepGraph:
+    """One stage-2 iteration -- rasterizer, SSAO, light filter, shade, SSR, loss, and the whole backward -- captured by
+    hand into TWO hipGraphs (forward, backward) that share one memory pool:
+
+        replay(forward); record(event); replay(backward); wait(event); read the binning counters
+
+    Compared with chaining torch.cuda.make_graphed_callables pieces (GIGS_RASTER_GRAPH=1: six graph launches) there are
+    no staging copies of activations or of incoming gradients, no zero-filled placeholder gradients, and the ~45 kernel
+    nodes of a step run without the 11-18 us the command processor spends between eager launches; compared with the
+    eager rasterizer the light's filter still starts when the blend kernel starts (an event node recorded by the
+    library inside the forward), not beside the single-workgroup scan kernels it would starve.
+
+    Static inputs: the Gaussian tensors and light.base ARE the graph's inputs (aliases: an optimizer that updates them
+    in place needs no copy; tensors replaced by densification trigger a re-capture); the camera matrices, view_dirs
+    and gt_image are copied into fixed buffers before the replay (skipped when the caller passes the captured tensor).
+    Gradients come from torch.autograd.grad inside the backward capture (no AccumulateGrad nodes, which would run on
+    the parameters' creation stream) and are handed out as `.grad` after the replay: assigned when `.grad` is None,
+    added otherwise -- the semantics of loss.backward().  With dp.GradSlab's sink active during the capture the
+    rasterizer's backward writes straight into the slab, as in the eager step.
+
+    Binning runs under AsyncBinning (fixed capacity, nothing read back inside the step); the counters are copied to
+    pinned memory by a node at the end of the forward graph and examined after the backward has been queued, so the
+    host waits for the forward only.  On overflow the capacity grows, both graphs are re-captured and the step is
+    repeated; its gradients are never handed out."""
+
+    def __init__(self, owner: "Stage2Step", cam: Dict, g: Dict[str, torch.Tensor]):
+        self.owner = owner
+        self.dev = g["means3D"].device
+        self.cfg = (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"]))
+        self.capacity = 0
+        self.gf = self.gb = self.key = None
+        self.recaptures = 0
+        self.fwd_done = torch.cuda.Event()
+
+    CAM_TENSORS = ("viewmatrix", "projmatrix", "campos")
+
+    def _params(self, g):
+        return [g[k] for k in g] + [p for p in self.owner.light.parameters()]
+
+    def _key(self, g):
+        import diff_gaussian_rasterization as dgr
+        sink = dgr._grad_sink or {}
+        return (tuple((t.data_ptr(), tuple(t.shape)) for t in self._params(g)),
+                tuple(sorted((k, v.data_ptr()) for k, v in sink.items())))
+
+    def _capture(self, cam, g, gt_image, view_dirs):
+        import gc
+        o = self.owner
+        H, W, _, _ = self.cfg
+        bg = torch.zeros(3, device=self.dev)
+        if self.capacity <= 0:
+            probe = GraphedRaster(cam, g, o.gi, o.sh_degree)._probe(cam, g, bg)
+            tiles = ((H + 15) // 16) * ((W + 15) // 16)
+            if probe > BUCKET_MAX_MEAN_LIST * tiles:
+                raise DenseScene(f"{probe} instances over {tiles} tiles")
+            self.capacity = max(65536, -(-2 * probe // 65536) * 65536)
+        self.bin = AsyncBinning(self.capacity, self.dev)
+        self.inner = Stage2Step(o.light, o.brdf_lut, o.gi, o.sh_degree, graphs=False, fused=True, **o.flags)
+        self.inner._defer_backward = True
+        self.s_cam = {k: (v.detach().clone() if k in self.CAM_TENSORS else v) for k, v in cam.items()}
+        self.s_vd, self.s_gt = view_dirs.detach().clone(), gt_image.detach().clone()
+        self._src = {}  # static buffer -> (data_ptr, version) of the tensor it was last filled from
+        params = self._params(g)
+        self.gf = self.gb = None
+        torch.cuda.synchronize()
+        # warm-up on a side stream: builds every cached table / library buffer outside the capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                with self.bin:
+                    res = self.inner(self.s_cam, g, self.s_gt, self.s_vd)
+                torch.autograd.grad(res.pop("_loss"), params + [res["viewspace_points"]], allow_unused=True)
+                del res
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gc.collect()
+        was = gc.isenabled()
+        gc.disable()  # see graphed(): a cyclic-GC pass during capture may destroy HIP objects, which HIP refuses
+        try:
+            gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # GIGS_STEP_GRAPH_PRIO=1 (diagnostic): capture the main branch on a high-priority stream.  Measured: the graph
+            # executor does not turn that into dispatch order (blend backward still 0.54 ms), see the delay node below
+            prio = os.environ.get("GIGS_STEP_GRAPH_PRIO", "0") == "1"
+            cap = torch.cuda.Stream(device=self.dev, priority=-1) if prio else None
+            with torch.cuda.graph(gf, stream=cap):
+                with self.bin:
+                    res = self.inner(self.s_cam, g, self.s_gt, self.s_vd)
+                self.bin.host.copy_(self.bin.counters, non_blocking=True)
+            loss = res.pop("_loss")
+            # The blend backward and the light's GGX backward become ready together (after the shade backward).  The
+            # former lasts as long as its longest tiles and must get them resident at once; the latter floods every CU
+            # with bandwidth-bound workgroups.  Started in that order (as eager launches happen to be: the side stream's
+            # event wait costs ~35 us) the blend backward takes 0.30 ms, the other way round 0.51: a delay node gives it
+            # the head start (GIGS_LIGHT_BWD_HEAD_START_US, default 10).
+            import pbr.renderutils.ops as light_ops
+            light_ops.bwd_head_start_ns = int(1e3 * float(os.environ.get("GIGS_LIGHT_BWD_HEAD_START_US", "10")))
+            try:
+                with torch.cuda.graph(gb, pool=gf.pool(), stream=cap):
+                    grads = torch.autograd.grad(loss, params + [res["viewspace_points"]], allow_unused=True)
+            finally:
+                light_ops.bwd_head_start_ns = 0
+            del loss
+        finally:
+            if was:
+                gc.enable()
+        self.gf, self.gb, self.res = gf, gb, res
+        self.grads, self.vp_grad = list(grads[:-1]), grads[-1]
+        self.key = self._key(g)
+        self.recaptures += 1
+
+    def _fill(self, name, static, src):
+        # per-view constants come back every n_views steps and gt_image is often one tensor: skip what is already there
+        tag = (src.data_ptr(), src._version)
+        if self._src.get(name) != tag:
+            static.copy_(src, non_blocking=True)
+            self._src[name] = tag
+
+    def __call__(self, cam, g, gt_image, view_dirs):
+        if (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"])) != self.cfg:
+            raise ValueError("WholeStepGraph: image size / field of view differ from the captured ones")
+        for _ in range(4):
+            if self.gf is None or self.key != self._key(g):
+                self._capture(cam, g, gt_image, view_dirs)
+            for k in self.CAM_TENSORS:
+                self._fill(k, self.s_cam[k], cam[k])
+            self._fill("view_dirs", self.s_vd, view_dirs)
+            self._fill("gt_image", self.s_gt, gt_image)
+            self.gf.replay()
+            self.fwd_done.record()
+            self.gb.replay()
+            self.fwd_done.synchronize()
+            r, over = int(self.bin.host[0]), int(self.bin.host[1])
+            if over:
+                self.capacity = -(-int(1.5 * over) // 65536) * 65536
+                self.gf = None
+                continue
+            params = self._params(g)
+            for p, gr in zip(params, self.grads):
+                if gr is None:
+                    continue
+                if p.grad is None:
+                    p.grad = gr
+                elif p.grad is not gr and p.grad.data_ptr() != gr.data_ptr():
+                    p.grad.add_(gr)
+            vp = self.res["viewspace_points"]
+            vp.grad = self.vp_grad
+            out = dict(self.res)
+            out["num_rendered"] = r
+            return out
+        raise RuntimeError("WholeStepGraph: the binning capacity kept overflowing")
+
+
 def view_dirs_for(cam: Dict, rays: torch.Tensor, device) -> torch.Tensor:
     """train.py:299-308."""
     H, W = cam["image_height"], cam["image_width"]
@@ -413,6 +566,8 @@ class Stage2Step:
         self.loss_fn = stage2_loss
         self.graphs = graphs
         self._captured = False
+        self._defer_backward = False  # WholeStepGraph's inner step: return the attached loss, the caller differentiates
+        self.whole = None
 
     def _capture(self, front_args, loss_args):
         def clone(args):
@@ -426,6 +581,15 @@ class Stage2Step:
         """extra_loss(normal_map, albedo_map, roughness_map, metallic_map) -> scalar added to the loss before
         backward (the BRDF / envmap regularisers of train.py:387-420; see gi-gs_amd/losses.py)."""
         dev = g["means3D"].device
+        if (self.fused and self.graphs and extra_loss is None and os.environ.get("GIGS_STEP_GRAPH", "1") == "1"
+                and os.environ.get("GIGS_RASTER_GRAPH", "0") != "1" and not getattr(self, "_dense", False)):
+            try:
+                if self.whole is None:
+                    self.whole = WholeStepGraph(self, cam, g)
+                return self.whole(cam, g, gt_image, view_dirs)
+            except DenseScene:
+                self._dense = True  # synchronous binning with the global radix sort: the rasterizer stays eager
+                self.whole = None
         if self.fused and self.graphs and os.environ.get("GIGS_RASTER_GRAPH", "0") == "1" and not getattr(self, "_dense", False):
             try:
                 return self._graphed_step(cam, g, gt_image, view_dirs, extra_loss)
@@ -620,9 +784,13 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     loss, render_rgb, render_direct, IRR = self.back(*args)
     if extra_loss is not None:
         loss = loss + extra_loss(normal_map, albedo_map, roughness_map, metallic_map)
+    res = dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct, IRR=IRR,
+               viewspace_points=screenspace_points, radii=radii)
+    if self._defer_backward:
+        res["_loss"] = loss
+        return res
     loss.backward()
-    return dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct, IRR=IRR,
-                viewspace_points=screenspace_points, radii=radii)
+    return res
 
 
 Stage2Step._eager_async = _eager_async

@@ -433,6 +433,13 @@ int gigs_selftest_round(unsigned long long* mismatches, void* stream);
  * Process-wide; set it before the forward that should record it. */
 void gigs_set_blend_begin_event(void* hip_event);
 
+/* One-wave kernel that occupies `stream` for about `nanoseconds` (it spins on the constant-rate wall clock; capped at
+ * 1 ms; capturable into a hipGraph).  Inside a graph, kernel nodes that become ready together start in an order the
+ * caller cannot choose; a short head start for the branch that carries a latency-bound kernel (the blend backward's
+ * long tiles) ahead of a branch that floods every CU (the light's GGX backward) is expressed as a delay node at the
+ * head of the latter (pipeline.WholeStepGraph).  gigs-hip extension. */
+int gigs_stream_delay(unsigned nanoseconds, void* stream);
+
 /* Asynchronous binning (gigs-hip extension).  The reference's forward reads the instance count back in the middle
  * (rasterizer_impl.cu:589-594) to size the binning buffer, which serialises host and device and keeps the forward out
  * of a hipGraph.  After gigs_set_async_binning(r_capacity > 0, counters) every gigs_forward asks the binning callback

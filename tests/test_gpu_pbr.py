@@ -193,7 +193,7 @@ def test_stage2_hipgraph_capture_matches_eager(orc):
     torch.manual_seed(1)
     sc = scenes.surface_scene(P=10_000, sh_degree=2, seed=9, scale_mu=0.025)
     gi = scenes.GI_DEFAULTS
-    H, W = 128, 160
+    H, W = 176, 224  # 154 tiles: sparse enough per tile for the tile-bucketed binning the graphed modes need
     cams = [scenes.orbit_camera(i, 6, W, H, radius=3.5) for i in (1, 4)]
     camts = [{k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
     gt = torch.rand(3, H, W, device=DEV)
@@ -235,7 +235,7 @@ def test_stage2_fused_matches_unfused(orc, metallic):
     import pipeline
     sc = scenes.surface_scene(P=10_000, sh_degree=2, seed=9, scale_mu=0.025)
     gi = scenes.GI_DEFAULTS
-    H, W = 128, 160
+    H, W = 176, 224  # 154 tiles: sparse enough per tile for the tile-bucketed binning the graphed modes need
     cams = [scenes.orbit_camera(i, 6, W, H, radius=3.5) for i in (1, 4)]
     camts = [{k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
     torch.manual_seed(1)
@@ -244,15 +244,17 @@ def test_stage2_fused_matches_unfused(orc, metallic):
     rays = pipeline.canonical_rays(cams[0], DEV)
     vds = [pipeline.view_dirs_for(c, rays, DEV) for c in camts]
     results = {}
-    for mode in ("unfused", "fused", "fused_graph", "fused_graph_raster"):
+    for mode in ("unfused", "fused", "fused_graph", "fused_graph_raster", "fused_step_graph"):
         torch.manual_seed(2)
         light = pbr.CubemapLight(base_res=64, device=DEV)
         g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
-        # fused_graph: glue replayed from hipGraphs, rasterizer launched eagerly with asynchronous binning (the default);
-        # fused_graph_raster: the rasterizer captured too (GIGS_RASTER_GRAPH=1)
+        # fused_step_graph: the whole iteration as two hand-captured hipGraphs (pipeline.WholeStepGraph, the default);
+        # fused_graph: glue replayed from hipGraphs, rasterizer launched eagerly with asynchronous binning;
+        # fused_graph_raster: the rasterizer captured too, six make_graphed_callables pieces (GIGS_RASTER_GRAPH=1)
         os.environ["GIGS_RASTER_GRAPH"] = "1" if mode == "fused_graph_raster" else "0"
+        os.environ["GIGS_STEP_GRAPH"] = "1" if mode == "fused_step_graph" else "0"
         step = pipeline.Stage2Step(light, lut, gi, 2, metallic=metallic, fused=mode != "unfused",
-                                   graphs=mode.startswith("fused_graph"))
+                                   graphs=mode in ("fused_graph", "fused_graph_raster", "fused_step_graph"))
         outs = []
         for ci in (0, 1, 0):
             for t in list(g.values()) + [light.base]:
@@ -261,9 +263,12 @@ def test_stage2_fused_matches_unfused(orc, metallic):
             torch.cuda.synchronize()
             outs.append((float(o["loss"]), {k: g[k].grad.clone() for k in ("albedo", "roughness", "metallic")},
                          light.base.grad.clone(), o["render_rgb"].clone(), o["IRR"].clone()))
+        if mode == "fused_step_graph":
+            assert step.whole is not None and step.whole.recaptures == 1  # three views, one capture
         results[mode] = outs
     os.environ.pop("GIGS_RASTER_GRAPH", None)
-    for mode in ("fused", "fused_graph", "fused_graph_raster"):
+    os.environ.pop("GIGS_STEP_GRAPH", None)
+    for mode in ("fused", "fused_graph", "fused_graph_raster", "fused_step_graph"):
         for (lu, gu, bu, ru, iu), (lf, gf, bf, rf, irf) in zip(results["unfused"], results[mode]):
             assert abs(lu - lf) <= 2e-6 * max(1.0, abs(lu)), (mode, lu, lf)
             torch.testing.assert_close(irf, iu, rtol=0, atol=2e-6)
@@ -276,7 +281,7 @@ def test_stage2_fused_matches_unfused(orc, metallic):
     assert abs(results["fused_graph"][0][0] - results["fused_graph"][1][0]) > 1e-6
 
 
-@pytest.mark.parametrize("raster", ["graph", "eager_async"])
+@pytest.mark.parametrize("raster", ["step_graph", "graph", "eager_async"])
 def test_graphed_step_survives_a_binning_overflow(raster, monkeypatch):
     """The whole-step hipGraph bins into a fixed-capacity buffer; a view with more instances than the capacity raises
     the device-side overflow flag, the capacity grows, the graph is re-captured and the step repeated: same loss,
@@ -285,6 +290,7 @@ def test_graphed_step_survives_a_binning_overflow(raster, monkeypatch):
     import pipeline
     from diff_gaussian_rasterization import AsyncBinning
     monkeypatch.setenv("GIGS_RASTER_GRAPH", "1" if raster == "graph" else "0")
+    monkeypatch.setenv("GIGS_STEP_GRAPH", "1" if raster == "step_graph" else "0")
     sc = scenes.surface_scene(P=20_000, sh_degree=2, seed=4, scale_mu=0.03)
     gi = scenes.GI_DEFAULTS
     H, W = 160, 208
@@ -300,13 +306,18 @@ def test_graphed_step_survives_a_binning_overflow(raster, monkeypatch):
         light = pbr.CubemapLight(base_res=64, device=DEV)
         g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
         step = pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=(mode == "graph"))
-        if mode == "graph" and raster == "graph":
-            step.graster = pipeline.GraphedRaster(camt, g, gi, 2, capacity=65536)  # far below this view's instance count
+        if mode == "graph" and raster == "step_graph":
+            step.whole = pipeline.WholeStepGraph(step, camt, g)
+            step.whole.capacity = 65536  # far below this view's instance count
+        elif mode == "graph" and raster == "graph":
+            step.graster = pipeline.GraphedRaster(camt, g, gi, 2, capacity=65536)
         elif mode == "graph":
             step._abin = AsyncBinning(65536, DEV)  # the eager rasterizer's asynchronous binning, same protocol
         o = step(camt, g, gt, vd)
         torch.cuda.synchronize()
-        if mode == "graph" and raster == "graph":
+        if mode == "graph" and raster == "step_graph":
+            assert step.whole.recaptures == 2 and step.whole.capacity > 65536
+        elif mode == "graph" and raster == "graph":
             assert step.graster.recaptures == 2 and step.graster.capacity > 65536
         elif mode == "graph":
             assert step._abin.capacity > 65536
