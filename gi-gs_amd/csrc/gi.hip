@@ -174,7 +174,8 @@ struct GiParams {
   int nrays;
   int tile_log2w;  // the 64 pixels of a workgroup form a (1 << tile_log2w) x (64 >> tile_log2w) rectangle
   int cert_shift;      // certification blocks are (1 << cert_shift)^2 pixels; 0 = no certification table
-  int cert_w, cert_h;  // blocks per row / column of the image; the table is (cert_w + 2) x (cert_h + 2) with its border
+  int cert_w, cert_h;  // blocks per row / column of the image; the table is (cert_w + 1) x (cert_h + 1): last column / row = border
+  float cert_d0;       // certification needs den > cert_d0 (CertK::d0)
   // j / step for j = start .. start + 63 (exact for a power-of-two step): the fast path reads its per-step factor from
   // here with a scalar load instead of converting and multiplying on the vector ALU for every group (marches of more
   // than kFjTable - kGiGroup steps take the general path)
@@ -651,81 +652,129 @@ __device__ __forceinline__ void march2_fast(const GiParams& p, const FastPix& c,
 struct CertPix {
   f32x2 Axy, cxy;  // FastPix::Axy / cxy scaled by 2^-shift
   float scale;     // 2^shift
-  int bw, bh;      // blocks per row / column of the image (the table has a border of one block all around)
+  int bw, bh;      // blocks per row / column of the image (the table has one more column / row: the never-certify border)
 };
 
-__device__ __forceinline__ int clamp_m1(int v, int hi) {  // median(v, -1, hi): one VOP3 instruction (the compiler emits min + max)
-  int r;
-  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(hi));
-  return r;
+typedef unsigned long long u64;
+
+// certification thresholds on the sample's denominator den = spz + 1e-7 (the hit interval is [den + cm - hh, den + cm + hh]):
+//   lo = (den + cm) * (1 - 2^-16) - (hh + 1e-6) > block maximum      <=>  den > t_hi   (stored per block)
+//   hi = (den + cm) * (1 + 2^-16) + (hh + 1e-6) < block non-zero min <=>  den < t_lo   (stored per block)
+//   lo > 0 (empty pixels hold z = 0)                                  <=>  den > d0     (a launch constant)
+// each rounded away from certification (gi_minmax_kernel).
+struct CertK { float lo_k, hi_k, d0; };
+__host__ __device__ __forceinline__ CertK cert_consts(float bias, float thick) {
+  const float cm = 0.5f * (bias - thick) - 0.0000001f, hh = 0.5f * (bias + thick);
+  CertK k;
+  k.lo_k = cm * (1.0f - 0x1p-16f) - hh - 1e-6f;
+  k.hi_k = cm * (1.0f + 0x1p-16f) + hh + 1e-6f;
+  const float d = -k.lo_k / (1.0f - 0x1p-16f);
+  k.d0 = d + fabsf(d) * 0x1p-20f + 1e-30f;
+  return k;
 }
 
-template <int kMode, int kGroup>
+// kTabOff: LDS byte address of the table (the kernels' dynamic LDS starts right after their static arrays; checked at
+// kernel entry).  The lookups are written as instructions because the compiler adds the -- constant -- base with a
+// v_add per lookup instead of using the ds_read offset field.
+template <int kMode, int kGroup, int kTabOff>
 __device__ __forceinline__ void march2_cert(const GiParams& p, const FastPix& c, const CertPix& cp, const f32x2* Bxy16,
-                                            f32x2 Bz2, __amdgpu_buffer_rsrc_t pos_z, const float2* __restrict__ s_tab,
-                                            int* hit) {
+                                            f32x2 Bz2, __amdgpu_buffer_rsrc_t pos_z, int* hit) {
   static_assert(kMode >= 3, "certification is wired into the projective marches");
-  bool open[2] = {true, true};
+  // Lane predicates are kept as 64-bit wave masks in SGPRs (ballots of single compares, combined with scalar logic,
+  // turned back into a lane predicate only where a select needs one): written with per-lane bools the compiler moves
+  // them through VGPRs (v_cndmask 0/1 + v_cmp_ne per use) -- a third of the march's vector instructions.
+  u64 open_m[2];
+  open_m[0] = open_m[1] = __builtin_amdgcn_ballot_w64(true);  // the lanes that march (EXEC)
   hit[0] = hit[1] = -1;
   const f32x2 Dz2 = {c.Dz, c.Dz};
-  const int row8 = (cp.bw + 2) * 8;
-  const char* tab0 = reinterpret_cast<const char*>(s_tab) + row8 + 8;  // entry of block (0, 0): the border sits at -1
+  const unsigned row8 = (unsigned)(cp.bw + 1) * 8u;
+  // table entry of block (bx, by) at byte by * row8 + bx * 8; column bw / row bh never certify
+  // block indices as unsigned: a negative one is a huge one, and both clamp to bw / bh (one v_min_u32 per coordinate)
+  unsigned bw_v = (unsigned)cp.bw, bh_v = (unsigned)cp.bh;
+  asm("" : "+v"(bw_v), "+v"(bh_v));  // in VGPRs: the VOP2 form with two VGPR operands issues faster than an SGPR-source one
+  // den > d0 for every sample of a ray <=> at both of its ends (den is a correctly rounded, hence monotone, function of j):
+  // decided once per ray instead of once per sample
+  u64 pos[2];
+  {
+    const float f0 = p.fjt[0], f1 = p.fjt[p.step - 1 - p.start];
+    const f32x2 da = __builtin_elementwise_fma(Bz2, f32x2{f0, f0}, Dz2), db = __builtin_elementwise_fma(Bz2, f32x2{f1, f1}, Dz2);
+    pos[0] = __builtin_amdgcn_ballot_w64(da.x > p.cert_d0) & __builtin_amdgcn_ballot_w64(db.x > p.cert_d0);
+    pos[1] = __builtin_amdgcn_ballot_w64(da.y > p.cert_d0) & __builtin_amdgcn_ballot_w64(db.y > p.cert_d0);
+  }
   for (int j0 = p.start; j0 < p.step; j0 += kGroup) {
     f32x2 tb[2][kGroup];  // sample position in block units (+ the rounding addend, scaled)
-    f32x2 mid[kGroup];
-    bool need[2][kGroup];
-    // phase A: every sample of the group up to its table entry and the certification decision; no branches
+    f32x2 dn[kGroup];
+    f32x2 th[2][kGroup];  // {t_lo, t_hi} of the sample's block
+    u64 cert[2][kGroup];
+    // the group's j / step factors, in SGPRs before the first lookup is issued: a scalar load between the lookups would
+    // bring a wait on the counter they share, i.e. on the lookups
+    float fjs[kGroup];
+#pragma unroll
+    for (int g = 0; g < kGroup; g++) fjs[g] = p.fjt[j0 - p.start + g];
+    asm volatile("" : "+s"(fjs[0]), "+s"(fjs[1]), "+s"(fjs[2]), "+s"(fjs[3]));
+    // phase A: every sample of the group up to its table lookup; no branches
 #pragma unroll
     for (int g = 0; g < kGroup; g++) {
-      const float fj = p.fjt[j0 - p.start + g];  // j / step
+      const float fj = fjs[g];  // j / step
       const f32x2 fj2 = {fj, fj};
-      const bool in_range = (j0 + g) < p.step;
       const f32x2 den = __builtin_elementwise_fma(Bz2, fj2, Dz2);
-      mid[g] = den + c.cm;
+      dn[g] = den;
       f32x2 r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
       if constexpr (kMode == 3) {
         const f32x2 e0 = __builtin_elementwise_fma(-den, r, f32x2{1.0f, 1.0f});
         r = __builtin_elementwise_fma(e0, r, r);
       }
-      const f32x2 lo_c = __builtin_elementwise_fma(mid[g], f32x2{1.0f - 0x1p-16f, 1.0f - 0x1p-16f}, f32x2{-c.hh - 1e-6f, -c.hh - 1e-6f});
-      const f32x2 hi_c = __builtin_elementwise_fma(mid[g], f32x2{1.0f + 0x1p-16f, 1.0f + 0x1p-16f}, f32x2{c.hh + 1e-6f, c.hh + 1e-6f});
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const float rk = k == 0 ? r.x : r.y;
         const f32x2 n = __builtin_elementwise_fma(Bxy16[k], fj2, cp.Axy);
         tb[k][g] = __builtin_elementwise_fma(n, f32x2{rk, rk}, cp.cxy);
-        const int bx = clamp_m1(cvt_flr(tb[k][g].x), cp.bw);
-        const int by = clamp_m1(cvt_flr(tb[k][g].y), cp.bh);
-        const float2 mm = *reinterpret_cast<const float2*>(tab0 + (__mul24(by, row8) + (bx << 3)));
-        const float lo = k == 0 ? lo_c.x : lo_c.y, hi = k == 0 ? hi_c.x : hi_c.y;
-        const bool cert = (lo > mm.y) | ((hi < mm.x) & (lo > 0.0f));
-        need[k][g] = open[k] & in_range & !cert;
+        const unsigned bx = min((unsigned)cvt_flr(tb[k][g].x), bw_v);
+        const unsigned by = min((unsigned)cvt_flr(tb[k][g].y), bh_v);
+        const unsigned toff = __umul24(by, row8) + (bx << 3);
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(th[k][g]) : "v"(toff), "n"(kTabOff));
+      }
+    }
+    // the lookups above are invisible to the compiler's wait-count bookkeeping: wait for them here (operands tie the order)
+    static_assert(kGroup == 4, "the wait below lists the lookups of a group of four");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(th[0][0]), "+v"(th[0][1]), "+v"(th[0][2]), "+v"(th[0][3]), "+v"(th[1][0]), "+v"(th[1][1]), "+v"(th[1][2]),
+                   "+v"(th[1][3]));
+#pragma unroll
+    for (int g = 0; g < kGroup; g++) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const float dk = k == 0 ? dn[g].x : dn[g].y;
+        const u64 above = __builtin_amdgcn_ballot_w64(dk > th[k][g].y);
+        const u64 below = __builtin_amdgcn_ballot_w64(dk < th[k][g].x);
+        cert[k][g] = above | (below & pos[k]);
       }
     }
     // phase B: in ray order, the exact part for the samples some lane of the wave still needs (~8 % of them: the
     // lookup is waited for on the spot, other waves cover the latency)
-    bool any_open = false;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
 #pragma unroll
       for (int g = 0; g < kGroup; g++) {
-        if (__builtin_amdgcn_ballot_w64(need[k][g]) != 0) {
+        const u64 need = (j0 + g) < p.step ? (open_m[k] & ~cert[k][g]) : 0ull;
+        if (need != 0ull) {
           const f32x2 t = tb[k][g] * cp.scale;  // exact: the pixel coordinates the uncertified march computes
           const int ix = cvt_flr(t.x);
           const int iy = cvt_flr(t.y);
-          const bool inb = (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+          const u64 inb = __builtin_amdgcn_ballot_w64((unsigned)ix < (unsigned)p.W) &
+                          __builtin_amdgcn_ballot_w64((unsigned)iy < (unsigned)p.H);
           const unsigned off = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;
-          const bool live = open[k] && need[k][g];
-          float z = gather_idx_issue((live && inb) ? off : 0xffffffffu, pos_z);
+          const u64 look = need & inb;
+          float z = gather_idx_issue(__builtin_amdgcn_inverse_ballot_w64(look) ? off : 0xffffffffu, pos_z);
           asm volatile("s_waitcnt vmcnt(0)" : "+v"(z));
-          const bool h = live && inb && fabsf(z - (k == 0 ? mid[g].x : mid[g].y)) <= c.hh;
-          hit[k] = h ? (int)off : hit[k];
-          open[k] = open[k] && !(live && (!inb || h));
+          const float mid = (k == 0 ? dn[g].x : dn[g].y) + c.cm;
+          const u64 h = look & __builtin_amdgcn_ballot_w64(fabsf(z - mid) <= c.hh);
+          hit[k] = __builtin_amdgcn_inverse_ballot_w64(h) ? (int)off : hit[k];
+          open_m[k] &= ~((need & ~inb) | h);  // left the image, or hit: the ray is closed
         }
       }
-      any_open = any_open || open[k];
     }
-    if (!__any(any_open)) break;
+    if ((open_m[0] | open_m[1]) == 0ull) break;
   }
 }
 
@@ -830,8 +879,10 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             float* __restrict__ occlusion, const float2* __restrict__ cert_tab) {
   __shared__ float s_part[kGiWaves][64];
   extern __shared__ float2 s_cert[];
+  constexpr int kCertOff = sizeof(float) * kGiWaves * 64;  // dynamic LDS follows the static array
   if constexpr (kCert) {
-    const int nb = (p.cert_w + 2) * (p.cert_h + 2);
+    if ((unsigned)(size_t)s_cert != (unsigned)kCertOff) __builtin_trap();  // the march addresses the table by this constant
+    const int nb = (p.cert_w + 1) * (p.cert_h + 1);
     for (int i = threadIdx.x; i < nb; i += 256) s_cert[i] = cert_tab[i];
     __syncthreads();
   }
@@ -866,7 +917,7 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             fast_ray<kMode>(p, tbn, ft, a, rays[2 * rb], Bxy[1], bz1);
             Bz2 = f32x2{bz0, bz1};
             int hit[2];
-            if constexpr (kCert) march2_cert<kMode, kGiGroup>(p, c, cp, Bxy, Bz2, pos_z, s_cert, hit);
+            if constexpr (kCert) march2_cert<kMode, kGiGroup, kCertOff>(p, c, cp, Bxy, Bz2, pos_z, hit);
             else march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
             occ += hit[0] >= 0 ? rays[2 * r + 1].y : 0.0f;
             occ += (hit[1] >= 0 && rb != r) ? rays[2 * rb + 1].y : 0.0f;
@@ -919,8 +970,10 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
            const float2* __restrict__ cert_tab) {
   __shared__ float s_part[kGiWaves][3][64];
   extern __shared__ float2 s_cert[];
+  constexpr int kCertOff = sizeof(float) * kGiWaves * 3 * 64;  // dynamic LDS follows the static array
   if constexpr (kCert) {
-    const int nb = (p.cert_w + 2) * (p.cert_h + 2);
+    if ((unsigned)(size_t)s_cert != (unsigned)kCertOff) __builtin_trap();  // the march addresses the table by this constant
+    const int nb = (p.cert_w + 1) * (p.cert_h + 1);
     for (int i = threadIdx.x; i < nb; i += 256) s_cert[i] = cert_tab[i];
     __syncthreads();
   }
@@ -962,7 +1015,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
           fast_ray<kMode>(p, tbn, ft, a, ra1, Bxy[1], bz1);
           Bz2 = f32x2{bz0, bz1};
           int hit[2];
-          if constexpr (kCert) march2_cert<kMode, kGiGroup>(p, c, cp, Bxy, Bz2, pos_z, s_cert, hit);
+          if constexpr (kCert) march2_cert<kMode, kGiGroup, kCertOff>(p, c, cp, Bxy, Bz2, pos_z, hit);
           else march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
           if (rb == r) hit[1] = -1;
           if (__any(hit[0] >= 0 || hit[1] >= 0)) {
@@ -1059,15 +1112,17 @@ static GiParams make_params(int W, int H, float fx, float fy, float radius, floa
   p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
   return p;
 }
-// Certification table, (bw + 2) x (bh + 2) entries: per (1 << shift)^2 block of the z plane {minimum over its non-zero
-// pixels (+inf if none), max(maximum, 0)}; NaN pixels are ignored (a NaN never passes the depth test).  Blocks of the
-// border ring and blocks the image covers only partly hold {-inf, +inf}: nothing is ever certified there, so samples
-// that may lie outside the image always take the exact path.  One wave per entry.
+// Certification table, (bw + 1) x (bh + 1) entries.  Per (1 << shift)^2 block of the z plane: the minimum over its non-zero
+// pixels (+inf if none) and max(maximum, 0) -- NaN pixels are ignored (a NaN never passes the depth test) -- turned into
+// the two thresholds {t_lo, t_hi} on a sample's denominator (CertK): the march then certifies with three compares and no
+// arithmetic.  The last column / row (indices bw / bh: where out-of-image block coordinates clamp to, negative ones
+// included, being huge as unsigned) and blocks the image covers only partly hold {-inf, +inf}: nothing is ever certified
+// there, so samples that may lie outside the image always take the exact path.  One wave per entry.
 __global__ void __launch_bounds__(64)
-gi_minmax_kernel(int W, int H, int shift, int bw, int bh, const float* __restrict__ z, float2* __restrict__ tab) {
-  const int bx = (int)blockIdx.x - 1, by = (int)blockIdx.y - 1, B = 1 << shift;
+gi_minmax_kernel(int W, int H, int shift, int bw, int bh, CertK ck, const float* __restrict__ z, float2* __restrict__ tab) {
+  const int bx = (int)blockIdx.x, by = (int)blockIdx.y, B = 1 << shift;
   float mn = __builtin_inff(), mx = 0.0f;
-  const bool full = bx >= 0 && by >= 0 && ((bx + 1) << shift) <= W && ((by + 1) << shift) <= H;
+  const bool full = bx < bw && by < bh && ((bx + 1) << shift) <= W && ((by + 1) << shift) <= H;
   if (full) {
     for (int i = threadIdx.x; i < B * B; i += 64) {
       const float v = z[(size_t)((by << shift) + (i >> shift)) * W + (bx << shift) + (i & (B - 1))];
@@ -1083,7 +1138,15 @@ gi_minmax_kernel(int W, int H, int shift, int bw, int bh, const float* __restric
     mn = -__builtin_inff();
     mx = __builtin_inff();
   }
-  if (threadIdx.x == 0) tab[(size_t)blockIdx.y * (bw + 2) + blockIdx.x] = make_float2(mn, mx);
+  if (threadIdx.x == 0) {
+    // thresholds on den (see CertK), each moved away from certification by 2^-20 relative
+    float t_hi = (mx - ck.lo_k) / (1.0f - 0x1p-16f);
+    t_hi = t_hi + fabsf(t_hi) * 0x1p-20f + 1e-30f;
+    float t_lo = (mn - ck.hi_k) / (1.0f + 0x1p-16f);
+    t_lo = t_lo - fabsf(t_lo) * 0x1p-20f - 1e-30f;
+    if (!(mx == mx) || !(mn == mn)) { t_hi = __builtin_inff(); t_lo = -__builtin_inff(); }  // NaN depths: never certify
+    tab[(size_t)by * (bw + 1) + bx] = make_float2(t_lo, t_hi);
+  }
 }
 
 // block size of the certification table: the smallest of 16 / 32 / 64 pixels whose table fits kCertMaxBytes of LDS
@@ -1103,6 +1166,7 @@ size_t gi_scratch_bytes(int W, int H) {
 // fills p.cert_*; returns the table's byte size (0 = run without certification)
 static size_t prepare_cert(GiParams& p, int mode, const float* pos, void* scratch, hipStream_t s) {
   p.cert_shift = p.cert_w = p.cert_h = 0;
+  p.cert_d0 = cert_consts(p.bias, p.thick).d0;
   const char* e = getenv("GIGS_GI_CERT");
   if (!scratch || mode < 3 || (e && e[0] == '0')) return 0;
   const int sh = cert_shift_for(p.W, p.H);
@@ -1110,8 +1174,8 @@ static size_t prepare_cert(GiParams& p, int mode, const float* pos, void* scratc
   p.cert_shift = sh;
   p.cert_w = (p.W + (1 << sh) - 1) >> sh;
   p.cert_h = (p.H + (1 << sh) - 1) >> sh;
-  hipLaunchKernelGGL(gi_minmax_kernel, dim3(p.cert_w + 2, p.cert_h + 2), dim3(64), 0, s, p.W, p.H, sh, p.cert_w, p.cert_h,
-                     pos + 2 * (size_t)p.H * p.W, (float2*)scratch);
+  hipLaunchKernelGGL(gi_minmax_kernel, dim3(p.cert_w + 1, p.cert_h + 1), dim3(64), 0, s, p.W, p.H, sh, p.cert_w, p.cert_h,
+                     cert_consts(p.bias, p.thick), pos + 2 * (size_t)p.H * p.W, (float2*)scratch);
   return cert_table_bytes(p.W, p.H, sh);
 }
 

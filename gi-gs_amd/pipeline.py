@@ -158,10 +158,11 @@ def gbuffer_post_fused(normal_map_from_depth: torch.Tensor, normal_map: torch.Te
 
 
 def rasterize(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, bg: torch.Tensor, gi: Dict,
-              inference: bool = False, derive_normal: bool = True, debug=False):
-    """The operator call of gaussian_renderer.render (:53-155): returns the raw 12-tuple + means2D."""
+              inference: bool = False, derive_normal: bool = True, debug=False, means2D: Optional[torch.Tensor] = None):
+    """The operator call of gaussian_renderer.render (:53-155): returns the raw 12-tuple + means2D.  `means2D`: a
+    persistent all-zero [P, 3] leaf to use instead of a fresh one (its values are never read, only its gradient)."""
     means3D = g["means3D"]
-    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
+    screenspace_points = means2D if means2D is not None else torch.zeros_like(means3D, requires_grad=True)
     st = make_settings(cam, sh_degree, bg, gi, means3D.device, inference=inference, debug=debug)
     out = GaussianRasterizer(st)(
         means3D=means3D, means2D=screenspace_points, opacities=g["opacities"], normal=g["normal"], shs=g["shs"],
@@ -367,6 +368,7 @@ class WholeStepGraph:
         self.gf = self.gb = self.key = None
         self.recaptures = 0
         self.fwd_done = torch.cuda.Event()
+        self._packs = {}
 
     CAM_TENSORS = ("viewmatrix", "projmatrix", "campos")
 
@@ -393,7 +395,16 @@ class WholeStepGraph:
         self.bin = AsyncBinning(self.capacity, self.dev)
         self.inner = Stage2Step(o.light, o.brdf_lut, o.gi, o.sh_degree, graphs=False, fused=True, **o.flags)
         self.inner._defer_backward = True
-        self.s_cam = {k: (v.detach().clone() if k in self.CAM_TENSORS else v) for k, v in cam.items()}
+        self.inner._static_bg = bg
+        self.inner._static_m2d = torch.zeros_like(g["means3D"], requires_grad=True)
+        # the three camera tensors are views of ONE static buffer: one copy per step
+        self.s_pack = self._pack(cam).clone()
+        self.s_cam = dict(cam)
+        off = 0
+        for k in self.CAM_TENSORS:
+            n = cam[k].numel()
+            self.s_cam[k] = self.s_pack[off:off + n].view(cam[k].shape)
+            off += n
         self.s_vd, self.s_gt = view_dirs.detach().clone(), gt_image.detach().clone()
         self._src = {}  # static buffer -> (data_ptr, version) of the tensor it was last filled from
         params = self._params(g)
@@ -445,6 +456,17 @@ class WholeStepGraph:
         self.key = self._key(g)
         self.recaptures += 1
 
+    def _pack(self, cam):
+        # (viewmatrix, projmatrix, campos) flattened into one tensor, built once per camera (training loops revisit them)
+        key = tuple((cam[k].data_ptr(), cam[k]._version) for k in self.CAM_TENSORS)
+        pk = self._packs.get(key)
+        if pk is None:
+            if len(self._packs) >= 8192:
+                self._packs.clear()
+            pk = torch.cat([cam[k].detach().reshape(-1).float() for k in self.CAM_TENSORS])
+            self._packs[key] = pk
+        return pk
+
     def _fill(self, name, static, src):
         # per-view constants come back every n_views steps and gt_image is often one tensor: skip what is already there
         tag = (src.data_ptr(), src._version)
@@ -458,8 +480,7 @@ class WholeStepGraph:
         for _ in range(4):
             if self.gf is None or self.key != self._key(g):
                 self._capture(cam, g, gt_image, view_dirs)
-            for k in self.CAM_TENSORS:
-                self._fill(k, self.s_cam[k], cam[k])
+            self._fill("camera", self.s_pack, self._pack(cam))
             self._fill("view_dirs", self.s_vd, view_dirs)
             self._fill("gt_image", self.s_gt, gt_image)
             self.gf.replay()
@@ -596,7 +617,11 @@ class Stage2Step:
             except DenseScene:
                 self._dense = True  # keep the rasterizer eager (synchronous binning, global radix sort); the rest stays graphed
                 self.step_begin = None
-        background = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
+        # train.py:263-264: black background for PBR (WholeStepGraph's inner step keeps it, and means2D, outside the graph)
+        background = getattr(self, "_static_bg", None)
+        if background is None:
+            background = torch.zeros(3, device=dev)
+        m2d = getattr(self, "_static_m2d", None)
         if self.fused:
             if self.step_begin is None:
                 import gigs_lib
@@ -616,9 +641,9 @@ class Stage2Step:
             with hook, (abin if abin is not None else _NULLCTX):
                 if self.pool is not None:
                     with self.pool:
-                        out = rasterize(cam, g, self.sh_degree, background, self.gi)
+                        out = rasterize(cam, g, self.sh_degree, background, self.gi, means2D=m2d)
                 else:
-                    out = rasterize(cam, g, self.sh_degree, background, self.gi)
+                    out = rasterize(cam, g, self.sh_degree, background, self.gi, means2D=m2d)
             if abin is not None:
                 abin.snapshot()
         finally:

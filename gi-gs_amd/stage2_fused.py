@@ -43,6 +43,7 @@ class _Stage2Fused(torch.autograd.Function):
         dev = albedo_map.device
         if not albedo_map.is_cuda:
             raise RuntimeError("stage2_fused needs CUDA/HIP tensors: gigs-hip has no CPU path")
+        ctx.set_materialize_grads(False)  # the three image outputs carry no gradient: no zero tensors for them (3 fills / step)
         H, W = int(cfg["H"]), int(cfg["W"])
         f = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
         normal_map, out_normal_view, albedo_map = f(normal_map), f(out_normal_view), f(albedo_map)
@@ -96,6 +97,8 @@ class _Stage2Fused(torch.autograd.Function):
         dev = albedo_map.device
         H, W = int(cfg["H"]), int(cfg["W"])
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        if g_loss is None:
+            g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_loss = g_loss.contiguous().float()
         d_direct, d_irr, d_rough_add, d_metal_add = new(3, H, W), new(3, H, W), new(1, H, W), new(1, H, W)
         d_albedo, d_rough = new(3, H, W), new(1, H, W)

@@ -107,7 +107,11 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only-sweep", action="store_true")
+    ap.add_argument("--modes", default="", help="comma-separated subset of the non-exact modes (default: all)")
+    ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
+    if args.modes:
+        MODES[1:] = args.modes.split(",")
     report = {"modes": MODES, "cases": []}
     for name, sc, cam, deg, gis in ([] if args.only_sweep else cases(not args.quick)):
         for gi in gis:
@@ -128,7 +132,7 @@ def main():
                          m["ssr_abd"]["mean_l1"]), flush=True)
     # workgroup pixel rectangle (GIGS_GI_TILE_LOG2W): once the march is no longer VALU-bound the z-plane gathers of a
     # wave cost by the number of image rows they touch (tools/microbench/gather_rate.hip)
-    if not args.quick:
+    if not args.quick and not args.no_sweep:
         sc = scenes.surface_scene(P=300_000, sh_degree=2, seed=0)
         cam = scenes.orbit_camera(5, 64, 800, 800, radius=3.5)
         gi = scenes.GI_DEFAULTS
