@@ -180,6 +180,7 @@ struct GiParams {
   // here with a scalar load instead of converting and multiplying on the vector ALU for every group (marches of more
   // than kFjTable - kGiGroup steps take the general path)
   float fjt[64];
+  float fjc[64];  // fjt with the entries past the last step (step - 1 - start) repeating the last one
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -710,7 +711,7 @@ __device__ __forceinline__ void march2_cert(const GiParams& p, const FastPix& c,
     // bring a wait on the counter they share, i.e. on the lookups
     float fjs[kGroup];
 #pragma unroll
-    for (int g = 0; g < kGroup; g++) fjs[g] = p.fjt[j0 - p.start + g];
+    for (int g = 0; g < kGroup; g++) fjs[g] = p.fjc[j0 - p.start + g];
     asm volatile("" : "+s"(fjs[0]), "+s"(fjs[1]), "+s"(fjs[2]), "+s"(fjs[3]));
     // phase A: every sample of the group up to its table lookup; no branches
 #pragma unroll
@@ -750,13 +751,16 @@ __device__ __forceinline__ void march2_cert(const GiParams& p, const FastPix& c,
         cert[k][g] = above | (below & pos[k]);
       }
     }
-    // phase B: in ray order, the exact part for the samples some lane of the wave still needs (~8 % of them: the
-    // lookup is waited for on the spot, other waves cover the latency)
+    // phase B: each ray's samples in order (the two rays are independent), the exact part for the samples some lane of
+    // the wave still needs (~8 % of them: the lookup is waited for on the spot, other waves cover the latency).  A group
+    // that runs past the last step repeats the last sample (fjc): repeating a sample changes nothing -- a ray it closed is
+    // closed, one it left open it leaves open again -- so there is no per-sample range test.
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int g = 0; g < kGroup; g++) {
+      if (((open_m[0] & ~cert[0][g]) | (open_m[1] & ~cert[1][g])) == 0ull) continue;  // one scalar test per sample pair
 #pragma unroll
-      for (int g = 0; g < kGroup; g++) {
-        const u64 need = (j0 + g) < p.step ? (open_m[k] & ~cert[k][g]) : 0ull;
+      for (int k = 0; k < 2; k++) {
+        const u64 need = open_m[k] & ~cert[k][g];
         if (need != 0ull) {
           const f32x2 t = tb[k][g] * cp.scale;  // exact: the pixel coordinates the uncertified march computes
           const int ix = cvt_flr(t.x);
@@ -1107,6 +1111,7 @@ static GiParams make_params(int W, int H, float fx, float fy, float radius, floa
   if (step - start > 64 - kGiGroup) pow2 = false;  // a partial last group may index kGiGroup - 1 entries past step - 1
   // j / step: exact for a power-of-two step; otherwise the correctly rounded quotient (read by the fast marches only)
   for (int k = 0; k < 64; k++) p.fjt[k] = pow2 ? (float)(start + k) * p.inv_step : (float)(start + k) / (float)step;
+  for (int k = 0; k < 64; k++) p.fjc[k] = p.fjt[k < step - 1 - start ? k : (step - 1 - start > 0 ? step - 1 - start : 0)];
   // GIGS_GI_TILE_LOG2W: tuning knob for the pixel rectangle of a workgroup (3 = 8x8 ... 6 = 64x1)
   const char* e = getenv("GIGS_GI_TILE_LOG2W");
   p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
