@@ -336,11 +336,11 @@ __device__ __forceinline__ void bitonic_sort_asc(unsigned n, unsigned npad_log2,
 // persistent grid strides over the order, skips the longer lists in front and stops at the first list that is too short
 // (a grid of T workgroups that mostly return at once costs more in dispatch than the sorting when each reserves its LDS).
 // one tile of up to 1024 * kItems keys: rocPRIM block radix sort, keys in registers (blocked arrangement)
-template <int kItems, typename Storage>
+template <int kItems, typename Storage, int kBlock = 1024>
 __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t* __restrict__ src, unsigned n, unsigned idx_bits,
                                                 uint64_t tile_hi, uint32_t base, uint64_t* __restrict__ keys_out,
                                                 uint32_t* __restrict__ point_list) {
-  using sorter = rocprim::block_radix_sort<uint64_t, 1024, kItems, rocprim::empty_type, 1, 1, 8>;
+  using sorter = rocprim::block_radix_sort<uint64_t, kBlock, kItems, rocprim::empty_type, 1, 1, 8>;
   const uint64_t idx_mask = (1ull << idx_bits) - 1;
   uint64_t k[kItems];
 #pragma unroll
@@ -367,17 +367,37 @@ __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t
 // CU costs tens of microseconds either way, so what matters is that long and short lists are in flight together (one launch
 // per size class, the first layout, ran them one after the other: 190 us at C2).  Lists beyond 16384 keys are sorted in
 // place in global memory with the all-ascending bitonic network (L2-resident; rare: dense scenes take the global radix sort).
-using SortS1 = rocprim::block_radix_sort<uint64_t, 1024, 1, rocprim::empty_type, 1, 1, 8>::storage_type;
 using SortS4 = rocprim::block_radix_sort<uint64_t, 1024, 4, rocprim::empty_type, 1, 1, 8>::storage_type;
 using SortS8 = rocprim::block_radix_sort<uint64_t, 1024, 8, rocprim::empty_type, 1, 1, 8>::storage_type;
 using SortS16 = rocprim::block_radix_sort<uint64_t, 1024, 16, rocprim::empty_type, 1, 1, 8>::storage_type;
+
+// The short lists -- two thirds of the tiles of a frame -- are sorted by 256-lane workgroups (8 keys per lane, 18 KB of LDS:
+// eight of them per CU instead of two 1024-lane ones, whose sixteen waves mostly wait at the passes' barriers).  The grid
+// walks tile_order from its short end and stops at the first list that belongs to bin_sort_kernel.
+constexpr unsigned kSmallList = 2048;
+using SortSmall = rocprim::block_radix_sort<uint64_t, 256, 8, rocprim::empty_type, 1, 1, 8>::storage_type;
+__global__ void __launch_bounds__(256)
+bin_sort_small_kernel(int T, unsigned idx_bits, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+                      const uint64_t* __restrict__ keys_unsorted, uint64_t* __restrict__ keys_out,
+                      uint32_t* __restrict__ point_list) {
+  __shared__ SortSmall storage;
+  for (int ob = T - 1 - (int)blockIdx.x; ob >= 0; ob -= (int)gridDim.x) {
+    const uint32_t tile = tile_order[ob];
+    const uint2 rg = ranges[tile];
+    const unsigned n = rg.y - rg.x;
+    if (n > kSmallList) break;  // ascending from this end: the rest is bin_sort_kernel's
+    if (n == 0) continue;
+    sort_tile_radix<8, SortSmall, 256>(storage, keys_unsorted + rg.x, n, idx_bits, (uint64_t)tile << 32, rg.x, keys_out,
+                                       point_list);
+  }
+}
 
 template <bool kBig>
 __global__ void __launch_bounds__(1024)
 bin_sort_kernel(int T, unsigned idx_bits, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                 uint64_t* __restrict__ keys_unsorted, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ point_list) {
   __shared__ union SortStorage {
-    SortS1 s1; SortS4 s4; SortS8 s8;
+    SortS4 s4; SortS8 s8;
     char big[kBig ? sizeof(SortS16) : 8];
     __device__ SortStorage() {}
   } storage;
@@ -386,7 +406,7 @@ bin_sort_kernel(int T, unsigned idx_bits, const uint32_t* __restrict__ tile_orde
     const uint32_t tile = tile_order[ob];
     const uint2 rg = ranges[tile];
     const unsigned n = rg.y - rg.x;
-    if (kBig ? n <= kSplit : n == 0) break;  // tile_order is descending: nothing further for this kernel
+    if (kBig ? n <= kSplit : n <= kSmallList) break;  // tile_order is descending: nothing further for this kernel
     if (!kBig && n > kSplit) continue;
     uint64_t* src = keys_unsorted + rg.x;
     const uint64_t tile_hi = (uint64_t)tile << 32;
@@ -406,8 +426,7 @@ bin_sort_kernel(int T, unsigned idx_bits, const uint32_t* __restrict__ tile_orde
         }
       }
     } else {
-      if (n <= 1024) sort_tile_radix<1>(storage.s1, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
-      else if (n <= 4096) sort_tile_radix<4>(storage.s4, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
+      if (n <= 4096) sort_tile_radix<4>(storage.s4, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
       else sort_tile_radix<8>(storage.s8, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
     }
   }
@@ -465,6 +484,8 @@ int launch_bin_sort(int T, int P, const BinningState& b, const ImageState& img, 
   hipLaunchKernelGGL(bin_sort_kernel<true>, dim3(std::min(T, 256)), dim3(1024), 0, s, T, ib, img.tile_order, img.ranges,
                      b.keys_unsorted, b.keys, b.point_list);
   hipLaunchKernelGGL(bin_sort_kernel<false>, dim3(std::min(T, 512)), dim3(1024), 0, s, T, ib, img.tile_order, img.ranges,
+                     b.keys_unsorted, b.keys, b.point_list);
+  hipLaunchKernelGGL(bin_sort_small_kernel, dim3(std::min(T, 2048)), dim3(256), 0, s, T, ib, img.tile_order, img.ranges,
                      b.keys_unsorted, b.keys, b.point_list);
   return 0;
 }

@@ -430,7 +430,9 @@ class WholeStepGraph:
             # executor does not turn that into dispatch order (blend backward still 0.54 ms), see the delay node below
             prio = os.environ.get("GIGS_STEP_GRAPH_PRIO", "0") == "1"
             cap = torch.cuda.Stream(device=self.dev, priority=-1) if prio else None
-            with torch.cuda.graph(gf, stream=cap):
+            # thread_local: a re-capture (binning overflow) may happen while RCCL's proxy thread is alive and issuing HIP
+            # calls of its own, which the default (global) capture mode turns into a capture failure
+            with torch.cuda.graph(gf, stream=cap, capture_error_mode="thread_local"):
                 with self.bin:
                     res = self.inner(self.s_cam, g, self.s_gt, self.s_vd)
                 self.bin.host.copy_(self.bin.counters, non_blocking=True)
@@ -443,7 +445,7 @@ class WholeStepGraph:
             import pbr.renderutils.ops as light_ops
             light_ops.bwd_head_start_ns = int(1e3 * float(os.environ.get("GIGS_LIGHT_BWD_HEAD_START_US", "10")))
             try:
-                with torch.cuda.graph(gb, pool=gf.pool(), stream=cap):
+                with torch.cuda.graph(gb, pool=gf.pool(), stream=cap, capture_error_mode="thread_local"):
                     grads = torch.autograd.grad(loss, params + [res["viewspace_points"]], allow_unused=True)
             finally:
                 light_ops.bwd_head_start_ns = 0
