@@ -415,3 +415,77 @@ def test_merged_level_filter_equals_per_level(base, monkeypatch):
     for a, b in zip(res["1"][0], res["0"][0]):
         assert torch.equal(a, b)
     assert torch.equal(res["1"][1], res["0"][1])
+
+
+def test_whole_step_graph_gradient_semantics_and_recapture(monkeypatch):
+    """pipeline.WholeStepGraph hands its gradients out with loss.backward()'s semantics and follows the parameters:
+    (1) `.grad is None` before the step -> the fresh gradient; (2) an existing `.grad` (gradient accumulation over views)
+    -> old + new; (3) a parameter tensor replaced by another one (densification) -> one re-capture, results as eager."""
+    import pbr
+    import pipeline
+    monkeypatch.setenv("GIGS_STEP_GRAPH", "1")
+    monkeypatch.setenv("GIGS_RASTER_GRAPH", "0")
+    sc = scenes.surface_scene(P=8000, sh_degree=2, seed=21, scale_mu=0.025)
+    gi = scenes.GI_DEFAULTS
+    H, W = 176, 224
+    cams = [scenes.orbit_camera(i, 6, W, H, radius=3.5) for i in (0, 3)]
+    camts = [{k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    torch.manual_seed(4)
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    rays = pipeline.canonical_rays(cams[0], DEV)
+    vds = [pipeline.view_dirs_for(c, rays, DEV) for c in camts]
+    keys = ("albedo", "roughness", "metallic")
+
+    def fresh():
+        torch.manual_seed(6)
+        light = pbr.CubemapLight(base_res=64, device=DEV)
+        g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        return light, g
+
+    def grads(g, light):
+        return {**{k: g[k].grad.clone() for k in keys}, "light": light.base.grad.clone()}
+
+    # eager reference: the two views separately
+    light, g = fresh()
+    eager = pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=False)
+    ref = []
+    for ci in (0, 1):
+        for t in list(g.values()) + [light.base]:
+            t.grad = None
+        o = eager(camts[ci], g, gt, vds[ci])
+        torch.cuda.synchronize()
+        ref.append((float(o["loss"]), grads(g, light)))
+
+    light, g = fresh()
+    step = pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=True)
+    o = step(camts[0], g, gt, vds[0])  # (1)
+    torch.cuda.synchronize()
+    assert step.whole is not None and step.whole.recaptures == 1
+    assert abs(float(o["loss"]) - ref[0][0]) <= 2e-6 * max(1.0, abs(ref[0][0]))
+    got = grads(g, light)
+    for k in got:
+        assert rel_peak(got[k].cpu().numpy(), ref[0][1][k].cpu().numpy()) < 2e-3, k
+    # (2) keep the gradients of view 0, step on view 1: the sum of both
+    keep = {k: v.clone() for k, v in got.items()}
+    for k in keys:
+        g[k].grad = keep[k].clone()
+    light.base.grad = keep["light"].clone()
+    step(camts[1], g, gt, vds[1])
+    torch.cuda.synchronize()
+    assert step.whole.recaptures == 1
+    acc = grads(g, light)
+    for k in acc:
+        want = (ref[0][1][k] + ref[1][1][k]).cpu().numpy()
+        assert rel_peak(acc[k].cpu().numpy(), want) < 2e-3, k
+    # (3) a replaced parameter tensor (same values): one re-capture, same results
+    g["albedo"] = g["albedo"].detach().clone().requires_grad_(True)
+    for t in list(g.values()) + [light.base]:
+        t.grad = None
+    o = step(camts[1], g, gt, vds[1])
+    torch.cuda.synchronize()
+    assert step.whole.recaptures == 2
+    assert abs(float(o["loss"]) - ref[1][0]) <= 2e-6 * max(1.0, abs(ref[1][0]))
+    got = grads(g, light)
+    for k in got:
+        assert rel_peak(got[k].cpu().numpy(), ref[1][1][k].cpu().numpy()) < 2e-3, k
