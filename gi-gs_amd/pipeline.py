@@ -590,7 +590,7 @@ class Stage2Step:
         self.graphs = graphs
         self._captured = False
         self._defer_backward = False  # WholeStepGraph's inner step: return the attached loss, the caller differentiates
-        self.whole = None
+        self.whole, self._wholes = None, {}
 
     def _capture(self, front_args, loss_args):
         def clone(args):
@@ -607,12 +607,19 @@ class Stage2Step:
         if (self.fused and self.graphs and extra_loss is None and os.environ.get("GIGS_STEP_GRAPH", "1") == "1"
                 and os.environ.get("GIGS_RASTER_GRAPH", "0") != "1" and not getattr(self, "_dense", False)):
             try:
-                if self.whole is None:
-                    self.whole = WholeStepGraph(self, cam, g)
-                return self.whole(cam, g, gt_image, view_dirs)
+                # one capture per (image size, field of view): datasets with per-camera intrinsics keep a few of them
+                cfg = (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"]))
+                if self.whole is None or self.whole.cfg != cfg:
+                    self.whole = self._wholes.get(cfg)
+                    if self.whole is None and len(self._wholes) < 4:
+                        self.whole = self._wholes[cfg] = WholeStepGraph(self, cam, g)
+                if self.whole is not None:
+                    return self.whole(cam, g, gt_image, view_dirs)
+                # more than four distinct camera models: the fifth onwards takes the piecewise path below
             except DenseScene:
                 self._dense = True  # synchronous binning with the global radix sort: the rasterizer stays eager
                 self.whole = None
+                self._wholes.clear()
         if self.fused and self.graphs and os.environ.get("GIGS_RASTER_GRAPH", "0") == "1" and not getattr(self, "_dense", False):
             try:
                 return self._graphed_step(cam, g, gt_image, view_dirs, extra_loss)

@@ -489,3 +489,19 @@ def test_whole_step_graph_gradient_semantics_and_recapture(monkeypatch):
     got = grads(g, light)
     for k in got:
         assert rel_peak(got[k].cpu().numpy(), ref[1][1][k].cpu().numpy()) < 2e-3, k
+    # (4) another image size: a second capture beside the first, which stays valid
+    H2, W2 = 144, 176
+    cam2 = scenes.orbit_camera(2, 6, W2, H2, radius=3.5)
+    camt2 = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam2.items()}
+    gt2 = torch.rand(3, H2, W2, device=DEV) * 0.5
+    vd2 = pipeline.view_dirs_for(camt2, pipeline.canonical_rays(cam2, DEV), DEV)
+    for t in list(g.values()) + [light.base]:
+        t.grad = None
+    o2 = step(camt2, g, gt2, vd2)
+    torch.cuda.synchronize()
+    assert tuple(o2["render_rgb"].shape[-2:]) == (H2, W2) and len(step._wholes) == 2
+    for t in list(g.values()) + [light.base]:
+        t.grad = None
+    o = step(camts[1], g, gt, vds[1])
+    torch.cuda.synchronize()
+    assert step.whole.recaptures == 2 and abs(float(o["loss"]) - ref[1][0]) <= 2e-6 * max(1.0, abs(ref[1][0]))
