@@ -459,22 +459,26 @@ class WholeStepGraph:
         self.recaptures += 1
 
     def _pack(self, cam):
-        # (viewmatrix, projmatrix, campos) flattened into one tensor, built once per camera (training loops revisit them)
-        key = tuple((cam[k].data_ptr(), cam[k]._version) for k in self.CAM_TENSORS)
-        pk = self._packs.get(key)
-        if pk is None:
-            if len(self._packs) >= 8192:
+        # (viewmatrix, projmatrix, campos) flattened into one tensor, built once per camera (training loops revisit them).
+        # The cache entry keeps the source tensors alive: a key of (address, version) alone could be met again by a NEW
+        # tensor that the allocator placed at a freed one's address.
+        src = tuple(cam[k] for k in self.CAM_TENSORS)
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        hit = self._packs.get(key)
+        if hit is None or any(a is not b for a, b in zip(hit[1], src)):
+            if len(self._packs) >= 4096:
                 self._packs.clear()
-            pk = torch.cat([cam[k].detach().reshape(-1).float() for k in self.CAM_TENSORS])
-            self._packs[key] = pk
-        return pk
+            hit = (torch.cat([t.detach().reshape(-1).float() for t in src]), src)
+            self._packs[key] = hit
+        return hit[0]
 
     def _fill(self, name, static, src):
         # per-view constants come back every n_views steps and gt_image is often one tensor: skip what is already there
-        tag = (src.data_ptr(), src._version)
-        if self._src.get(name) != tag:
+        # (the reference to the last source keeps its address from being reused by a different tensor)
+        last = self._src.get(name)
+        if last is None or last[0] is not src or last[1] != src._version:
             static.copy_(src, non_blocking=True)
-            self._src[name] = tag
+            self._src[name] = (src, src._version)
 
     def __call__(self, cam, g, gt_image, view_dirs):
         if (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"])) != self.cfg:
