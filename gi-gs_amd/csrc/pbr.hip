@@ -796,6 +796,7 @@ struct ShadeArgs {
   float rough_scale, rough_bias;
   float *out_F0, *out_linear, *out_roughness;
   const float *g_albedo_mul_a, *g_albedo_mul_b, *g_roughness_add, *g_metallic_add;
+  const float *g_scale, *lamb_mask, *lamb_acc4;
 };
 
 __device__ __forceinline__ float get_mip(float r, int L, float& dmip_dr) {  // pbr/light.py:142-152
@@ -986,12 +987,13 @@ shade_bwd_kernel(ShadeArgs A) {
   if (live) {
     const bool mk = A.mask[p] != 0;
     const size_t e = (size_t)p * A.ps, cs = A.cs;
+    const float gscale = A.g_scale ? A.g_scale[0] : 1.0f;  // x * 1.0f is exact: the plain operator is unchanged
     float g_d[3] = {0, 0, 0}, g_s[3] = {0, 0, 0};  // grads w.r.t. linear diffuse_rgb / specular_rgb
     const float pre_d[3] = {q.drgb.x, q.drgb.y, q.drgb.z}, pre_s[3] = {q.srgb.x, q.srgb.y, q.srgb.z};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       // render = where(mask, gamma(clamp(tone(d + s))), bg)
-      float g = (A.g_render && mk) ? A.g_render[e + c * cs] : 0.0f;
+      float g = (A.g_render && mk) ? A.g_render[e + c * cs] * gscale : 0.0f;
       if (g != 0.0f) {
         float x = pre_d[c] + pre_s[c], d_tone = 1.0f, d_gam = 1.0f;
         if (A.tone) x = aces(x, d_tone);
@@ -1034,12 +1036,18 @@ shade_bwd_kernel(ShadeArgs A) {
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      if (A.g_albedo_mul_a) d_alb[c] += A.g_albedo_mul_a[e + c * cs] * A.g_albedo_mul_b[e + c * cs];
+      if (A.g_albedo_mul_a) d_alb[c] += (A.g_albedo_mul_a[e + c * cs] * gscale) * A.g_albedo_mul_b[e + c * cs];
       A.d_albedo[e + c * cs] = d_alb[c];
     }
-    if (A.d_metallic) A.d_metallic[p] = d_m + (A.g_metallic_add ? A.g_metallic_add[p] : 0.0f);
+    float add_r = A.g_roughness_add ? A.g_roughness_add[p] : 0.0f, add_m = A.g_metallic_add ? A.g_metallic_add[p] : 0.0f;
+    if (A.lamb_mask) {  // stage2_loss_bwd_kernel's two lines
+      const float m = A.lamb_mask[p], cnt = A.lamb_acc4[3];
+      add_r += -m / cnt * (0.001f * gscale);
+      add_m += m / cnt * (0.001f * gscale);
+    }
+    if (A.d_metallic) A.d_metallic[p] = d_m + add_m;
     const float d_r = d_fgx * q.dfgx_dv + d_fgy * q.dfgy_dv + (q.lvl_inside ? d_lvl * q.dmdr : 0.0f);
-    A.d_roughness[p] = (d_r + (A.g_roughness_add ? A.g_roughness_add[p] : 0.0f)) * A.rough_scale;
+    A.d_roughness[p] = (d_r + add_r) * A.rough_scale;
   }
   // ---- light textures (wave-uniform control flow from here on) ----
   if (A.d_diffuse && !(A.ablate & 1)) {
@@ -1350,6 +1358,9 @@ static int apply_shade_ext(gigs::ShadeArgs& A, const gigs_shade_ext* ext, bool b
       return gigs_internal_fail(GIGS_ERR_INVALID, "shade_bwd: g_albedo_mul_a/b must be given together");
     A.g_albedo_mul_a = ext->g_albedo_mul_a; A.g_albedo_mul_b = ext->g_albedo_mul_b;
     A.g_roughness_add = ext->g_roughness_add; A.g_metallic_add = ext->g_metallic_add;
+    if ((ext->lamb_mask == nullptr) != (ext->lamb_acc4 == nullptr))
+      return gigs_internal_fail(GIGS_ERR_INVALID, "shade_bwd: lamb_mask / lamb_acc4 must be given together");
+    A.g_scale = ext->g_scale; A.lamb_mask = ext->lamb_mask; A.lamb_acc4 = ext->lamb_acc4;
   }
   return 0;
 }

@@ -211,7 +211,8 @@ __global__ void __launch_bounds__(256)
 stage2_loss_fwd_kernel(int H, int W, const float* __restrict__ direct, const float* __restrict__ irr,
                        const float* __restrict__ gt, const float* __restrict__ mask_f,
                        const float* __restrict__ roughness, const float* __restrict__ metallic,
-                       float* __restrict__ render_rgb, float* __restrict__ acc) {
+                       float* __restrict__ render_rgb, float* __restrict__ acc, float* __restrict__ d_direct_unit,
+                       float* __restrict__ d_irr_unit) {
   __shared__ float s_red[4];
   __shared__ float s_t[3][kHaloH][kHaloW];
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
@@ -225,10 +226,39 @@ stage2_loss_fwd_kernel(int H, int W, const float* __restrict__ direct, const flo
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       LossTaps t = srgb_taps(s_t[c], ly, lx);
-      const float med = t.has_nan ? __builtin_nanf("") : median9(t.v);
+      float sorted[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) sorted[k] = t.v[k];
+      const float med = t.has_nan ? __builtin_nanf("") : median9(sorted);
       const float r = direct[c * HW + p] + med;
       if (render_rgb) render_rgb[c * HW + p] = r;
-      l1 += fabsf(r - gt[c * HW + p]);
+      const float diff = r - gt[c * HW + p];
+      l1 += fabsf(diff);
+      if (d_direct_unit) {
+        // stage2_loss_bwd_kernel's work for a unit upstream gradient, on the tile and the median this pass already has
+        const float gs = 1.0f / (3.0f * (float)H * (float)W);
+        const float sgn = diff > 0.0f ? gs : (diff < 0.0f ? -gs : 0.0f);  // d|x| = sign(x), 0 at 0 and for NaN
+        d_direct_unit[c * HW + p] = sgn;
+        if (!(t.has_nan || sgn == 0.0f)) {
+          // the whole gradient goes to the first tap (row-major) equal to the median (median3x3_bwd_kernel)
+          int k = 0;
+          bool routed = false;
+          for (int dy = -1; dy <= 1 && !routed; dy++)
+            for (int dx = -1; dx <= 1; dx++, k++) {
+              if (t.v[k] == med) {
+                const int yy = y + dy, xx = x + dx;
+                if (!(yy < 0 || yy >= H || xx < 0 || xx >= W)) {
+                  const size_t q = (size_t)yy * W + xx;
+                  float d;
+                  lin2srgb(irr[c * HW + q], d);
+                  if (d != 0.0f) atomicAdd(d_irr_unit + c * HW + q, sgn * d);
+                }
+                routed = true;  // a padding tap selected: the gradient is dropped
+                break;
+              }
+            }
+        }
+      }
     }
     const float m = mask_f[p];
     rs = (1.0f - roughness[p]) * m;
@@ -390,10 +420,32 @@ int gigs_stage2_loss_fwd(int height, int width, const float* render_direct, cons
   float* rows = acc4 + 4;  // [kAccSlots][4] partial sums behind the four totals
   gigs::launch_zero(rows, 4 * gigs::kAccSlots, s);
   hipLaunchKernelGGL(gigs::stage2_loss_fwd_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, s, height,
-                     width, render_direct, irr_linear, gt_image, normal_mask_f, roughness, metallic, render_rgb, rows);
+                     width, render_direct, irr_linear, gt_image, normal_mask_f, roughness, metallic, render_rgb, rows,
+                     (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(gigs::stage2_loss_finish_kernel, dim3(1), dim3(64), 0, s, height, width, rows, acc4, loss);
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "stage2_loss_fwd: launch failed");
+  return 0;
+}
+
+int gigs_stage2_loss_fwd_grad(int height, int width, const float* render_direct, const float* irr_linear,
+                              const float* gt_image, const float* normal_mask_f, const float* roughness,
+                              const float* metallic, float* render_rgb, float* acc4, float* loss,
+                              float* d_render_direct_unit, float* d_irr_linear_unit, void* stream) {
+  if (height <= 0 || width <= 0 || !render_direct || !irr_linear || !gt_image || !normal_mask_f || !roughness ||
+      !metallic || !acc4 || !loss || !d_render_direct_unit || !d_irr_linear_unit)
+    return gigs_internal_fail(GIGS_ERR_INVALID, "stage2_loss_fwd_grad: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  void* tok; gigs_internal_stage_begin(19, stream, &tok);
+  float* rows = acc4 + 4;
+  gigs::launch_zero(rows, 4 * gigs::kAccSlots, s);
+  gigs::launch_zero(d_irr_linear_unit, 3 * (size_t)height * width, s);
+  hipLaunchKernelGGL(gigs::stage2_loss_fwd_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, s, height,
+                     width, render_direct, irr_linear, gt_image, normal_mask_f, roughness, metallic, render_rgb, rows,
+                     d_render_direct_unit, d_irr_linear_unit);
+  hipLaunchKernelGGL(gigs::stage2_loss_finish_kernel, dim3(1), dim3(64), 0, s, height, width, rows, acc4, loss);
+  gigs_internal_stage_end(tok);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "stage2_loss_fwd_grad: launch failed");
   return 0;
 }
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "gigs_normalize_mask": (_i, [_i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_stage2_loss_fwd_grad": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_cube_texture_fwd": (_i, [_i, _f, _i, _f, _f, _i, C.c_void_p]),
     "gigs_cube_texture_bwd": (_i, [_i, _i, _f, _f, _f, _i, C.c_void_p]),
     "gigs_latlong_to_cubemap": (_i, [_i, _i, _i, _i, _i, _f, _f, C.c_void_p]),
@@ -117,7 +118,8 @@ class ShadeExt(C.Structure):
     _fields_ = [("planar", C.c_int), ("rough_scale", C.c_float), ("rough_bias", C.c_float),
                 ("out_F0", C.c_void_p), ("out_linear", C.c_void_p), ("out_roughness", C.c_void_p),
                 ("g_albedo_mul_a", C.c_void_p), ("g_albedo_mul_b", C.c_void_p),
-                ("g_roughness_add", C.c_void_p), ("g_metallic_add", C.c_void_p)]
+                ("g_roughness_add", C.c_void_p), ("g_metallic_add", C.c_void_p),
+                ("g_scale", C.c_void_p), ("lamb_mask", C.c_void_p), ("lamb_acc4", C.c_void_p)]
 
 
 class SpecLevel(C.Structure):

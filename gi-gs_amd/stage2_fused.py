@@ -3,8 +3,9 @@
 The reference expresses this stretch of train.py (:293-402) as ~120 torch ops forward and as many
 backward; `pipeline.Stage2Front` / `pipeline.stage2_loss` restate it op by op.  Here the same
 arithmetic runs as five kernels forward (gigs_gbuffer_post, gigs_shade_fwd_ex, gigs_ssr,
-gigs_stage2_loss_fwd + its 1-thread finish) and two backward (gigs_stage2_loss_bwd,
-gigs_shade_bwd_ex), all reading and writing the rasterizer's [C,H,W] planes directly.
+gigs_stage2_loss_fwd_grad + its 1-thread finish) and ONE backward (gigs_shade_bwd_ex: the loss's
+gradient planes are written by the forward pass for a unit upstream gradient and scaled there),
+all reading and writing the rasterizer's [C,H,W] planes directly.
 
 Gradients leave through exactly the tensors train.py differentiates: albedo_map, roughness_map,
 metallic_map (-> the rasterizer's backward) and light.diffuse / light.specular (-> build_mips'
@@ -77,11 +78,14 @@ class _Stage2Fused(torch.autograd.Function):
             # Gaussian_SSR (train.py:370-379); its backward is closed-form (grad_albedo = grad * abd)
             IRR, abd = _ops.SSR(W, H, cfg["focal_x"], cfg["focal_y"], gi["radius"], gi["bias"], gi["thick"], gi["delta"],
                                 gi["step"], gi["start"], onv, depth_pos, linear_rgb, albedo_map, rough_f, metallic_f, F0)
-            gigs_lib.check(_lib.gigs_stage2_loss_fwd(H, W, _p(render_direct), _p(IRR), _p(gt_image), _p(mask_f),
-                                                     _p(rough_f), _p(metallic_f), _p(render_rgb), _p(acc4), _p(loss), s),
-                           "stage2_loss_fwd")
+            # the loss and, in the same pass over the image, its gradients w.r.t. render_direct / IRR for a unit upstream
+            # gradient (the backward then has no loss kernel: gigs_shade_bwd_ex scales them and forms the lamb terms)
+            d_direct_u, d_irr_u = new(3, H, W), new(3, H, W)
+            gigs_lib.check(_lib.gigs_stage2_loss_fwd_grad(H, W, _p(render_direct), _p(IRR), _p(gt_image), _p(mask_f),
+                                                          _p(rough_f), _p(metallic_f), _p(render_rgb), _p(acc4), _p(loss),
+                                                          _p(d_direct_u), _p(d_irr_u), s), "stage2_loss_fwd_grad")
         ctx.save_for_backward(normals_view, view_dirs, albedo_map, roughness_map, mask_u8, mask_f, occlusion,
-                              metallic_map if use_metallic else None, lut, diffuse, render_direct, IRR, abd, gt_image,
+                              metallic_map if use_metallic else None, lut, diffuse, d_direct_u, d_irr_u, abd,
                               acc4, *specular)
         ctx.cfg = cfg
         ctx.need_light = (ctx.needs_input_grad[12], [ctx.needs_input_grad[13 + i] for i in range(len(specular))])
@@ -92,7 +96,7 @@ class _Stage2Fused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *_unused):
         (normals_view, view_dirs, albedo_map, roughness_map, mask_u8, mask_f, occlusion, metallic_map, lut, diffuse,
-         render_direct, IRR, abd, gt_image, acc4, *specular) = ctx.saved_tensors
+         d_direct_u, d_irr_u, abd, acc4, *specular) = ctx.saved_tensors
         cfg = ctx.cfg
         dev = albedo_map.device
         H, W = int(cfg["H"]), int(cfg["W"])
@@ -100,7 +104,6 @@ class _Stage2Fused(torch.autograd.Function):
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_loss = g_loss.contiguous().float()
-        d_direct, d_irr, d_rough_add, d_metal_add = new(3, H, W), new(3, H, W), new(1, H, W), new(1, H, W)
         d_albedo, d_rough = new(3, H, W), new(1, H, W)
         d_metal = new(1, H, W) if metallic_map is not None else None
         need_d, need_s = ctx.need_light
@@ -114,18 +117,15 @@ class _Stage2Fused(torch.autograd.Function):
         d_diffuse, d_spec = views[0], views[1:]
         spec_ptr, dspec_ptr = _ptr_array(specular), _ptr_array(d_spec)
         spec_res = (C.c_int * len(specular))(*[int(s.shape[1]) for s in specular])
-        ext = gigs_lib.ShadeExt(planar=1, rough_scale=1.0 - 0.04, rough_bias=0.04, g_albedo_mul_a=_p(d_irr),
-                                g_albedo_mul_b=_p(abd), g_roughness_add=_p(d_rough_add),
-                                g_metallic_add=_p(d_metal_add) if metallic_map is not None else None)
+        # unit-gradient planes from the forward, scaled by g_loss inside the kernel; lamb terms formed there too
+        ext = gigs_lib.ShadeExt(planar=1, rough_scale=1.0 - 0.04, rough_bias=0.04, g_albedo_mul_a=_p(d_irr_u),
+                                g_albedo_mul_b=_p(abd), g_scale=_p(g_loss), lamb_mask=_p(mask_f), lamb_acc4=_p(acc4))
         with torch.cuda.device(dev):
             s = _stream()
-            gigs_lib.check(_lib.gigs_stage2_loss_bwd(H, W, _p(render_direct), _p(IRR), _p(gt_image), _p(mask_f), _p(acc4),
-                                                     _p(g_loss), _p(d_direct), _p(d_irr), _p(d_rough_add), _p(d_metal_add),
-                                                     s), "stage2_loss_bwd")
             gigs_lib.check(_lib.gigs_shade_bwd_ex(
                 H, W, _p(normals_view), _p(view_dirs), _p(albedo_map), _p(roughness_map), _p(mask_u8), _p(occlusion),
                 _p(metallic_map), _p(diffuse), int(diffuse.shape[1]), len(specular), spec_ptr, spec_res, _p(lut),
-                int(lut.shape[-2]), int(lut.shape[-3]), int(bool(cfg["tone"])), int(bool(cfg["gamma"])), _p(d_direct),
+                int(lut.shape[-2]), int(lut.shape[-3]), int(bool(cfg["tone"])), int(bool(cfg["gamma"])), _p(d_direct_u),
                 None, None, None, _p(d_albedo), _p(d_rough), _p(d_metal), _p(d_diffuse), dspec_ptr, C.addressof(ext), s),
                 "shade_bwd_ex")
         return (None, None, None, d_albedo, d_rough, d_metal, None, None, None, None, None, None, d_diffuse, *d_spec)

@@ -247,13 +247,18 @@ int gigs_shade_bwd(int H, int W, const float* normals, const float* view_dirs, c
  *   backward extras (may be NULL): d_albedo += g_albedo_mul_a * g_albedo_mul_b (Gaussian_SSR's closed-form
  *                  backward grad_out * abd, R/diff_gaussian_rasterization/__init__.py:671-673);
  *                  g_roughness_add / g_metallic_add [H,W] are added to the roughness (remapped) / metallic
- *                  gradients (the lamb regulariser, train.py:401-402).
+ *                  gradients (the lamb regulariser, train.py:401-402);
+ *                  g_scale (device scalar, NULL = 1): g_render and g_albedo_mul_a are gradients for a UNIT upstream
+ *                  gradient (gigs_stage2_loss_fwd_grad writes them in the forward) and are multiplied by it here;
+ *                  lamb_mask [H,W] + lamb_acc4 (gigs_stage2_loss_fwd's acc4): the lamb regulariser's gradients
+ *                  -/+ mask / acc4[3] * 0.001 * g_scale are formed here instead of being read from g_*_add.
  * With ext != NULL diffuse_rgb / specular_rgb / diffuse_light may be NULL (not written). */
 typedef struct gigs_shade_ext {
   int planar;
   float rough_scale, rough_bias;
   float *out_F0, *out_linear, *out_roughness;
   const float *g_albedo_mul_a, *g_albedo_mul_b, *g_roughness_add, *g_metallic_add;
+  const float *g_scale, *lamb_mask, *lamb_acc4;
 } gigs_shade_ext;
 int gigs_shade_fwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
                       const float* roughness, const uint8_t* mask, const float* occlusion,
@@ -301,6 +306,15 @@ int gigs_stage2_loss_bwd(int height, int width, const float* render_direct, cons
                          const float* gt_image, const float* normal_mask_f, const float* acc4, const float* g_loss,
                          float* d_render_direct, float* d_irr_linear, float* d_roughness, float* d_metallic,
                          void* stream);
+/* gigs_stage2_loss_fwd that also writes, in the same pass over the image (the backward kernel would convert the same
+ * halo tiles and select the same medians again), the loss gradients w.r.t. render_direct and irr_linear for a unit
+ * upstream gradient ([3,H,W] each; d_irr_linear_unit is zeroed inside and accumulated with atomics through the median's
+ * tap selection).  gigs_shade_bwd_ex scales them (ext.g_scale) and forms the lamb terms (ext.lamb_*), so the stage-2
+ * backward needs no loss kernel. */
+int gigs_stage2_loss_fwd_grad(int height, int width, const float* render_direct, const float* irr_linear,
+                              const float* gt_image, const float* normal_mask_f, const float* roughness,
+                              const float* metallic, float* render_rgb, float* acc4, float* loss,
+                              float* d_render_direct_unit, float* d_irr_linear_unit, void* stream);
 
 /* dr.texture(cubemap[None], dirs[None], filter_mode="linear", boundary_mode="cube") (train.py:409-417, render.py:80,
  * relight.py:108) for n directions [n,3], sampled as the shade kernel samples light.diffuse (face by largest |axis|,
