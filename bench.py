@@ -303,14 +303,23 @@ def main():
         params_light = [p for p in light.parameters()]
     else:
         params_light = []
-    flat_params = [g[k] for k in PARAM_KEYS] + params_light
+    # slab order: the stage-2 trainable set (materials, then the light) last and adjacent, so that
+    # GIGS_BENCH_REDUCE=trainable can reduce it with ONE collective
+    SLAB_KEYS = ["means3D", "opacities", "normal", "shs", "scales", "rotations", "albedo", "roughness", "metallic"]
+    SINK_NAME = {"opacities": "opacity", "shs": "sh"}
+    flat_params = [g[k] for k in SLAB_KEYS] + params_light
+    reduce_only = None
+    if os.environ.get("GIGS_BENCH_REDUCE", "all") == "trainable" and args.config != "c3":
+        # opt-in (NOT the measured default): a stage-2 iteration's gradients w.r.t. everything but albedo / roughness /
+        # metallic and the light are identically zero on every rank (dp.GradSlab.allreduce_async(only=...))
+        reduce_only = list(range(SLAB_KEYS.index("albedo"), len(flat_params)))
     # multi-rank: every gradient lives in one persistent flat slab; the rasterizer's backward writes into it directly
     # (dgr.grad_sink), so the all-reduce bucket needs no packing pass
     slab = sink = None
     if use_dist:
         import diff_gaussian_rasterization as dgr_mod
         slab = dp.GradSlab(flat_params)
-        sink = slab.sink(["means3D", "opacity", "normal", "albedo", "roughness", "metallic", "sh", "scales", "rotations"])
+        sink = slab.sink([SINK_NAME.get(k, k) for k in SLAB_KEYS])
     force_coll = os.environ.get("GIGS_BENCH_FORCE_DIST", "0") == "1"
     stepper = relighter = None
     inference = args.config == "c3"
@@ -345,7 +354,7 @@ def main():
             # one flat bucket on the communication stream: xGMI is point-to-point, a single large all-reduce keeps every
             # link busy.  The step ends where an optimizer would read the reduced gradients, so the wait is part of it
             # (exact, no one-step gradient delay).
-            slab.allreduce_async(force=force_coll)
+            slab.allreduce_async(force=force_coll, only=reduce_only)
             slab.wait()
         return out
 
@@ -460,7 +469,8 @@ def main():
                                       else "whole step = 2 hand-captured hipGraphs (fwd, bwd), asynchronous binning"
                                       if (stepper is not None and getattr(stepper, "whole", None) is not None)
                                       else "eager launches, asynchronous binning (no host read-back)"),
-                       "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce" % world},
+                       "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce%s"
+                                      % (world, " of the stage-2 trainable set only (GIGS_BENCH_REDUCE=trainable)" if reduce_only else "")},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         if parity_rep is not None:

@@ -122,26 +122,57 @@ class GradSlab:
         if self.agree_presence:
             self.presence.copy_(torch.tensor(pres, dtype=torch.float32), non_blocking=True)
 
-    def allreduce_async(self, average: bool = False, force: bool = False) -> None:
+    def _ranges(self, only) -> List[torch.Tensor]:
+        """The slab as the fewest contiguous pieces that cover the parameters `only` (indices into the slab's order)."""
+        if only is None:
+            return [self.flat]
+        idx = sorted(set(int(i) for i in only))
+        pieces, k = [], 0
+        while k < len(idx):
+            j = k
+            while j + 1 < len(idx) and idx[j + 1] == idx[j] + 1:
+                j += 1
+            pieces.append(self.flat[self.offsets[idx[k]]:self.offsets[idx[j]] + self.params[idx[j]].numel()])
+            k = j + 1
+        return pieces
+
+    def allreduce_async(self, average: bool = False, force: bool = False, only: Optional[Sequence[int]] = None,
+                        check_rest_zero: bool = False) -> None:
         """Sum (or average) the slab over all ranks on the communication stream.  Parameters whose .grad is None
         here contribute zeros.  `force` issues the collective even with a single rank (a one-GPU rehearsal of the
-        whole code path: process group, communication stream, RCCL launch)."""
+        whole code path: process group, communication stream, RCCL launch).
+
+        `only` (indices into the slab's parameter order): reduce just these parameters' stretches of the slab -- for
+        steps whose other gradients are IDENTICALLY ZERO on every rank, e.g. a stage-2 iteration of train.py, where the
+        loss reaches only albedo / roughness / metallic and the light (the blend weights are detached from the material
+        planes: SURVEY App. D, tests/test_gpu_parity.py::test_backward_stage2_pattern_and_linearity); a sum of zeros is
+        zero, so the result equals the full reduction with 5 of 46 floats per Gaussian on the wire.  Adjacent parameters
+        share one collective (order the slab accordingly).  `check_rest_zero` verifies the premise (one device read)."""
         world = _world(self.group)
         if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
             self._pending = False
             return
         self._gather_stray()
         self._average = average
+        pieces = self._ranges(only)
+        if only is not None and check_rest_zero:
+            keep = set(int(i) for i in only)
+            rest = [v for i, v in enumerate(self.views) if i not in keep]
+            if rest and float(torch.stack([v.abs().max() for v in rest if v.numel()]).max()) != 0.0:
+                raise RuntimeError("GradSlab.allreduce_async(only=...): a parameter outside `only` has a non-zero gradient")
+        self._pieces = pieces
         if self._comm is not None:
             self._comm.wait_stream(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self._comm):
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                for piece in pieces:
+                    dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
                 if self.agree_presence:
                     dist.all_reduce(self.presence, op=dist.ReduceOp.MAX, group=self.group)
                 if average:
-                    self.flat.div_(world)
+                    for piece in pieces:
+                        piece.div_(world)
         else:  # CPU tensors (gloo tests): genuinely asynchronous work handles
-            self._work = [dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+            self._work = [dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for piece in pieces]
             if self.agree_presence:
                 self._work.append(dist.all_reduce(self.presence, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
         self._pending = True
@@ -157,7 +188,8 @@ class GradSlab:
                 w.wait()
             self._work = []
             if self._average:
-                self.flat.div_(_world(self.group))
+                for piece in self._pieces:
+                    piece.div_(_world(self.group))
         # agree_presence: one small read-back per step, after the collective; otherwise the local pattern is everyone's
         pres = self.presence.tolist() if self.agree_presence else self._local_presence
         for p, v, has in zip(self.params, self.views, pres):

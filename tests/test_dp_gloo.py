@@ -61,6 +61,26 @@ def _worker(rank, world, port, out_dir):
         assert params[0].grad.data_ptr() == slab.views[0].data_ptr() and params[2].grad.data_ptr() == slab.views[2].data_ptr()
         out.append(dict(local=local, reduced=[None if p.grad is None else p.grad.clone() for p in params[:4]], busy=float(busy.sum())))
 
+    # stage-2 pattern: only parameters 1 and 2 (adjacent: one collective) and 4 carry gradients, the others are exact zeros
+    slab5 = dp.GradSlab(params)
+    for p in params:
+        p.grad = None
+    slab5.attach()
+    part = [torch.randn(p.shape, generator=g) for p in params]
+    for i in (1, 2, 4):
+        params[i].grad.copy_(part[i])
+    assert len(slab5._ranges([1, 2, 4])) == 2
+    slab5.allreduce_async(only=[1, 2, 4], check_rest_zero=True)
+    slab5.wait()
+    only_out = dict(local=part, reduced=[p.grad.clone() for p in params])
+    params[0].grad.fill_(1.0)  # the premise is violated: the check notices
+    try:
+        slab5.allreduce_async(only=[1, 2, 4], check_rest_zero=True)
+        only_caught = False
+        slab5.wait()
+    except RuntimeError:
+        only_caught = True
+
     # statistics
     vg = torch.randn(P, 3, generator=g)
     radii = torch.randint(0, 30, (P,), generator=g)
@@ -82,7 +102,7 @@ def _worker(rank, world, port, out_dir):
     dens = {n: model["params"][n].clone() for n in densify_ref.NAMES}
     assert dens["xyz"].shape[0] != P  # something was cloned / split / pruned
     views = [dp.view_for(s, rank, world, 7) for s in range(5)]
-    torch.save(dict(conv=conv, local=grads, slab=out, vg=vg, radii=radii, stats=st, views=views, dens=dens),
+    torch.save(dict(conv=conv, local=grads, slab=out, only=only_out, only_caught=only_caught, vg=vg, radii=radii, stats=st, views=views, dens=dens),
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -107,6 +127,12 @@ def test_view_parallel_reduction_world2(tmp_path):
             for k in range(world):
                 torch.testing.assert_close(r[k]["slab"][step]["reduced"][i], want)
         assert r[0]["slab"][step]["reduced"][3] is None and r[1]["slab"][step]["reduced"][3] is None
+    # partial reduction (stage-2 pattern): the listed parameters are summed, the others stay the exact zeros they were
+    for i in range(5):
+        for k in range(world):
+            want = r[0]["only"]["local"][i] + r[1]["only"]["local"][i] if i in (1, 2, 4) else torch.zeros_like(r[0]["only"]["local"][i])
+            torch.testing.assert_close(r[k]["only"]["reduced"][i], want)
+    assert r[0]["only_caught"] and r[1]["only_caught"]
     # statistics: sums of per-view norms (NOT the norm of the summed gradient), max of radii and of the abs term
     vis = [x["radii"] > 0 for x in r]
     zero = torch.zeros(1)
