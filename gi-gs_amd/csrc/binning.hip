@@ -326,15 +326,13 @@ __device__ __forceinline__ void bitonic_sort_asc(unsigned n, unsigned npad_log2,
   }
 }
 
-// One workgroup per tile, longest lists first.  A list of up to kThreads * kItems keys is sorted by rocPRIM's block radix
-// sort (keys in registers, 8 bits per pass over the 32 + log2(P) significant bits; measured on the box,
-// tools/microbench/bitonic_lds.hip: 8192 keys 55 us, 4096 keys 34 us, 1024 keys 12 us per workgroup -- a bitonic network in
-// LDS, the first implementation, needs 70 / 40 / 20: sorting thousands of 64-bit keys on ONE CU costs tens of microseconds
-// either way, which is why the three size classes run concurrently on forked streams); longer lists (only in the last
-// class) in place in global memory with the all-ascending bitonic network (L2-resident; rare: dense scenes take the global
-// radix sort instead).  tile_order lists the tiles longest first, so a class is one contiguous stretch of it: a small
-// persistent grid strides over the order, skips the longer lists in front and stops at the first list that is too short
-// (a grid of T workgroups that mostly return at once costs more in dispatch than the sorting when each reserves its LDS).
+// One workgroup per tile.  A list of up to kBlock * kItems keys is sorted by rocPRIM's block radix sort (keys in registers,
+// 8 bits per pass over the 32 + log2(P) significant bits; measured on the box, tools/microbench/bitonic_lds.hip: 8192 keys
+// 55 us, 4096 keys 34 us, 1024 keys 12 us per 1024-lane workgroup -- a bitonic network in LDS, the first implementation, needs
+// 70 / 40 / 20: sorting thousands of 64-bit keys on ONE CU costs tens of microseconds either way, so what matters is how many
+// lists are in flight).  tile_order lists the tiles longest first, so a size class is one contiguous stretch of it: small
+// persistent grids stride over the order and stop at the first list that belongs to another kernel (a grid of T workgroups
+// that mostly return at once costs more in dispatch than the sorting when each reserves its LDS).
 // one tile of up to 1024 * kItems keys: rocPRIM block radix sort, keys in registers (blocked arrangement)
 template <int kItems, typename Storage, int kBlock = 1024>
 __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t* __restrict__ src, unsigned n, unsigned idx_bits,
@@ -360,13 +358,11 @@ __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t
   __syncthreads();  // the storage is reused by the next tile of this workgroup
 }
 
-// One workgroup (1024 lanes) per tile, longest lists first (tile_order), on a small persistent grid.  A list is sorted by
-// rocPRIM's block radix sort with 1, 4, 8 (kernel A: 64 KB of LDS, two workgroups per CU) or 16 (kernel B: 132 KB) keys per
-// lane -- measured on the box, tools/microbench/bitonic_lds.hip: 8192 keys 55 us, 4096 keys 34 us, 1024 keys 12 us per
-// workgroup; a bitonic network in LDS, the first implementation, needs 70 / 40 / 20: sorting thousands of 64-bit keys on ONE
-// CU costs tens of microseconds either way, so what matters is that long and short lists are in flight together (one launch
-// per size class, the first layout, ran them one after the other: 190 us at C2).  Lists beyond 16384 keys are sorted in
-// place in global memory with the all-ascending bitonic network (L2-resident; rare: dense scenes take the global radix sort).
+// bin_sort_kernel: one 1024-lane workgroup per tile, longest lists first (tile_order), on a small persistent grid, 4 or 8 keys
+// per lane (kernel <false>: lists of 2049..8192 keys, 64 KB of LDS, two workgroups per CU) or 16 (kernel <true>: up to 16384,
+// 132 KB; usually empty-handed).  One launch per size class, the first layout, ran them one after the other (190 us at C2);
+// lists beyond 16384 keys are sorted in place in global memory with the all-ascending bitonic network (L2-resident; rare:
+// dense scenes take the global radix sort).
 using SortS4 = rocprim::block_radix_sort<uint64_t, 1024, 4, rocprim::empty_type, 1, 1, 8>::storage_type;
 using SortS8 = rocprim::block_radix_sort<uint64_t, 1024, 8, rocprim::empty_type, 1, 1, 8>::storage_type;
 using SortS16 = rocprim::block_radix_sort<uint64_t, 1024, 16, rocprim::empty_type, 1, 1, 8>::storage_type;
