@@ -1,4 +1,4 @@
-# GI march: default library vs every gpurun_in/lib_*.so -- speed (tools/gi_tune.py); accuracy vs the exact march for the default
+# GI march: default library vs every gpurun_in/lib_*.so (tools/gi_tune.py: SSAO + SSR on the C2 G-buffer, ms)
 set -e
 cd $GRAFT_REPO_ROOT
 python tools/gi_tune.py - 2>&1 | tail -1
@@ -7,4 +7,3 @@ for f in gpurun_in/lib_*.so; do
   GIGS_LIB=$GRAFT_REPO_ROOT/$f python tools/gi_tune.py - 2>&1 | tail -1
 done
 python tools/gi_tune.py - 2>&1 | tail -1
-python tools/gi_variants.py --modes proj --no-sweep --reps 5 2>&1 | grep -v "^$" | tail -24
