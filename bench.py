@@ -468,6 +468,10 @@ def main():
                                       "hipGraph (GIGS_RASTER_GRAPH=1)" if os.environ.get("GIGS_RASTER_GRAPH", "0") == "1"
                                       else "whole step = 2 hand-captured hipGraphs (fwd, bwd), asynchronous binning"
                                       if (stepper is not None and getattr(stepper, "whole", None) is not None)
+                                      else "eager launches, synchronous binning (one read-back of the instance count%s)"
+                                      % ("; dense scene: global radix sort" if getattr(stepper, "_dense", False) else "")
+                                      if (args.graphs == "off" or args.fused == "off" or getattr(stepper, "_dense", False)
+                                          or os.environ.get("GIGS_RASTER_ASYNC", "1") != "1")
                                       else "eager launches, asynchronous binning (no host read-back)"),
                        "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce%s"
                                       % (world, " of the stage-2 trainable set only (GIGS_BENCH_REDUCE=trainable)" if reduce_only else "")},
