@@ -622,7 +622,7 @@ def test_async_binning_capacity_and_overflow(orc):
         assert np.isfinite(np.nan_to_num(v)).all(), k
 
 
-@pytest.mark.parametrize("case", ["c2ish", "ragged", "gi_settings"])
+@pytest.mark.parametrize("case", ["c2ish", "ragged", "gi_settings", "blocks32", "blocks64"])
 def test_gi_certification_is_exact(case, monkeypatch):
     """The march's conservative coarse-depth certification (LDS min/max table of the z plane) only skips lookups that
     cannot hit: SSAO and SSR outputs are bit-identical with it switched off (GIGS_GI_CERT=0), on smooth and ragged
@@ -633,6 +633,10 @@ def test_gi_certification_is_exact(case, monkeypatch):
         sc, cam, gis = scenes.surface_scene(P=120_000, sh_degree=1, seed=8, scale_mu=0.012), scenes.orbit_camera(9, 32, 640, 512, radius=3.4), [scenes.GI_DEFAULTS]
     elif case == "ragged":
         sc, cam, gis = scenes.surface_scene(P=50_000, sh_degree=1, seed=2, scale_mu=0.02), scenes.orbit_camera(3, 16, 611, 403, radius=3.2), [scenes.GI_DEFAULTS]
+    elif case == "blocks32":  # the table of 16-pixel blocks would exceed its LDS budget: 32-pixel blocks, ragged edges
+        sc, cam, gis = scenes.surface_scene(P=60_000, sh_degree=1, seed=5, scale_mu=0.02), scenes.orbit_camera(5, 16, 1621, 1043, radius=3.3), [scenes.GI_DEFAULTS]
+    elif case == "blocks64":  # 64-pixel blocks
+        sc, cam, gis = scenes.surface_scene(P=60_000, sh_degree=1, seed=6, scale_mu=0.02), scenes.orbit_camera(2, 16, 2891, 1777, radius=3.3), [dict(scenes.GI_DEFAULTS, delta=0.25)]
     else:
         sc, cam = scenes.surface_scene(P=30_000, sh_degree=1, seed=3, scale_mu=0.02), scenes.orbit_camera(0, 4, 208, 160, radius=3.5)
         gis = [dict(scenes.GI_DEFAULTS, radius=1.6, start=4), dict(scenes.GI_DEFAULTS, step=12, start=5, delta=0.125),
