@@ -797,7 +797,7 @@ def _fused_begin(self, start_event=None):
 
 def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view, albedo_map,
                 roughness_map, metallic_map, occlusion_map, depth_pos, lights, extra_loss=None):
-    """fused=True: everything after the rasterizer is stage2_fused._Stage2Fused (7 kernels instead of ~250)."""
+    """fused=True: everything after the rasterizer is stage2_fused._Stage2Fused (6 kernels instead of ~250)."""
     from stage2_fused import Stage2FusedBack
     H, W = cam["image_height"], cam["image_width"]
     main = torch.cuda.current_stream()

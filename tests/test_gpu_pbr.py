@@ -228,7 +228,7 @@ def test_stage2_hipgraph_capture_matches_eager(orc):
 
 @pytest.mark.parametrize("metallic", [True, False])
 def test_stage2_fused_matches_unfused(orc, metallic):
-    """stage2_fused (gbuffer_post + shade_ex + SSR + loss as one autograd node, 7 kernels) against the
+    """stage2_fused (gbuffer_post + shade_ex + SSR + loss as one autograd node, 6 kernels) against the
     op-by-op torch formulation of train.py:293-402 in pipeline.Stage2Front / stage2_loss: same loss, image
     and gradients, eagerly and replayed from a hipGraph on a second view."""
     import pbr
