@@ -505,3 +505,41 @@ def test_whole_step_graph_gradient_semantics_and_recapture(monkeypatch):
     o = step(camts[1], g, gt, vds[1])
     torch.cuda.synchronize()
     assert step.whole.recaptures == 2 and abs(float(o["loss"]) - ref[1][0]) <= 2e-6 * max(1.0, abs(ref[1][0]))
+
+
+def test_loss_gradient_planes_from_the_forward_pass_equal_the_backward_kernel():
+    """gigs_stage2_loss_fwd_grad writes d loss / d render_direct and d loss / d IRR for a unit upstream gradient in the
+    forward pass; times g_loss they must equal what the stand-alone backward kernel (gigs_stage2_loss_bwd) computes, and
+    loss / render_rgb / acc4 must equal gigs_stage2_loss_fwd's."""
+    import gigs_lib
+    lib = gigs_lib.lib()
+    H, W = 83, 131
+    g = torch.Generator(device="cpu").manual_seed(12)
+    rnd = lambda *s: torch.rand(*s, generator=g).to(DEV)  # noqa: E731
+    direct, irr, gt = rnd(3, H, W), rnd(3, H, W) * 0.3, rnd(3, H, W)
+    irr[:, 10:14, 20:30] = float("nan")  # NaN windows drop their gradient
+    irr[:, 40:60, 50:90] = 0.001          # the linear segment of the sRGB curve, and median ties
+    mask = (rnd(1, H, W) > 0.3).float()
+    rough, metal = rnd(1, H, W), rnd(1, H, W)
+    n_acc = 4 + 4 * 256
+    s = torch.cuda.current_stream().cuda_stream
+    p = lambda t: t.data_ptr()  # noqa: E731
+    rgb_a, acc_a, loss_a = torch.empty(3, H, W, device=DEV), torch.empty(n_acc, device=DEV), torch.empty(1, device=DEV)
+    rgb_b, acc_b, loss_b = torch.empty(3, H, W, device=DEV), torch.empty(n_acc, device=DEV), torch.empty(1, device=DEV)
+    du, iu = torch.empty(3, H, W, device=DEV), torch.empty(3, H, W, device=DEV)
+    gigs_lib.check(lib.gigs_stage2_loss_fwd(H, W, p(direct), p(irr), p(gt), p(mask), p(rough), p(metal), p(rgb_a), p(acc_a),
+                                            p(loss_a), s), "loss_fwd")
+    gigs_lib.check(lib.gigs_stage2_loss_fwd_grad(H, W, p(direct), p(irr), p(gt), p(mask), p(rough), p(metal), p(rgb_b),
+                                                 p(acc_b), p(loss_b), p(du), p(iu), s), "loss_fwd_grad")
+    gl = torch.tensor([0.75], device=DEV)  # a power of two times 3: the scaling is exact up to one rounding
+    dd, di = torch.empty(3, H, W, device=DEV), torch.empty(3, H, W, device=DEV)
+    dr, dm = torch.empty(1, H, W, device=DEV), torch.empty(1, H, W, device=DEV)
+    gigs_lib.check(lib.gigs_stage2_loss_bwd(H, W, p(direct), p(irr), p(gt), p(mask), p(acc_a), p(gl), p(dd), p(di), p(dr),
+                                            p(dm), s), "loss_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(loss_a, loss_b) and torch.equal(acc_a[:4], acc_b[:4])
+    assert torch.equal(rgb_a.nan_to_num(), rgb_b.nan_to_num())
+    torch.testing.assert_close(du * 0.75, dd, rtol=2e-7, atol=0)
+    # several atomics of either sign may land on one texel in any order: cancellation leaves ~1e-11 of a ~1e-4 term
+    torch.testing.assert_close(iu * 0.75, di, rtol=1e-6, atol=1e-9)
+    assert float(di.abs().sum()) > 0 and float((dd != 0).float().mean()) > 0.9
