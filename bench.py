@@ -225,8 +225,8 @@ CONFIGS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="BASELINE.json configuration (c2 = the headline metric's; c3 relight inference; c4/c5 3 M Gaussians "
                          "at the Mip-NeRF360 images_4 resolutions)")
