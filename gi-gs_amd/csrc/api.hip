@@ -343,7 +343,8 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
       // The per-tile LDS sort is O(n log^2 n) in the list length: for dense scenes (mean list above kBucketMaxMeanList
       // instances; 3 M Gaussians at 1237x822 average 7000) the global radix sort of the reference-shaped path wins
       // (measured: 9.2 vs 1.6 ms at that size), so a synchronous call -- which knows R here -- switches over.
-      if ((size_t)num_rendered > (size_t)gigs::kBucketMaxMeanList * T) dense = true;
+      static const int max_mean = [] { const char* e = getenv("GIGS_BUCKET_MAX_MEAN"); return e ? atoi(e) : gigs::kBucketMaxMeanList; }();
+      if ((size_t)num_rendered > (size_t)max_mean * T) dense = true;
     }
   }
   if (bucket && !dense) {

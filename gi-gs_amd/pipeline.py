@@ -221,7 +221,7 @@ class RasterFront(torch.nn.Module):
                                       rotations=rotations, derive_normal=True)
 
 
-BUCKET_MAX_MEAN_LIST = 2500  # csrc/gigs_common.h kBucketMaxMeanList
+BUCKET_MAX_MEAN_LIST = int(os.environ.get("GIGS_BUCKET_MAX_MEAN", "2500"))  # csrc/gigs_common.h kBucketMaxMeanList
 
 
 class DenseScene(RuntimeError):
