@@ -543,3 +543,55 @@ def test_loss_gradient_planes_from_the_forward_pass_equal_the_backward_kernel():
     # several atomics of either sign may land on one texel in any order: cancellation leaves ~1e-11 of a ~1e-4 term
     torch.testing.assert_close(iu * 0.75, di, rtol=1e-6, atol=1e-9)
     assert float(di.abs().sum()) > 0 and float((dd != 0).float().mean()) > 0.9
+
+
+def test_whole_step_graph_writes_gradients_into_the_all_reduce_slab(monkeypatch):
+    """Multi-GPU readiness on one GPU: with dp.GradSlab's sink active, the captured backward writes the rasterizer's
+    gradients straight into the slab (the `.grad` tensors handed out ARE the slab's views, on every replay), the light's
+    gradient is copied in once by the slab, and the numbers equal the eager step's."""
+    import diff_gaussian_rasterization as dgr
+    import dp
+    import pbr
+    import pipeline
+    monkeypatch.setenv("GIGS_STEP_GRAPH", "1")
+    monkeypatch.setenv("GIGS_RASTER_GRAPH", "0")
+    sc = scenes.surface_scene(P=6000, sh_degree=2, seed=31, scale_mu=0.025)
+    gi = scenes.GI_DEFAULTS
+    H, W = 160, 208
+    cams = [scenes.orbit_camera(i, 6, W, H, radius=3.5) for i in (0, 2)]
+    camts = [{k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    torch.manual_seed(8)
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    rays = pipeline.canonical_rays(cams[0], DEV)
+    vds = [pipeline.view_dirs_for(c, rays, DEV) for c in camts]
+    order = ["means3D", "opacities", "normal", "shs", "scales", "rotations", "albedo", "roughness", "metallic"]
+    names = {"opacities": "opacity", "shs": "sh"}
+
+    def run(graphs):
+        torch.manual_seed(9)
+        light = pbr.CubemapLight(base_res=64, device=DEV)
+        g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        params = [g[k] for k in order] + [light.base]
+        slab = dp.GradSlab(params)
+        sink = slab.sink([names.get(k, k) for k in order])
+        step = pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=graphs)
+        outs = []
+        for ci in (0, 1, 0):
+            for p in params:
+                p.grad = None
+            with dgr.grad_sink(sink):
+                step(camts[ci], g, gt, vds[ci])
+            if graphs:
+                for i, k in enumerate(order):
+                    assert g[k].grad is not None and g[k].grad.data_ptr() == slab.views[i].data_ptr(), k
+            slab._gather_stray()  # what allreduce_async does before the collective: strays (the light) are copied in
+            torch.cuda.synchronize()
+            assert light.base.grad.data_ptr() == slab.views[-1].data_ptr()
+            outs.append(slab.flat.clone())
+        return outs
+
+    eager, graph = run(False), run(True)
+    for a, b in zip(eager, graph):
+        assert rel_peak(b.cpu().numpy(), a.cpu().numpy()) < 2e-3
+    assert float((graph[0] - graph[1]).abs().max()) > 0  # two views, two different gradients in the same slab
