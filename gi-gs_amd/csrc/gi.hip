@@ -751,32 +751,51 @@ __device__ __forceinline__ void march2_cert(const GiParams& p, const FastPix& c,
         cert[k][g] = above | (below & pos[k]);
       }
     }
-    // phase B: each ray's samples in order (the two rays are independent), the exact part for the samples some lane of
-    // the wave still needs (~8 % of them: the lookup is waited for on the spot, other waves cover the latency).  A group
-    // that runs past the last step repeats the last sample (fjc): repeating a sample changes nothing -- a ray it closed is
-    // closed, one it left open it leaves open again -- so there is no per-sample range test.
+    // phase B: the exact part for the samples some lane of the wave still needs (~8 % of them).  A group that runs past the
+    // last step repeats the last sample (fjc): repeating a sample changes nothing -- a ray it closed is closed, one it left
+    // open it leaves open again -- so there is no per-sample range test.  Two stages, so that a group with several such
+    // samples pays ONE round trip to the z plane instead of one per sample: every lookup that MAY be needed (judged with the
+    // rays' state at the start of the group: a ray can only close) is requested, then the samples are resolved in order --
+    // each ray's own (the two rays are independent) -- with the state as it evolves.
+    u64 maybe[2][kGroup], any = 0ull;
 #pragma unroll
-    for (int g = 0; g < kGroup; g++) {
-      if (((open_m[0] & ~cert[0][g]) | (open_m[1] & ~cert[1][g])) == 0ull) continue;  // one scalar test per sample pair
+    for (int k = 0; k < 2; k++)
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const u64 need = open_m[k] & ~cert[k][g];
-        if (need != 0ull) {
-          const f32x2 t = tb[k][g] * cp.scale;  // exact: the pixel coordinates the uncertified march computes
-          const int ix = cvt_flr(t.x);
-          const int iy = cvt_flr(t.y);
-          const u64 inb = __builtin_amdgcn_ballot_w64((unsigned)ix < (unsigned)p.W) &
-                          __builtin_amdgcn_ballot_w64((unsigned)iy < (unsigned)p.H);
-          const unsigned off = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;
-          const u64 look = need & inb;
-          float z = gather_idx_issue(__builtin_amdgcn_inverse_ballot_w64(look) ? off : 0xffffffffu, pos_z);
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(z));
-          const float mid = (k == 0 ? dn[g].x : dn[g].y) + c.cm;
-          const u64 h = look & __builtin_amdgcn_ballot_w64(fabsf(z - mid) <= c.hh);
-          hit[k] = __builtin_amdgcn_inverse_ballot_w64(h) ? (int)off : hit[k];
-          open_m[k] &= ~((need & ~inb) | h);  // left the image, or hit: the ray is closed
+      for (int g = 0; g < kGroup; g++) { maybe[k][g] = open_m[k] & ~cert[k][g]; any |= maybe[k][g]; }
+    if (any != 0ull) {
+      float z[2][kGroup];
+      unsigned off[2][kGroup];
+      u64 inb[2][kGroup];
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int g = 0; g < kGroup; g++) {
+          z[k][g] = 0.0f; off[k][g] = 0u; inb[k][g] = 0ull;
+          if (maybe[k][g] != 0ull) {
+            const f32x2 t = tb[k][g] * cp.scale;  // exact: the pixel coordinates the uncertified march computes
+            const int ix = cvt_flr(t.x);
+            const int iy = cvt_flr(t.y);
+            inb[k][g] = __builtin_amdgcn_ballot_w64((unsigned)ix < (unsigned)p.W) & __builtin_amdgcn_ballot_w64((unsigned)iy < (unsigned)p.H);
+            off[k][g] = __umul24((unsigned)iy, (unsigned)p.W) + (unsigned)ix;
+            z[k][g] = gather_idx_issue(__builtin_amdgcn_inverse_ballot_w64(maybe[k][g] & inb[k][g]) ? off[k][g] : 0xffffffffu, pos_z);
+          }
         }
-      }
+      static_assert(kGroup == 4, "the wait below lists the lookups of a group of four");
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(z[0][0]), "+v"(z[0][1]), "+v"(z[0][2]), "+v"(z[0][3]), "+v"(z[1][0]), "+v"(z[1][1]), "+v"(z[1][2]), "+v"(z[1][3]));
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int g = 0; g < kGroup; g++) {
+          const u64 need = open_m[k] & maybe[k][g];  // the ray may have closed at an earlier sample of this group
+          if (need != 0ull) {
+            const u64 look = need & inb[k][g];
+            const float mid = (k == 0 ? dn[g].x : dn[g].y) + c.cm;
+            const u64 h = look & __builtin_amdgcn_ballot_w64(fabsf(z[k][g] - mid) <= c.hh);
+            hit[k] = __builtin_amdgcn_inverse_ballot_w64(h) ? (int)off[k][g] : hit[k];
+            open_m[k] &= ~((need & ~inb[k][g]) | h);  // left the image, or hit: the ray is closed
+          }
+        }
     }
     if ((open_m[0] | open_m[1]) == 0ull) break;
   }
