@@ -26,23 +26,32 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-importlib.import_module("gi-gs_amd")
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import dp  # noqa: E402
-import gigs_lib  # noqa: E402
-import pipeline  # noqa: E402
-import scenes  # noqa: E402
+# torch, numpy and the package are imported by run() -- AFTER the arguments are parsed and, for --gpus N > 1 without a
+# launcher, after the N ranks have been started as a child torchrun (no GPU call may precede that)
+np = torch = dp = gigs_lib = pipeline = scenes = None
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 PARAM_KEYS = ["means3D", "opacities", "normal", "albedo", "roughness", "metallic", "shs", "scales", "rotations"]
+
+
+def _imports():
+    global np, torch, dp, gigs_lib, pipeline, scenes
+    importlib.import_module("gi-gs_amd")
+    import numpy as _np
+    import torch as _torch
+
+    import dp as _dp
+    import gigs_lib as _gigs_lib
+    import pipeline as _pipeline
+    import scenes as _scenes
+    np, torch, dp, gigs_lib, pipeline, scenes = _np, _torch, _dp, _gigs_lib, _pipeline, _scenes
 
 
 def algorithmic_bytes(P, V, R, N, M, T):
@@ -88,6 +97,12 @@ _PMC_NAMES = {"ssao": "ssao_kernel", "ssr": "ssr_kernel", "blend_fwd": "blend_fw
               "preprocess_bwd": "preprocess_bwd_kernel", "sort": "bin_sort_kernel"}
 
 
+def _pmc_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")))
+    return os.path.relpath(files[-1], ROOT) if files else None
+
+
 def _pmc_entry(stage: str):
     """Counters of `stage`'s kernel from the newest committed summary (profiles/rNN/pmc_summary*.json, by name order);
     template instantiations of one kernel are matched by prefix and the one with the most launches is taken."""
@@ -117,58 +132,67 @@ def pmc_valu_busy(stage: str):
         return None
 
 
-def make_light(device, shade: str):
-    if shade == "hip":
-        import pbr
-        light = pbr.CubemapLight(base_res=256).to(device)
-        return light, pbr.get_brdf_lut().to(device)
-    return None, None
+def make_light(device, shade: str = "hip"):
+    import pbr
+    light = pbr.CubemapLight(base_res=256).to(device)
+    return light, pbr.get_brdf_lut().to(device)
 
 
-def stub_step(cam, g, sh_degree, gi, gt_image):
-    """Step without the deferred shade (used only until the HIP shade lands; flagged in the
-    JSON line as config.shade = "none")."""
-    dev = g["means3D"].device
-    bg = torch.zeros(3, device=dev)
-    res = pipeline.render(cam, g, sh_degree, bg, gi, derive_normal=True)
-    H, W = cam["image_height"], cam["image_width"]
-    albedo_map, metallic_map = res["albedo_map"], res["metallic_map"]
-    roughness_map = res["roughness_map"] * (1.0 - 0.04) + 0.04
-    occ = res["occlusion_map"].detach()
-    render_direct = torch.where(res["normal_mask"], (albedo_map * occ).clamp(0, 1), bg[:, None, None])
-    ssr = pipeline.Gaussian_SSR(cam["tanfovx"], cam["tanfovy"], W, H, gi["radius"], gi["bias"], gi["thick"],
-                                gi["delta"], gi["step"], gi["start"])
-    F0 = (1.0 - metallic_map) * 0.04 + albedo_map * metallic_map
-    (IRR, _) = ssr(res["out_normal_view"].detach(), res["depth_pos"].detach(),
-                   pipeline.srgb_to_linear(render_direct).detach(), albedo_map, roughness_map, metallic_map, F0)
-    IRR = pipeline.filters.median_blur(pipeline.linear_to_srgb(IRR)[None], (3, 3))[0]
-    loss = torch.abs(render_direct + IRR - gt_image).mean()
-    loss = loss + 0.001 * ((1.0 - roughness_map[res["normal_mask"]]).mean() + metallic_map[res["normal_mask"]].mean())
-    loss.backward()
-    return dict(loss=loss.detach(), radii=res["radii"])
-
-
-def cpu_baseline_and_parity(sc, cam, gi, sh_degree, light, brdf_lut, stepper, config):
+def cpu_baseline_and_parity(sc, cam, gi, sh_degree, light, brdf_lut, stepper, config, single_thread_res=0):
     """The checker leg (rank 0, N = 1 only): ONE view of the timed workload on the CPU oracle -- rasterizer fwd, the
     operator's filters + SSAO, light pre-filter, shade, SSR, sRGB/median, rasterizer bwd (oracle/stage2_ref.py; no
     shade / light backward on the CPU, so the CPU time is a lower bound of a full step) -- timed on all host cores,
     and the same view from the timed GPU path compared with it (oracle/parity.py): integer state bit for bit,
-    every fp plane's mean L1, rasterizer-backward gradients, and the PSNR (utils/image_utils.py:31) of the final
-    stage-2 image."""
+    every fp plane's mean L1 and the share of its elements beyond 1e-4 / 1e-5, rasterizer-backward gradients, the PSNR
+    (utils/image_utils.py:31) of the final stage-2 image, K (evaluated pixel-Gaussian pairs) and the covered-pixel
+    fraction; beside it the same per-pixel figures for the product's EXACT march and for the oracle against its
+    FMA-contracted twin (parity.march_noise).  `single_thread_res` > 0 adds a single-thread timing on a bounded sample:
+    the same scene and camera at that (square) resolution."""
     from oracle import oracle as orc
     from oracle import parity
     orc.build()
     cores = orc.max_threads()
     orc.set_threads(cores)
     only = ("albedo", "roughness", "metallic")  # the planes stage 2 differentiates (SURVEY App. D)
-    gpu = parity.gpu_capture(sc, cam, gi, sh_degree, light=light, brdf_lut=brdf_lut, stepper=stepper, grads_only=only,
-                             dev=str(light.base.device) if light is not None else "cuda:0")
+    dev = str(light.base.device)
+    gpu = parity.gpu_capture(sc, cam, gi, sh_degree, light=light, brdf_lut=brdf_lut, stepper=stepper, grads_only=only, dev=dev)
     ref, t = parity.oracle_capture(orc, sc, cam, gi, sh_degree, light_base=gpu.get("light_base"), grads_only=only)
     rep = parity.compare(gpu, ref)
+    rep["gi_per_pixel"] = parity.march_noise(orc, sc, cam, gi, sh_degree, gpu, ref, light=light, brdf_lut=brdf_lut, dev=dev)
     cpu = dict(value=round(1.0 / t["total"], 4), unit="renders/s", cores=cores, kind="port",
                sample="1 step of the same workload (%s, 1 view) on the oracle: " % config
                       + ", ".join("%s %.2fs" % (k, v) for k, v in t.items() if k != "total")
                       + "; backward blend is single-threaded (deterministic double sums), no shade/light backward on the CPU")
+    if single_thread_res:
+        # bounded single-thread sample (SURVEY 8(d) asks for both timings; the full-size view would take minutes on one
+        # core): the SAME scene through the same oracle sequence at a reduced square resolution, light pre-filter
+        # (resolution-independent: 6 x 256^2 texels, minutes on one core) excluded and said so
+        import numpy as _np
+        small = scenes.orbit_camera(cam.get("index", 0), cam.get("n_views", 64), single_thread_res, single_thread_res, radius=3.5)
+        orc.set_threads(1)
+        t1 = {}
+        t0 = time.perf_counter()
+        raw = parity.stage2_ref.operator_forward(orc, sc, small, gi, sh_degree, keep_state=True, timings=t1)
+        tb = time.perf_counter()
+        pg = parity.pixel_grads(single_thread_res, single_thread_res, only=only)
+        raw["rasterizer"].backward(**{"grad_" + k: v for k, v in pg.items()})
+        t1["backward"] = time.perf_counter() - tb
+        F0 = _np.full((3, single_thread_res, single_thread_res), 0.04, _np.float32)
+        ts = time.perf_counter()
+        fx, fy = parity.stage2_ref.focal(small)
+        orc.ssr(single_thread_res, single_thread_res, fx, fy, gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"],
+                gi["start"], raw["out_normal_view"], raw["depth_pos"], raw["render"], raw["albedo_map"], raw["roughness_map"],
+                raw["metallic_map"], F0)
+        t1["ssr"] = time.perf_counter() - ts
+        total = time.perf_counter() - t0
+        orc.set_threads(cores)
+        cpu["single_thread"] = dict(
+            value=round(1.0 / total, 4), unit="renders/s", cores=1,
+            sample="the same scene, 1 view at %dx%d (%.1f %% of the pixels; all %d Gaussians preprocessed and binned), 1 thread: "
+                   % (single_thread_res, single_thread_res, 100.0 * single_thread_res ** 2 / (cam["image_width"] * cam["image_height"]),
+                      sc["means3D"].shape[0])
+                   + ", ".join("%s %.2fs" % (k, v) for k, v in t1.items())
+                   + "; light pre-filter and shade not included (resolution-independent / negligible)")
     return cpu, rep
 
 
@@ -222,11 +246,14 @@ CONFIGS = {
 }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed blocks of --steps steps each: the first is the contract's measurement (`value`), all of them "
+                         "give `repeats` = median / min / max ms per step")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="BASELINE.json configuration (c2 = the headline metric's; c3 relight inference; c4/c5 3 M Gaussians "
                          "at the Mip-NeRF360 images_4 resolutions)")
@@ -236,35 +263,101 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--sh-degree", type=int, default=None)
     ap.add_argument("--start", type=int, default=8, help="GI march start (8 = reference CLI default, 64 = README)")
-    ap.add_argument("--shade", choices=["auto", "hip", "none"], default="auto")
+    ap.add_argument("--shade", choices=["auto", "hip"], default="auto", help="(kept for older command lines; always hip)")
     ap.add_argument("--graphs", choices=["on", "off"], default="on",
                     help="capture the launch-bound glue segments of the step into hipGraphs")
     ap.add_argument("--fused", choices=["on", "off"], default="on",
                     help="run the tensor glue between rasterizer and loss.backward() as the fused stage-2 node "
                          "(gi-gs_amd/stage2_fused.py) instead of op-by-op torch")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and parity)")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (drop_in_step, full_grad_step, iteration) that follow the timed region")
+    ap.add_argument("--cpu-single-res", type=int, default=200,
+                    help="resolution of the bounded single-thread CPU sample (0 = skip)")
+    args = ap.parse_args(argv)
     cP, cW, cH, cD, cname = CONFIGS[args.config]
     args.gaussians = cP if args.gaussians is None else args.gaussians
     args.sh_degree = cD if args.sh_degree is None else args.sh_degree
-    W = args.width or args.res or cW
-    H = args.height or args.res or cH
+    args.W = args.width or args.res or cW
+    args.H = args.height or args.res or cH
+    args.cname = cname
+    return args
 
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: start the N ranks as a CHILD
+    `python -m torch.distributed.run` (this process has made no GPU call and never will), relay rank 0's JSON line.
+    Fails loudly when fewer than N GPUs are visible (GIGS_BENCH_BACKEND=gloo, the rehearsal mode, lets ranks share cards)."""
+    backend = os.environ.get("GIGS_BENCH_BACKEND", "nccl")
+    import torch as _torch  # device_count() only: it does not initialise the GPU (and nothing is exec'ed from here)
+    n = _torch.cuda.device_count()
+    if n < 1 or (backend == "nccl" and n < args.gpus):
+        raise SystemExit("bench.py --gpus %d: %d GPU(s) visible; one rank per GPU over RCCL needs %d "
+                         "(GIGS_BENCH_BACKEND=gloo rehearses the rank logic on fewer cards)" % (args.gpus, n, args.gpus))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, GIGS_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        raise SystemExit("bench.py --gpus %d: the %d-rank run failed (exit code %d, %s JSON line)"
+                         % (args.gpus, args.gpus, rc, "no" if line is None else "a"))
+    print(line, flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+    # everything a library prints to stdout (RCCL's version banner, ...) goes to stderr; the JSON line alone to stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    line = run(args)
+    if line is not None:
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    return 0
+
+
+def run(args):
+    _imports()
+    W, H, cname = args.W, args.H, args.cname
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py start them: "
+                         "`python bench.py --gpus N`)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path in the product)")
     # GIGS_BENCH_BACKEND=gloo with fewer GPUs than ranks is a rehearsal mode (ranks share cards, the all-reduce
     # goes through the host); the measured configuration is one rank per GPU over RCCL
     backend = os.environ.get("GIGS_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible -- one rank per GPU over RCCL" % (world, n_dev))
+    dev_index = local_rank if backend == "nccl" else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     # GIGS_BENCH_FORCE_DIST=1: run the distributed code path (process group, gradient all-reduce, barriers) with a
     # single rank -- a one-GPU rehearsal of everything but the inter-GPU traffic
-    use_dist = world > 1 or os.environ.get("GIGS_BENCH_FORCE_DIST", "0") == "1"
+    force_coll = os.environ.get("GIGS_BENCH_FORCE_DIST", "0") == "1"
+    use_dist = world > 1 or force_coll
     dist = None
+    ranks_seen = 1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -275,68 +368,68 @@ def main():
     def init_dist():
         # Called AFTER the first (hipGraph-capturing) step: RCCL's proxy thread issues HIP calls of its own, and a
         # HIP call from another thread while a stream is capturing in the default (global) mode fails the capture.
+        nonlocal ranks_seen
         if not use_dist:
             return
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, (world, args.gpus)
+        ranks_seen = dist.get_world_size()
+        if ranks_seen != world:
+            raise SystemExit("bench.py: the process group has %d ranks, WORLD_SIZE says %d" % (ranks_seen, world))
 
-    shade = args.shade
-    if shade == "auto":
-        shade = "hip" if os.path.exists(os.path.join(ROOT, "gi-gs_amd", "pbr", "__init__.py")) else "none"
-
+    shade = "hip"
     gi = dict(scenes.GI_DEFAULTS, start=args.start)
     sc = scenes.surface_scene(P=args.gaussians, sh_degree=args.sh_degree, seed=0)
     P, M = sc["means3D"].shape[0], sc["shs"].shape[1]
     g = {k: torch.from_numpy(sc[k]).to(dev).requires_grad_(True) for k in PARAM_KEYS}
     n_views = 64
-    cams = [scenes.orbit_camera(i, n_views, W, H, radius=3.5) for i in range(n_views)]
+    cams = [dict(scenes.orbit_camera(i, n_views, W, H, radius=3.5), index=i, n_views=n_views) for i in range(n_views)]
     cams_t = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
     yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, W, device=dev), indexing="ij")
     gt_image = torch.stack([0.5 + 0.3 * torch.sin(6 * xx), 0.5 + 0.3 * torch.cos(5 * yy), 0.4 + 0.2 * xx * yy])
-    light, brdf_lut = make_light(dev, shade)
+    light, brdf_lut = make_light(dev)
     rays = pipeline.canonical_rays(cams[0], dev)
     view_dirs = [pipeline.view_dirs_for(c, rays, dev) for c in cams_t]  # per-camera constants, like gt_image
-    if light is not None:
-        params_light = [p for p in light.parameters()]
-    else:
-        params_light = []
-    # slab order: the stage-2 trainable set (materials, then the light) last and adjacent, so that
-    # GIGS_BENCH_REDUCE=trainable can reduce it with ONE collective
+    params_light = [p for p in light.parameters()]
+    # slab order: the stage-2 trainable set (materials, then the light) last and adjacent, so that it is ONE collective
     SLAB_KEYS = ["means3D", "opacities", "normal", "shs", "scales", "rotations", "albedo", "roughness", "metallic"]
     SINK_NAME = {"opacities": "opacity", "shs": "sh"}
     flat_params = [g[k] for k in SLAB_KEYS] + params_light
+    inference = args.config == "c3"
+    # What is reduced.  A stage-2 iteration DECLARES its non-zero gradient set: the loss reaches albedo / roughness /
+    # metallic and the light only (train.py:330-420; the blend weights are detached from the material planes, SURVEY
+    # App. D), every other gradient is an exact zero on every rank -- so that stretch of the slab is the collective
+    # (5 of 46 floats per Gaussian + the light), and the premise is VERIFIED on the first two reduced steps
+    # (check_rest_zero: one device read each, outside the timed region when --warmup >= 2).  GIGS_BENCH_REDUCE=all
+    # reduces every gradient (what a stage-1 iteration needs).
+    reduce_mode = os.environ.get("GIGS_BENCH_REDUCE", "trainable")
     reduce_only = None
-    if os.environ.get("GIGS_BENCH_REDUCE", "all") == "trainable" and args.config != "c3":
-        # opt-in (NOT the measured default): a stage-2 iteration's gradients w.r.t. everything but albedo / roughness /
-        # metallic and the light are identically zero on every rank (dp.GradSlab.allreduce_async(only=...))
+    if reduce_mode == "trainable" and not inference:
         reduce_only = list(range(SLAB_KEYS.index("albedo"), len(flat_params)))
     # multi-rank: every gradient lives in one persistent flat slab; the rasterizer's backward writes into it directly
     # (dgr.grad_sink), so the all-reduce bucket needs no packing pass
-    slab = sink = None
+    slab = sink = dgr_mod = None
     if use_dist:
         import diff_gaussian_rasterization as dgr_mod
         slab = dp.GradSlab(flat_params)
+        slab.timing = True
         sink = slab.sink([SINK_NAME.get(k, k) for k in SLAB_KEYS])
-    force_coll = os.environ.get("GIGS_BENCH_FORCE_DIST", "0") == "1"
-    stepper = relighter = None
-    inference = args.config == "c3"
+    stepper = relighter = g_inf = None
     if inference:
         # configs[2]: relight.py -- HDR latlong map -> 256^2 cubemap, build_mips ONCE, then per view
         # render(inference=True) -> pbr_shading -> Gaussian_SSR -> sRGB -> median -> sum (gi-gs_amd/relight.py)
         import relight
-        if shade != "hip":
-            raise SystemExit("--config c3 needs the HIP shade")
         hdri = torch.from_numpy(scenes.synthetic_envmap(512, 1024, seed=1)).to(dev)
         light = relight.make_light(hdri, res=256)
         relighter = relight.Relighter(light, gi, args.sh_degree, metallic=False, fused=(args.fused == "on"), brdf_lut=brdf_lut,
                                       graphs=(args.graphs == "on"))
         g_inf = {k: v.detach() for k, v in g.items()}
-    elif shade == "hip":
+    else:
         stepper = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=(args.graphs == "on"),
                                       fused=(args.fused == "on"))
+    checked = [0]
 
     def one_step(i):
         vi = dp.view_for(i, rank, world, n_views)
@@ -346,15 +439,14 @@ def main():
         for p in flat_params:
             p.grad = None
         with (dgr_mod.grad_sink(sink) if sink is not None else _NULL):
-            if shade == "hip":
-                out = stepper(cam, g, gt_image, view_dirs[vi])
-            else:
-                out = stub_step(cam, g, args.sh_degree, gi, gt_image)
+            out = stepper(cam, g, gt_image, view_dirs[vi])
         if use_dist and dist.is_initialized():
             # one flat bucket on the communication stream: xGMI is point-to-point, a single large all-reduce keeps every
             # link busy.  The step ends where an optimizer would read the reduced gradients, so the wait is part of it
             # (exact, no one-step gradient delay).
-            slab.allreduce_async(force=force_coll, only=reduce_only)
+            check = reduce_only is not None and checked[0] < 2
+            checked[0] += 1
+            slab.allreduce_async(force=force_coll, only=reduce_only, check_rest_zero=check)
             slab.wait()
         return out
 
@@ -363,25 +455,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_block(first):
+        """EXACTLY --steps steps between two (barrier + synchronize) brackets; the maximum over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(first + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
     if use_dist:
         one_step(0)  # captures the hipGraphs (untimed, before the process group exists)
         torch.cuda.synchronize()
         init_dist()
     for i in range(args.warmup):
         one_step(i)
-    barrier()
+    if slab is not None:
+        torch.cuda.synchronize()
+        slab.comm_stats()  # drop the warm-up collectives' events
     with gigs_lib.profile() as prof:
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            one_step(args.warmup + i)
-        barrier()
-        t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = timed_block(args.warmup)  # the contract's measurement
+    comm = None
+    if slab is not None:
+        comm = slab.comm_stats()
+        if comm is not None:
+            comm["reduced"] = ("stage-2 non-zero set: albedo, roughness, metallic, light (rest verified zero on the first 2 steps)"
+                               if reduce_only is not None else "every gradient")
+            comm["floats_per_gaussian"] = round((comm["bytes"] / 4 - sum(p.numel() for p in params_light)) / P, 2)
+            comm["backend"] = backend
+    blocks = [elapsed]
+    for b in range(1, max(1, args.repeats)):
+        blocks.append(timed_block(args.warmup + b * args.steps))
+    per_step = sorted(1e3 * x / args.steps for x in blocks)
+    repeats = {"blocks": len(blocks), "steps_per_block": args.steps, "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
+               "ms_per_step_min": round(per_step[0], 4), "ms_per_step_max": round(per_step[-1], 4),
+               "value_median": round(args.steps * world / (1e-3 * per_step[len(per_step) // 2] * args.steps), 3)}
 
+    line = None
     if rank == 0:
         # V (visible), R (instances) averaged over the views of the timed region (outside it)
         import diff_gaussian_rasterization as dgr
@@ -396,6 +511,7 @@ def main():
                     cam["projmatrix"], 1.0, cam["tanfovx"], cam["tanfovy"], H, W, args.sh_degree, False, False, False, False)
                 Rs.append(int(res[0]))
                 Vs.append(int((res[2] > 0).sum()))
+                del res
         V, R = float(np.mean(Vs)), float(np.mean(Rs))
         N, T = H * W, ((W + 15) // 16) * ((H + 15) // 16)
         ab = algorithmic_bytes(P, V, R, N, M, T)
@@ -414,7 +530,8 @@ def main():
                 kernels[name] = rec
 
         add_stages(prof.stages, args.steps, "live")  # hipEvents over the timed region
-        if shade == "hip" and args.graphs == "on" and world == 1 and not inference:
+        eager = None
+        if args.graphs == "on" and world == 1 and not inference:
             # stages replayed from a hipGraph carry no events: time them on a few extra eager steps of the same
             # workload OUTSIDE the timed region (marked "eager-extra"; the live entries above are not touched)
             eager = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=False, fused=(args.fused == "on"))
@@ -427,6 +544,12 @@ def main():
                     eager(cams_t[(2 + i) % n_views], g, gt_image, view_dirs[(2 + i) % n_views])
                 torch.cuda.synchronize()
             add_stages(prof2.stages, extra, "eager-extra")
+        # light pre-filter: its real traffic is the cached pair-weight tables, not the textures (PMC FETCH_SIZE of the
+        # committed pass when there is one)
+        for nm in ("cubemap_fwd", "cubemap_bwd"):
+            if nm in kernels:
+                kernels[nm]["note"] = ("per launch of the %d launches per step (mips, diffuse, merged GGX levels); the GGX launch "
+                                       "streams its cached pair weights: see roofline_light" % round(kernels[nm]["launches_per_step"]))
         # the roofline entry: the kernel with the largest time per step among those with an event timing -- taken live
         # over the timed region where the stage is launched eagerly, otherwise from the eager steps right after it (a
         # step replayed from hipGraphs, the default, has no events inside its kernel nodes)
@@ -437,23 +560,33 @@ def main():
         if dom is not None and "achieved_GBs" in kernels[dom]:
             a = kernels[dom]["achieved_GBs"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
-                        "valu_busy": pmc_valu_busy(dom), "timed": kernels[dom]["timed"],
-                        "note": "dominant kernel by time; its z-plane lookups are served by L2/L1 (the plane is 2.5 MB) and "
-                                "most of them are skipped by the certification table in LDS, so it is bound by fp32 VALU "
-                                "issue, not by HBM (valu_busy = share of its cycles with the vector ALUs issuing, from the "
-                                "committed PMC pass; DESIGN.md section 5)"}
+                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom), "timed": kernels[dom]["timed"]}
+            vb = pmc_valu_busy(dom)
+            if vb is not None:
+                # what actually binds the kernel when it is not HBM: the share of its cycles with the vector ALUs issuing.
+                # NOT measured in this run (PMC needs rocprofv3): read from the committed pass named here
+                roofline["limiter"] = {"resource": "valu_issue" if vb > roofline["frac"] else "hbm",
+                                       "valu_busy_from_committed_pmc": vb, "pmc_summary": _pmc_file()}
+            if dom in ("ssao", "ssr"):
+                roofline["note"] = ("dominant kernel by time; contract fields are its HBM roofline (algorithmic bytes / duration), "
+                                    "which does not bind it: its z-plane lookups are served by L2/L1 (the plane is 2.5 MB) and most "
+                                    "are skipped by the certification table in LDS, so the march is bound by fp32 VALU issue "
+                                    "(`limiter`; DESIGN.md section 5)")
         cpu = parity_rep = None
         vi0 = args.warmup % n_views
-        if not args.no_cpu_baseline and world == 1 and shade == "hip":
+        if not args.no_cpu_baseline and world == 1:
             if inference:
                 cpu, parity_rep = cpu_baseline_and_parity_c3(sc, cams[vi0], gi, args.sh_degree, relighter, light, g_inf,
                                                              view_dirs[vi0], cams_t[vi0])
             else:
                 cpu, parity_rep = cpu_baseline_and_parity(sc, cams[vi0], gi, args.sh_degree, light, brdf_lut, stepper,
-                                                          args.config.upper())
+                                                          args.config.upper(), single_thread_res=args.cpu_single_res)
+        extras = {}
+        if not args.no_extras and world == 1 and not inference:
+            extras = secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n_views, sc)
         what = ("relight renders/sec (inference, PBR+indirect, mips built once)" if inference
                 else "train-step renders/sec (fwd+bwd, G-buffer+indirect)")
+        dense = bool(getattr(stepper, "_dense", False))
         line = {
             "metric": "%s at %dx%d; PSNR vs the CPU oracle" % (what, W, H),
             "value": round(args.steps * world / elapsed, 3), "unit": "renders/s", "n_gpus": world,
@@ -469,22 +602,92 @@ def main():
                                       else "whole step = 2 hand-captured hipGraphs (fwd, bwd), asynchronous binning"
                                       if (stepper is not None and getattr(stepper, "whole", None) is not None)
                                       else "eager launches, synchronous binning (one read-back of the instance count%s)"
-                                      % ("; dense scene: global radix sort" if getattr(stepper, "_dense", False) else "")
-                                      if (args.graphs == "off" or args.fused == "off" or getattr(stepper, "_dense", False)
+                                      % ("; dense scene: global radix sort" if dense else "")
+                                      if (args.graphs == "off" or args.fused == "off" or dense
                                           or os.environ.get("GIGS_RASTER_ASYNC", "1") != "1")
                                       else "eager launches, asynchronous binning (no host read-back)"),
                        "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce%s"
-                                      % (world, " of the stage-2 trainable set only (GIGS_BENCH_REDUCE=trainable)" if reduce_only else "")},
+                                      % (world, " of the stage-2 non-zero gradient set" if reduce_only else " of every gradient")},
+            "ranks_seen": ranks_seen, "comm": comm, "repeats": repeats,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
+        line.update(extras)
         if parity_rep is not None:
             # the timed GPU path vs the CPU oracle on one view of this very workload (oracle/parity.py)
             line["psnr_vs_oracle_db"] = parity_rep.get("psnr_render_rgb")
+            for k in ("K_pairs_evaluated", "K_pairs_contributing", "covered_px_frac"):
+                if k in parity_rep:
+                    line["config"][k] = parity_rep[k]
             line["parity_" + args.config] = parity_rep
-        print(json.dumps(line))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    return line
+
+
+def _time_steps(fn, warm, n):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(warm + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"ms_per_step": round(1e3 * dt, 3), "renders_per_s": round(1.0 / dt, 2), "steps": n}
+
+
+def secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n_views, sc):
+    """Secondary measurements of the same workload, after the timed region (rank 0, one GPU):
+
+    drop_in_step    what an UNMODIFIED train.py gets through the reference's own API, op by op: GaussianRasterizer ->
+                    gbuffer post-processing -> pbr_shading -> Gaussian_SSR -> L1 -> loss.backward(), eager, torch glue
+                    (Stage2Step(graphs=False, fused=False)): the drop-in claim's own figure
+    full_grad_step  rasterizer forward (+ in-op filters + SSAO) and backward with ALL SEVEN incoming gradient planes
+                    live (colour, opacity, depth, normal, albedo, roughness, metallic: the blend backward's dL/dalpha
+                    chain runs, which the stage-2 pattern of the headline step skips); no shade / SSR
+    iteration       a COMPLETE stage-2 training iteration of train.py:247-523: activations of the raw parameter groups,
+                    the headline step, BRDF TV + lamb + envmap TV, backward, Adam on Gaussians and light, clamp
+    """
+    out = {}
+    leaves = list(g.values()) + list(light.parameters())
+
+    def clear():
+        for p in leaves:
+            p.grad = None
+
+    drop = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=False, fused=False)
+
+    def drop_step(i):
+        clear()
+        drop(cams_t[i % n_views], g, gt_image, view_dirs[i % n_views])
+    out["drop_in_step"] = dict(_time_steps(drop_step, 3, 12), what="op-by-op through GaussianRasterizer / pbr_shading / "
+                               "Gaussian_SSR, eager, torch glue (--fused off --graphs off)")
+    del drop
+    torch.manual_seed(11)
+    H, W = args.H, args.W
+    wts = [torch.randn(c, H, W, device=gt_image.device) / (H * W) for c in (3, 1, 1, 3, 3, 1, 1)]
+    bg = torch.zeros(3, device=gt_image.device)
+
+    def full_step(i):
+        clear()
+        o, _m2d, _ = pipeline.rasterize(cams_t[i % n_views], g, args.sh_degree, bg, gi)
+        planes = (o[0], o[2], o[3], o[5], o[7], o[8], o[9])
+        torch.autograd.backward(planes, wts)
+    with gigs_lib.profile() as prof:
+        rec = _time_steps(full_step, 3, 12)
+    st = {k: round(ms / n, 4) for k, (ms, n) in prof.stages.items() if n and k in ("blend_fwd", "blend_bwd", "preprocess_bwd")}
+    out["full_grad_step"] = dict(rec, kernels_avg_ms=st, what="rasterizer + in-op filters + SSAO forward, backward with all seven "
+                                 "incoming gradient planes live, eager")
+    clear()
+    try:
+        import train_iteration
+        out["iteration"] = train_iteration.bench_iteration(sc, light, brdf_lut, gi, args.sh_degree, cams_t, view_dirs, gt_image,
+                                                           steps=max(20, args.steps), warmup=5)
+    except ImportError:
+        pass
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

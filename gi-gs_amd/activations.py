@@ -67,3 +67,13 @@ def activate(raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     g = dict(zip(OUT, out))
     g["means3D"] = raw["xyz"]
     return g
+
+
+def activate_torch(raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The same getters as the reference writes them (scene/gaussian_model.py:178-263): eight torch op chains.  The
+    checker of `activate` and the 'torch glue' leg of the iteration benchmarks."""
+    F = torch.nn.functional
+    return dict(means3D=raw["xyz"], shs=torch.cat((raw["f_dc"], raw["f_rest"]), dim=1), opacities=torch.sigmoid(raw["opacity"]),
+                normal=F.normalize(raw["normal"], dim=-1), albedo=torch.sigmoid(raw["albedo"]),
+                roughness=torch.sigmoid(raw["roughness"]), metallic=torch.sigmoid(raw["metallic"]),
+                scales=torch.exp(raw["scaling"]), rotations=F.normalize(raw["rotation"]))

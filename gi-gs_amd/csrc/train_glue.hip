@@ -381,6 +381,10 @@ struct AdamGroups {
   float step_size[kAdamMaxGroups];      // lr / (1 - beta1^t)
   float bc2_sqrt[kAdamMaxGroups];       // sqrt(1 - beta2^t)
   int count;
+  // hipGraph-capturable form: the two per-step scalars of group k are read from device memory, dyn[2 * (dyn_base + k)]
+  // = {step_size, bc2_sqrt}, which the host refreshes before every replay (NULL: the by-value members above)
+  const float* dyn;
+  int dyn_base;
 };
 
 struct AdamConsts { float b2, omb1, omb2, eps; };  // beta2, 1 - beta1, 1 - beta2 (rounded from double as torch does), eps
@@ -403,7 +407,8 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
   float* __restrict__ Gr = G.grad[gi];
   float* __restrict__ M = G.exp_avg[gi];
   float* __restrict__ V = G.exp_avg_sq[gi];
-  const float ss = G.step_size[gi], bs = G.bc2_sqrt[gi];
+  const float ss = G.dyn ? G.dyn[2 * (G.dyn_base + gi)] : G.step_size[gi];
+  const float bs = G.dyn ? G.dyn[2 * (G.dyn_base + gi) + 1] : G.bc2_sqrt[gi];
   const bool vec = ((((uintptr_t)P | (uintptr_t)Gr | (uintptr_t)M | (uintptr_t)V) & 15) == 0) && base + kAdamChunk <= n;
   if (vec) {
 #pragma unroll
@@ -718,6 +723,18 @@ int gigs_masked_l1_bwd(int channels, int height, int width, const float* a, cons
 
 int gigs_adam_step(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
                    void* stream) {
+  return gigs_adam_step_dyn(n_groups, groups, beta1, beta2, eps, zero_grad, nullptr, stream);
+}
+
+void gigs_adam_scalars(double lr, int step, double beta1, double beta2, float* out2) {
+  // torch/optim/adam.py (_single_tensor_adam): python-float bias corrections, then fp32 tensor ops
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  out2[0] = (float)(lr / bc1);
+  out2[1] = (float)sqrt(bc2);
+}
+
+int gigs_adam_step_dyn(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
+                       const float* dyn, void* stream) {
   if (n_groups < 0 || (n_groups > 0 && !groups)) return gigs_internal_fail(GIGS_ERR_INVALID, "adam_step: bad argument");
   hipStream_t s = (hipStream_t)stream;
   void* tok; gigs_internal_stage_begin(26, stream, &tok);
@@ -729,24 +746,33 @@ int gigs_adam_step(int n_groups, const gigs_adam_group* groups, double beta1, do
     int k = 0;
     for (; done < n_groups && k < gigs::kAdamMaxGroups; done++) {
       const gigs_adam_group& g = groups[done];
-      if (g.n < 0 || g.step < 1 || (g.n > 0 && (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq))) {
+      if (g.n < 0 || (!dyn && g.step < 1) || (g.n > 0 && (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq))) {
         gigs_internal_stage_end(tok);
         return gigs_internal_fail(GIGS_ERR_INVALID, "adam_step: bad group");
       }
-      if (g.n == 0) continue;
+      if (g.n == 0) {
+        if (dyn && k > 0) break;  // keep the (dyn_base + k) <-> group index correspondence: close this launch
+        if (dyn) { G.dyn_base = done + 1; }
+        continue;
+      }
       const unsigned long long c = (unsigned long long)((g.n + gigs::kAdamChunk - 1) / gigs::kAdamChunk);
       if (chunks + c > 0x7fffffffull) break;  // next launch
+      if (k == 0) G.dyn_base = done;
       G.param[k] = g.param; G.grad[k] = g.grad; G.exp_avg[k] = g.exp_avg; G.exp_avg_sq[k] = g.exp_avg_sq;
       G.n[k] = g.n;
       G.first_chunk[k] = chunks;
       chunks += (unsigned)c;
       // torch/optim/adam.py (_single_tensor_adam): python-float bias corrections, then fp32 tensor ops
-      const double bc1 = 1.0 - pow(beta1, (double)g.step), bc2 = 1.0 - pow(beta2, (double)g.step);
-      G.step_size[k] = (float)(g.lr / bc1);
-      G.bc2_sqrt[k] = (float)sqrt(bc2);
+      if (!dyn) {
+        float sc[2];
+        gigs_adam_scalars(g.lr, g.step, beta1, beta2, sc);
+        G.step_size[k] = sc[0];
+        G.bc2_sqrt[k] = sc[1];
+      }
       k++;
     }
     G.count = k;
+    G.dyn = dyn;
     G.first_chunk[k] = chunks;
     if (k == 0 || chunks == 0) {
       if (k == 0 && done < n_groups) {  // a single group too large for one grid

@@ -28,7 +28,14 @@ tiny presence-mask all-reduce (MAX) issued together with the bucket, for loops w
 
 Zero-copy packing: `GradSlab.sink()` hands the slab's views to the rasterizer's backward
 (`diff_gaussian_rasterization.grad_sink`), whose kernels then write the per-Gaussian gradients straight into
-the bucket; autograd adopts those tensors as `.grad` without a copy.
+the bucket.  What that saves depends on who hands the gradient to the parameter: `pipeline.WholeStepGraph`
+(torch.autograd.grad inside the capture) assigns the sink tensor itself as `.grad` -- no copy at all; eager
+`loss.backward()` goes through AccumulateGrad, which CLONES a gradient that something else still references (the
+sink dictionary does), so `.grad` is a fresh tensor and `_gather_stray` copies it into the slab once (one copy
+instead of the `torch.cat` of every gradient).  The sink is only meaningful when the rasterizer's inputs ARE the
+leaf parameters: with activations in between, the view receives dL/d(activated input), not the parameter's
+gradient.  `attach()` and the sink are mutually exclusive per parameter (a `.grad` that already aliases the sink
+tensor would be added to itself by AccumulateGrad): `attach(skip=sink)` leaves sinked parameters at `.grad = None`.
 
 Densification statistics must be reduced as STATISTICS, not recomputed from reduced gradients:
 the norm of `means2D.grad[:, :2]` and the abs accumulator are per-view quantities that the
@@ -85,12 +92,26 @@ class GradSlab:
         self._comm = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._work: list = []
         self._pending = False
+        # timing=True: three events per collective (backward done on the compute stream; collective begin / end on the
+        # communication stream), read by comm_stats() after a synchronize
+        self.timing = False
+        self._events: list = []
+        self._bytes = 0
 
-    def rebuild_if_resized(self) -> bool:
-        """After densification the parameter tensors change size: re-carve the slab (returns True if it did)."""
-        if all(v.shape == p.shape for v, p in zip(self.views, self.params)):
+    def rebuild(self, params: Sequence[torch.Tensor]) -> bool:
+        """After densification: the reference REPLACES the nn.Parameter objects (cat_tensors_to_optimizer /
+        _prune_optimizer, scene/gaussian_model.py:595-706), so the caller passes the current list.  Re-carves the slab
+        when any tensor is a new object or has a new shape (returns True if it did); an all-reduce must not be pending."""
+        params = list(params)
+        same = len(params) == len(self.params) and all(a is b and v.shape == a.shape
+                                                       for a, b, v in zip(params, self.params, self.views))
+        if same:
             return False
-        self.__init__(self.params, self.group, self.agree_presence)
+        if self._pending:
+            raise RuntimeError("GradSlab.rebuild: an all-reduce is pending (call wait() first)")
+        timing = self.timing
+        self.__init__(params, self.group, self.agree_presence)
+        self.timing = timing
         return True
 
     def sink(self, names: Sequence[str]) -> Dict[str, torch.Tensor]:
@@ -98,12 +119,15 @@ class GradSlab:
         rasterizer's backward writes the gradient of its input `name` into that view."""
         return {n: v for n, v in zip(names, self.views)}
 
-    def attach(self, zero: bool = True) -> None:
-        """Point every parameter's .grad at its slab view (autograd then accumulates into the slab)."""
+    def attach(self, zero: bool = True, skip: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """Point every parameter's .grad at its slab view (autograd then accumulates into the slab).  `skip`: the
+        dictionary handed to grad_sink -- parameters whose view is a sink target keep `.grad = None`, because the
+        rasterizer's backward OVERWRITES the view and returns it, and AccumulateGrad would then add it to itself."""
         if zero:
             self.flat.zero_()
+        sinked = set(t.data_ptr() for t in skip.values()) if skip else ()
         for p, v in zip(self.params, self.views):
-            p.grad = v
+            p.grad = None if v.data_ptr() in sinked else v
 
     def _gather_stray(self) -> None:
         # a gradient that is not already the slab view (autograd made a fresh tensor) is copied in once
@@ -161,9 +185,17 @@ class GradSlab:
             if rest and float(torch.stack([v.abs().max() for v in rest if v.numel()]).max()) != 0.0:
                 raise RuntimeError("GradSlab.allreduce_async(only=...): a parameter outside `only` has a non-zero gradient")
         self._pieces = pieces
+        self._bytes = sum(p.numel() * p.element_size() for p in pieces)
         if self._comm is not None:
-            self._comm.wait_stream(torch.cuda.current_stream(self.flat.device))
+            main = torch.cuda.current_stream(self.flat.device)
+            ev = None
+            if self.timing:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record(main)
+            self._comm.wait_stream(main)
             with torch.cuda.stream(self._comm):
+                if ev:
+                    ev[1].record(self._comm)
                 for piece in pieces:
                     dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
                 if self.agree_presence:
@@ -171,6 +203,9 @@ class GradSlab:
                 if average:
                     for piece in pieces:
                         piece.div_(world)
+                if ev:
+                    ev[2].record(self._comm)
+                    self._events.append(ev)
         else:  # CPU tensors (gloo tests): genuinely asynchronous work handles
             self._work = [dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for piece in pieces]
             if self.agree_presence:
@@ -195,6 +230,21 @@ class GradSlab:
         for p, v, has in zip(self.params, self.views, pres):
             p.grad = v if has > 0 else None
         self._pending = False
+
+    def comm_stats(self, reset: bool = True) -> Optional[Dict[str, float]]:
+        """Averages over the collectives issued since the last reset (timing=True; call after a synchronize):
+        `allreduce_ms` = the collective itself on the communication stream, `exposed_ms` = from the end of the backward
+        on the compute stream to the end of the collective -- what a step that consumes the reduced gradients right
+        away (wait() directly after allreduce_async(), as bench.py does) pays for it -- and `bytes` per collective."""
+        if not self._events:
+            return None
+        n = len(self._events)
+        out = {"collectives": n, "bytes": int(self._bytes),
+               "allreduce_ms": round(sum(e[1].elapsed_time(e[2]) for e in self._events) / n, 4),
+               "exposed_ms": round(sum(e[0].elapsed_time(e[2]) for e in self._events) / n, 4)}
+        if reset:
+            self._events = []
+        return out
 
     def allreduce(self, average: bool = False) -> torch.Tensor:
         self.allreduce_async(average)

@@ -94,6 +94,8 @@ SIGNATURES = {
     "gigs_masked_l1_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_masked_l1_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_adam_step": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, C.c_void_p]),
+    "gigs_adam_step_dyn": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, _f, C.c_void_p]),
+    "gigs_adam_scalars": (None, [C.c_double, _i, C.c_double, C.c_double, C.POINTER(C.c_float)]),
     "gigs_activate_fwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gigs_activate_bwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gigs_densify_stats": (_i, [_i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),

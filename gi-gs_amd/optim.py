@@ -100,3 +100,110 @@ class FusedAdam(torch.optim.Optimizer):
                 gigs_lib.check(_lib.gigs_adam_step(len(groups), C.cast(arr, C.c_void_p), b1, b2, eps,
                                                    int(bool(zero_grad)), stream), "adam_step")
         return loss
+
+
+class CapturedAdam:
+    """FusedAdam's update as a hipGraph-capturable launch (pipeline.WholeStepGraph captures it behind the backward).
+
+    A captured kernel's by-value arguments are frozen, but Adam's step size changes every iteration (bias corrections,
+    learning-rate schedules).  The launch captured here reads the two per-step scalars of every group -- lr / (1 - b1^t)
+    and sqrt(1 - b2^t) -- from a small DEVICE table (gigs_adam_step_dyn); `advance()` -- called by the host before each
+    replay -- counts the step in the optimizer's state (so state_dict() / the reference's densification code see what
+    torch.optim.Adam would have written), evaluates the scalars exactly as the eager launch does (gigs_adam_scalars:
+    double arithmetic, torch's order) for the CURRENT param_group["lr"], and queues one pinned-memory copy of the table.
+
+        cap = CapturedAdam([gaussian_optimizer, light_optimizer], params, grads)   # grads: the graph's static buffers
+        with torch.cuda.graph(g): cap.launch()                                      # inside the capture
+        each step: cap.advance(); g.replay()
+
+    Every listed parameter must have a gradient buffer (a parameter without one is simply not listed: its moments and
+    step count stay untouched, as torch.optim.Adam leaves a parameter whose .grad is None)."""
+
+    def __init__(self, optimizers, params, grads):
+        self.entries = []  # (optimizer, group, parameter, gradient buffer)
+        by_id = {id(p): g for p, g in zip(params, grads) if g is not None}
+        self.buckets = {}
+        dev = None
+        for opt in optimizers:
+            if not isinstance(opt, FusedAdam):
+                raise TypeError("CapturedAdam needs FusedAdam optimizers")
+            for group in opt.param_groups:
+                key = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))
+                for p in group["params"]:
+                    gr = by_id.get(id(p))
+                    if gr is None:
+                        continue
+                    if (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or gr.dtype != torch.float32
+                            or not gr.is_contiguous() or gr.shape != p.shape):
+                        raise RuntimeError("CapturedAdam: parameters and gradient buffers must be contiguous fp32 on the GPU")
+                    dev = p.device if dev is None else dev
+                    st = opt.state[p]
+                    if len(st) == 0:
+                        st["step"] = torch.tensor(0.0)
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    self.buckets.setdefault(key, []).append(len(self.entries))
+                    self.entries.append((opt, group, p, gr))
+        if not self.entries:
+            raise ValueError("CapturedAdam: no parameter with a gradient buffer")
+        self.device = dev
+        n = len(self.entries)
+        # table rows follow the launch order: bucket by bucket
+        self.order = [i for idx in self.buckets.values() for i in idx]
+        self.table = torch.zeros(n, 2, dtype=torch.float32, device=dev)
+        self.host = torch.zeros(n, 2, dtype=torch.float32).pin_memory()
+        self._sc = (C.c_float * 2)()
+
+    def warmup(self) -> None:
+        CapturedAdam.warmup_device(self.device)
+
+    @staticmethod
+    def warmup_device(device) -> None:
+        """One launch of the kernel on a scratch group, OUTSIDE any capture (the first launch of a kernel loads its code
+        object, which must not happen while a stream is capturing)."""
+        t = [torch.zeros(16, dtype=torch.float32, device=device) for _ in range(4)]
+        tab = torch.ones(2, dtype=torch.float32, device=device)
+        grp = (gigs_lib.AdamGroup * 1)(gigs_lib.AdamGroup(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                                                          16, 0.0, 0))
+        with torch.cuda.device(device):
+            gigs_lib.check(_lib.gigs_adam_step_dyn(1, C.cast(grp, C.c_void_p), 0.9, 0.999, 1e-8, 0, tab.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream), "adam_step_dyn")
+            torch.cuda.current_stream().synchronize()
+
+    def key(self):
+        """What a capture depends on: the tensors' addresses (a replaced parameter / moment needs a re-capture)."""
+        return tuple((p.data_ptr(), gr.data_ptr(), o.state[p]["exp_avg"].data_ptr(), o.state[p]["exp_avg_sq"].data_ptr())
+                     for o, _, p, gr in self.entries)
+
+    def launch(self) -> None:
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            row = 0
+            for (b1, b2, eps), idx in self.buckets.items():
+                groups = []
+                for i in idx:
+                    o, _, p, gr = self.entries[i]
+                    st = o.state[p]
+                    groups.append(gigs_lib.AdamGroup(p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(),
+                                                     st["exp_avg_sq"].data_ptr(), p.numel(), 0.0, 0))
+                arr = (gigs_lib.AdamGroup * len(groups))(*groups)
+                gigs_lib.check(_lib.gigs_adam_step_dyn(len(groups), C.cast(arr, C.c_void_p), b1, b2, eps, 0,
+                                                       self.table[row:].data_ptr(), stream), "adam_step_dyn")
+                row += len(idx)
+
+    def advance(self) -> None:
+        """Host side of one update: step counts += 1, table := this step's scalars (async copy on the current stream)."""
+        for row, i in enumerate(self.order):
+            o, group, p, _ = self.entries[i]
+            st = o.state[p]
+            st["step"] += 1
+            _lib.gigs_adam_scalars(float(group["lr"]), int(st["step"]), float(group["betas"][0]), float(group["betas"][1]),
+                                   self._sc)
+            self.host[row, 0], self.host[row, 1] = self._sc[0], self._sc[1]
+        self.table.copy_(self.host, non_blocking=True)
+
+    def retreat(self) -> None:
+        """Undo advance() for a step that is being repeated (binning overflow: its update was never replayed)."""
+        for i in self.order:
+            o, _, p, _ = self.entries[i]
+            o.state[p]["step"] -= 1

@@ -351,8 +351,10 @@ class WholeStepGraph:
     in place needs no copy; tensors replaced by densification trigger a re-capture); the camera matrices, view_dirs
     and gt_image are copied into fixed buffers before the replay (skipped when the caller passes the captured tensor).
     Gradients come from torch.autograd.grad inside the backward capture (no AccumulateGrad nodes, which would run on
-    the parameters' creation stream) and are handed out as `.grad` after the replay: assigned when `.grad` is None,
-    added otherwise -- the semantics of loss.backward().  With dp.GradSlab's sink active during the capture the
+    the parameters' creation stream) and are handed out as `.grad` after the replay: assigned when `.grad` is None
+    (the graph's static output buffer itself, no copy), added otherwise -- the semantics of loss.backward().  A caller
+    that accumulates over views without clearing still holds the previous hand-out, which the next replay overwrites:
+    such a `.grad` is moved into a tensor of its own before the replay (one clone, only in that case).  With dp.GradSlab's sink active during the capture the
     rasterizer's backward writes straight into the slab, as in the eager step.
 
     Binning runs under AsyncBinning (fixed capacity, nothing read back inside the step); the counters are copied to
@@ -362,10 +364,10 @@ class WholeStepGraph:
 
     def __init__(self, owner: "Stage2Step", cam: Dict, g: Dict[str, torch.Tensor]):
         self.owner = owner
-        self.dev = g["means3D"].device
+        self.dev = next(iter(g.values())).device
         self.cfg = (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"]))
         self.capacity = 0
-        self.gf = self.gb = self.key = None
+        self.gf = self.gb = self.go = self.key = self.adam = None
         self.recaptures = 0
         self.fwd_done = torch.cuda.Event()
         self._packs = {}
@@ -379,24 +381,30 @@ class WholeStepGraph:
         import diff_gaussian_rasterization as dgr
         sink = dgr._grad_sink or {}
         return (tuple((t.data_ptr(), tuple(t.shape)) for t in self._params(g)),
-                tuple(sorted((k, v.data_ptr()) for k, v in sink.items())))
+                tuple(sorted((k, v.data_ptr()) for k, v in sink.items())),
+                self.adam.key() if self.adam is not None else None)
 
     def _capture(self, cam, g, gt_image, view_dirs):
         import gc
         o = self.owner
         H, W, _, _ = self.cfg
         bg = torch.zeros(3, device=self.dev)
+        prep = o.prepare if o.prepare is not None else (lambda raw: raw)
+        with torch.no_grad():
+            ga = prep(g)  # the rasterizer's inputs (for the probe and the shapes); the capture re-derives them
         if self.capacity <= 0:
-            probe = GraphedRaster(cam, g, o.gi, o.sh_degree)._probe(cam, g, bg)
+            probe = GraphedRaster(cam, ga, o.gi, o.sh_degree)._probe(cam, ga, bg)
             tiles = ((H + 15) // 16) * ((W + 15) // 16)
             if probe > BUCKET_MAX_MEAN_LIST * tiles:
                 raise DenseScene(f"{probe} instances over {tiles} tiles")
             self.capacity = max(65536, -(-2 * probe // 65536) * 65536)
         self.bin = AsyncBinning(self.capacity, self.dev)
-        self.inner = Stage2Step(o.light, o.brdf_lut, o.gi, o.sh_degree, graphs=False, fused=True, **o.flags)
+        self.inner = Stage2Step(o.light, o.brdf_lut, o.gi, o.sh_degree, graphs=False, fused=True, regularizer=o.regularizer,
+                                **o.flags)
         self.inner._defer_backward = True
         self.inner._static_bg = bg
-        self.inner._static_m2d = torch.zeros_like(g["means3D"], requires_grad=True)
+        self.inner._static_m2d = torch.zeros_like(ga["means3D"], requires_grad=True)
+        del ga
         # the three camera tensors are views of ONE static buffer: one copy per step
         self.s_pack = self._pack(cam).clone()
         self.s_cam = dict(cam)
@@ -416,11 +424,18 @@ class WholeStepGraph:
         with torch.cuda.stream(side):
             for _ in range(2):
                 with self.bin:
-                    res = self.inner(self.s_cam, g, self.s_gt, self.s_vd)
+                    res = self.inner(self.s_cam, prep(g), self.s_gt, self.s_vd)
                 torch.autograd.grad(res.pop("_loss"), params + [res["viewspace_points"]], allow_unused=True)
                 del res
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if o.optimizers:
+            from optim import CapturedAdam
+            CapturedAdam.warmup_device(self.dev)
+            if o.post_update is not None:
+                with torch.no_grad():
+                    o.post_update()  # idempotent (a clamp): run once outside the capture as its warm-up
+            torch.cuda.synchronize()
         gc.collect()
         was = gc.isenabled()
         gc.disable()  # see graphed(): a cyclic-GC pass during capture may destroy HIP objects, which HIP refuses
@@ -434,7 +449,7 @@ class WholeStepGraph:
             # calls of its own, which the default (global) capture mode turns into a capture failure
             with torch.cuda.graph(gf, stream=cap, capture_error_mode="thread_local"):
                 with self.bin:
-                    res = self.inner(self.s_cam, g, self.s_gt, self.s_vd)
+                    res = self.inner(self.s_cam, prep(g), self.s_gt, self.s_vd)
                 self.bin.host.copy_(self.bin.counters, non_blocking=True)
             loss = res.pop("_loss")
             # The blend backward and the light's GGX backward become ready together (after the shade backward).  The
@@ -450,10 +465,22 @@ class WholeStepGraph:
             finally:
                 light_ops.bwd_head_start_ns = 0
             del loss
+            go = adam = None
+            if o.optimizers:
+                # the update as a third graph (train.py:517-522): it is replayed only once the host has seen that the
+                # forward's binning did not overflow, and -- multi-GPU -- after the gradient all-reduce
+                from optim import CapturedAdam
+                adam = CapturedAdam(o.optimizers, params, list(grads[:-1]))
+                go = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(go, pool=gf.pool(), stream=cap, capture_error_mode="thread_local"):
+                    adam.launch()
+                    if o.post_update is not None:
+                        with torch.no_grad():
+                            o.post_update()
         finally:
             if was:
                 gc.enable()
-        self.gf, self.gb, self.res = gf, gb, res
+        self.gf, self.gb, self.go, self.adam, self.res = gf, gb, go, adam, res
         self.grads, self.vp_grad = list(grads[:-1]), grads[-1]
         self.key = self._key(g)
         self.recaptures += 1
@@ -489,6 +516,12 @@ class WholeStepGraph:
             self._fill("camera", self.s_pack, self._pack(cam))
             self._fill("view_dirs", self.s_vd, view_dirs)
             self._fill("gt_image", self.s_gt, gt_image)
+            # gradient accumulation over views: a parameter that still holds the buffer handed out by the previous step
+            # (the caller did not clear it) would see that buffer overwritten by this replay -- keep the old values in a
+            # tensor of its own, the hand-out below then adds to it
+            for p, gr in zip(self._params(g), self.grads):
+                if gr is not None and p.grad is not None and p.grad.data_ptr() == gr.data_ptr():
+                    p.grad = p.grad.clone()
             self.gf.replay()
             self.fwd_done.record()
             self.gb.replay()
@@ -499,13 +532,21 @@ class WholeStepGraph:
                 self.gf = None
                 continue
             params = self._params(g)
-            for p, gr in zip(params, self.grads):
-                if gr is None:
-                    continue
-                if p.grad is None:
-                    p.grad = gr
-                elif p.grad is not gr and p.grad.data_ptr() != gr.data_ptr():
-                    p.grad.add_(gr)
+            if self.go is not None:
+                # complete iteration: all-reduce (multi-GPU) -> Adam + clamp from the third graph; the gradients are
+                # consumed inside the step, the parameters keep .grad = None (zero_grad(set_to_none=True), train.py:518)
+                if self.owner.before_update is not None:
+                    self.owner.before_update()
+                self.adam.advance()
+                self.go.replay()
+            else:
+                for p, gr in zip(params, self.grads):
+                    if gr is None:
+                        continue
+                    if p.grad is None:
+                        p.grad = gr  # the graph's static output itself (or the all-reduce slab's view under grad_sink)
+                    else:
+                        p.grad.add_(gr)
             vp = self.res["viewspace_points"]
             vp.grad = self.vp_grad
             out = dict(self.res)
@@ -582,7 +623,17 @@ class Stage2Step:
     individually.  Results are identical to graphs=False (same kernels, same order)."""
 
     def __init__(self, light, brdf_lut, gi: Dict, sh_degree: int, metallic: bool = True, indirect: bool = True,
-                 gamma: bool = False, tone: bool = False, graphs: bool = False, fused: bool = False):
+                 gamma: bool = False, tone: bool = False, graphs: bool = False, fused: bool = False,
+                 prepare=None, regularizer=None, optimizers=None, post_update=None, before_update=None):
+        """The last five arguments turn the step into a COMPLETE training iteration (train_iteration.Stage2Trainer):
+        `prepare(raw) -> g` maps the optimizer's tensors to the rasterizer's inputs (the GaussianModel getters;
+        `__call__` then takes the raw dictionary), `regularizer(maps) -> scalar` adds the BRDF / envmap terms of
+        train.py:387-420 (maps: normal_map, albedo_map, roughness_map, metallic_map -- the rasterizer's planes --
+        and gt_image), `optimizers` (FusedAdam) are stepped after the backward, `before_update()` runs between the two
+        (the multi-GPU gradient all-reduce) and `post_update()` after (cubemap.clamp_, train.py:522).  All of it is
+        part of the captured step when graphs=True (pipeline.WholeStepGraph)."""
+        self.prepare, self.regularizer, self.optimizers = prepare, regularizer, list(optimizers or [])
+        self.post_update, self.before_update = post_update, before_update
         self.gi, self.sh_degree, self.metallic = gi, sh_degree, metallic
         self.fused, self.light, self.brdf_lut = fused, light, brdf_lut
         self.flags = dict(metallic=metallic, indirect=indirect, gamma=gamma, tone=tone)
@@ -607,7 +658,7 @@ class Stage2Step:
                  extra_loss=None):
         """extra_loss(normal_map, albedo_map, roughness_map, metallic_map) -> scalar added to the loss before
         backward (the BRDF / envmap regularisers of train.py:387-420; see gi-gs_amd/losses.py)."""
-        dev = g["means3D"].device
+        raw = g
         if (self.fused and self.graphs and extra_loss is None and os.environ.get("GIGS_STEP_GRAPH", "1") == "1"
                 and os.environ.get("GIGS_RASTER_GRAPH", "0") != "1" and not getattr(self, "_dense", False)):
             try:
@@ -618,12 +669,32 @@ class Stage2Step:
                     if self.whole is None and len(self._wholes) < 4:
                         self.whole = self._wholes[cfg] = WholeStepGraph(self, cam, g)
                 if self.whole is not None:
-                    return self.whole(cam, g, gt_image, view_dirs)
+                    return self.whole(cam, raw, gt_image, view_dirs)
                 # more than four distinct camera models: the fifth onwards takes the piecewise path below
             except DenseScene:
                 self._dense = True  # synchronous binning with the global radix sort: the rasterizer stays eager
                 self.whole = None
                 self._wholes.clear()
+        regen = (lambda: self.prepare(raw)) if self.prepare is not None else None
+        if regen is not None:
+            g = regen()
+        res = self._step(cam, g, gt_image, view_dirs, extra_loss, regen)
+        if self.optimizers:  # complete iteration, eager formulation: train.py:517-522
+            if self.before_update is not None:
+                self.before_update()
+            for o in self.optimizers:
+                o.step()
+            for leaf in self._leaves(raw):
+                leaf.grad = None  # zero_grad(set_to_none=True)
+            if self.post_update is not None:
+                with torch.no_grad():
+                    self.post_update()
+        return res
+
+    def _step(self, cam, g, gt_image, view_dirs, extra_loss=None, regen=None):
+        """Everything but WholeStepGraph: the chained-graph formulation (GIGS_RASTER_GRAPH=1) and the eager ones.
+        `regen()` rebuilds the rasterizer's inputs from the raw parameters for a repeated step (binning overflow)."""
+        dev = g["means3D"].device
         if self.fused and self.graphs and os.environ.get("GIGS_RASTER_GRAPH", "0") == "1" and not getattr(self, "_dense", False):
             try:
                 return self._graphed_step(cam, g, gt_image, view_dirs, extra_loss)
@@ -650,6 +721,7 @@ class Stage2Step:
         abin = None
         if self.fused and self.graphs and os.environ.get("GIGS_RASTER_ASYNC", "1") == "1" and not getattr(self, "_dense", False):
             abin = self._eager_async(cam, g, background)
+        pre_grads = _snapshot_grads(self._leaves(g)) if abin is not None else None
         try:
             with hook, (abin if abin is not None else _NULLCTX):
                 if self.pool is not None:
@@ -675,9 +747,8 @@ class Stage2Step:
                     res["num_rendered"] = abin.check()
                 except BinningOverflow as ex:
                     self._abin = AsyncBinning(-(-int(1.5 * ex.needed) // 65536) * 65536, dev)
-                    for t in list(g.values()) + list(self.light.parameters()):
-                        t.grad = None
-                    return self.__call__(cam, g, gt_image, view_dirs, extra_loss)
+                    _restore_grads(pre_grads)  # the overflowed step's contribution is dropped, earlier ones are kept
+                    return self._step(cam, regen() if regen is not None else g, gt_image, view_dirs, extra_loss, regen)
             return res
         front_args = (normal_map_from_depth, normal_map, out_normal_view, albedo_map, roughness_map, metallic_map,
                       occlusion_map.detach(), st.viewmatrix, view_dirs)
@@ -695,9 +766,39 @@ class Stage2Step:
         loss, render_rgb = self.loss_fn(render_direct, IRR, gt_image, normal_mask_f, roughness_f, metallic_f)
         if extra_loss is not None:
             loss = loss + extra_loss(normal_map, albedo_map, roughness_map, metallic_map)
+        if self.regularizer is not None:
+            loss = loss + self.regularizer(dict(normal_map=normal_map, albedo_map=albedo_map, roughness_map=roughness_map,
+                                                metallic_map=metallic_map, gt_image=gt_image))
         loss.backward()
         return dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct.detach(),
                     IRR=IRR.detach(), viewspace_points=screenspace_points, radii=radii)
+
+
+def _grad_leaves(t: torch.Tensor):
+    """The leaf tensors whose .grad a backward through `t` accumulates into (t itself if it is a leaf)."""
+    if t.grad_fn is None:
+        return [t] if t.requires_grad else []
+    out, seen, todo = [], set(), [t.grad_fn]
+    while todo:
+        fn = todo.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        if hasattr(fn, "variable"):
+            out.append(fn.variable)
+        todo.extend(nf for nf, _ in fn.next_functions)
+    return out
+
+
+def _snapshot_grads(leaves):
+    """[(leaf, None | copy of its .grad)]: what a step that may have to be repeated (binning overflow) must restore.
+    Costs nothing in the usual case (gradients cleared before the step); one clone per tensor when accumulating."""
+    return [(p, None if p.grad is None else p.grad.clone()) for p in leaves]
+
+
+def _restore_grads(snapshot):
+    for p, gr in snapshot or ():
+        p.grad = gr
 
 
 class _NullCtx:
@@ -733,6 +834,7 @@ def _graphed_step(self, cam, g, gt_image, view_dirs, extra_loss=None):
     if self.step_begin is None:
         self.step_begin = torch.cuda.Event()
         self._bg = torch.zeros(3, device=dev)  # train.py:263-264: black background for PBR
+    pre_grads = _snapshot_grads(self._leaves(g))
     for attempt in range(4):
         self.step_begin.record()
         lights = list(self._fused_begin(self.step_begin))
@@ -756,8 +858,7 @@ def _graphed_step(self, cam, g, gt_image, view_dirs, extra_loss=None):
             res["num_rendered"] = self.graster.check()
             return res
         except BinningOverflow:
-            for t in list(g.values()) + list(self.light.parameters()):
-                t.grad = None
+            _restore_grads(pre_grads)
     raise RuntimeError("Stage2Step: the binning capacity kept overflowing")
 
 
@@ -822,6 +923,9 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     loss, render_rgb, render_direct, IRR = self.back(*args)
     if extra_loss is not None:
         loss = loss + extra_loss(normal_map, albedo_map, roughness_map, metallic_map)
+    if self.regularizer is not None:
+        loss = loss + self.regularizer(dict(normal_map=normal_map, albedo_map=albedo_map, roughness_map=roughness_map,
+                                            metallic_map=metallic_map, gt_image=gt_image))
     res = dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct, IRR=IRR,
                viewspace_points=screenspace_points, radii=radii)
     if self._defer_backward:
@@ -831,6 +935,17 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     return res
 
 
+def _leaves(self, g):
+    out, seen = [], set()
+    for t in list(g.values()) + list(self.light.parameters()):
+        for leaf in _grad_leaves(t):
+            if id(leaf) not in seen:
+                seen.add(id(leaf))
+                out.append(leaf)
+    return out
+
+
+Stage2Step._leaves = _leaves
 Stage2Step._eager_async = _eager_async
 Stage2Step._graphed_step = _graphed_step
 Stage2Step._fused_begin = _fused_begin

@@ -372,6 +372,13 @@ int gigs_masked_l1_bwd(int channels, int height, int width, const float* a, cons
                        const float* loss_count, const float* g_loss, float* g_a, float* g_b, void* stream);
 int gigs_adam_step(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
                    void* stream);
+/* hipGraph-capturable form (gigs-hip extension): the per-step scalars of group k -- {lr / (1 - beta1^t), sqrt(1 - beta2^t)}
+ * -- are read by the kernel from DEVICE memory, dyn[2k], dyn[2k+1] (k = index into `groups`; the groups' lr / step members
+ * are ignored), so a captured launch stays valid while the host refreshes the table before every replay.
+ * gigs_adam_scalars computes one group's pair exactly as gigs_adam_step does (double arithmetic, torch's order). */
+int gigs_adam_step_dyn(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
+                       const float* dyn, void* stream);
+void gigs_adam_scalars(double lr, int step, double beta1, double beta2, float* out2);
 
 /* The parameter getters of GaussianModel (scene/gaussian_model.py:48-58, 178-263) as one pass each way:
  * shs = cat(f_dc [P,1,3], f_rest [P,K-1,3]) -> [P,K,3]; opacities / albedo / roughness / metallic = sigmoid(raw);

@@ -81,6 +81,23 @@ def _worker(rank, world, port, out_dir):
     except RuntimeError:
         only_caught = True
 
+    # densification replaces the parameter OBJECTS (cat_tensors_to_optimizer, scene/gaussian_model.py:669-706): the slab is
+    # rebuilt from the current list and reduces the grown tensors
+    grown = [torch.zeros(P + 5 + rank * 0, 3, requires_grad=True), params[1]]
+    slab2 = dp.GradSlab(params[:2])
+    assert slab2.rebuild(params[:2]) is False
+    assert slab2.rebuild(grown) is True and slab2.views[0].shape == (P + 5, 3) and slab2.flat.numel() == (P + 5) * 3 + params[1].numel()
+    gg = [torch.randn(p.shape, generator=g) for p in grown]
+    for p, t in zip(grown, gg):
+        p.grad = t.clone()
+    slab2.allreduce_async()
+    slab2.wait()
+    rebuilt = dict(local=gg, reduced=[p.grad.clone() for p in grown])
+    # attach(skip=sink): sinked parameters keep .grad = None, the rest alias the slab
+    sk = slab2.sink(["a"])
+    slab2.attach(skip=sk)
+    assert grown[0].grad is None and grown[1].grad.data_ptr() == slab2.views[1].data_ptr()
+
     # statistics
     vg = torch.randn(P, 3, generator=g)
     radii = torch.randint(0, 30, (P,), generator=g)
@@ -102,7 +119,7 @@ def _worker(rank, world, port, out_dir):
     dens = {n: model["params"][n].clone() for n in densify_ref.NAMES}
     assert dens["xyz"].shape[0] != P  # something was cloned / split / pruned
     views = [dp.view_for(s, rank, world, 7) for s in range(5)]
-    torch.save(dict(conv=conv, local=grads, slab=out, only=only_out, only_caught=only_caught, vg=vg, radii=radii, stats=st, views=views, dens=dens),
+    torch.save(dict(conv=conv, local=grads, slab=out, only=only_out, rebuilt=rebuilt, only_caught=only_caught, vg=vg, radii=radii, stats=st, views=views, dens=dens),
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -133,6 +150,9 @@ def test_view_parallel_reduction_world2(tmp_path):
             want = r[0]["only"]["local"][i] + r[1]["only"]["local"][i] if i in (1, 2, 4) else torch.zeros_like(r[0]["only"]["local"][i])
             torch.testing.assert_close(r[k]["only"]["reduced"][i], want)
     assert r[0]["only_caught"] and r[1]["only_caught"]
+    for i in range(2):  # the slab rebuilt around a grown parameter
+        for k in range(world):
+            torch.testing.assert_close(r[k]["rebuilt"]["reduced"][i], r[0]["rebuilt"]["local"][i] + r[1]["rebuilt"]["local"][i])
     # statistics: sums of per-view norms (NOT the norm of the summed gradient), max of radii and of the abs term
     vis = [x["radii"] > 0 for x in r]
     zero = torch.zeros(1)

@@ -145,7 +145,7 @@ def test_c3_inference_planes():
         np.testing.assert_array_equal(ha[k], hb[k])
 
 
-def _oracle_parity(orc, sc, cam, deg, light_res, tag, grads_only=None):
+def _oracle_parity(orc, sc, cam, deg, light_res, tag, grads_only=None, per_pixel=False):
     """One view through the product (timed formulation: fused stage-2 node) and through the oracle composition."""
     import pbr
     from oracle import parity
@@ -156,9 +156,26 @@ def _oracle_parity(orc, sc, cam, deg, light_res, tag, grads_only=None):
         gi = scenes.GI_DEFAULTS
         gpu = parity.gpu_capture(sc, cam, gi, deg, light=light, brdf_lut=pbr.get_brdf_lut().to(DEV), grads_only=grads_only, dev=DEV)
         ref, _ = parity.oracle_capture(orc, sc, cam, gi, deg, light_base=gpu["light_base"], grads_only=grads_only)
+        noise = parity.march_noise(orc, sc, cam, gi, deg, gpu, ref, light=light, brdf_lut=pbr.get_brdf_lut().to(DEV),
+                                   dev=DEV) if per_pixel else None
     finally:
         orc.set_threads(min(8, orc.max_threads()))
     rep = parity.compare(gpu, ref)
+    if noise is not None:
+        # The per-pixel reading of north_star's 1e-4: the GI planes have ISOLATED outliers (a march sample that rounds to
+        # the neighbouring pixel at a depth edge flips one ray's hit: up to ~3e-3 on occlusion) on top of a 1e-7 mean.  The
+        # reference's own arithmetic has them too: the oracle against its FMA-contracted twin (nvcc's default contraction)
+        # is the yardstick.  The default march may change at most twice as many elements beyond 1e-4 as that twin does
+        # (floor: 2e-5 of the plane), the exact march likewise; everything else is within 1e-4 by the definition of the
+        # fraction, and the means are asserted below.
+        rep["gi_per_pixel"] = noise
+        for k, tw in noise["oracle_vs_fma_twin"].items():
+            bar = 2.0 * max(tw["frac_over_1e-4"], 1e-5)
+            for who in ("default_vs_oracle", "exact_vs_oracle"):
+                got = noise[who][k]
+                print(tag, k, who, "frac>1e-4 %.2e (twin %.2e) max %.2e" % (got["frac_over_1e-4"], tw["frac_over_1e-4"], got["max"]))
+                assert got["frac_over_1e-4"] <= bar, (tag, k, who, got, tw)
+                assert got["max"] <= 10.0 * max(tw["max"], 1e-3), (tag, k, who, got, tw)
     print(tag, {k: rep[k] for k in ("num_rendered", "n_contrib_flips", "worst_plane_mean_l1", "worst_grad_rel_l1", "psnr_render_rgb")})
     # north_star: bit-exact tile/point indices ...
     assert rep["num_rendered"][0] == rep["num_rendered"][1], tag
@@ -181,7 +198,7 @@ def test_c2_full_size_matches_oracle(orc):
     roughness-0.08 level), GI step 16 / start 8 -- against the oracle, through the same fused stage-2 node bench.py times."""
     sc = scenes.surface_scene(P=300_000, sh_degree=2, seed=0)
     cam = scenes.orbit_camera(5, 64, 800, 800, radius=3.5)
-    rep = _oracle_parity(orc, sc, cam, 2, 256, "C2", grads_only=("albedo", "roughness", "metallic"))
+    rep = _oracle_parity(orc, sc, cam, 2, 256, "C2", grads_only=("albedo", "roughness", "metallic"), per_pixel=True)
     assert rep["num_rendered"][0] > 1_000_000
 
 

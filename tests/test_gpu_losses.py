@@ -284,3 +284,56 @@ def test_fused_activations_match_the_getters():
             assert torch.allclose(gg[:3], w[:3], rtol=1e-5)
             gg, w = gg[3:], w[3:]
         assert (gg - w).abs().max().item() <= 1e-5 * max(w.abs().max().item(), 1e-30), n
+
+
+def test_captured_adam_in_a_hipgraph_equals_the_eager_launch():
+    """optim.CapturedAdam (gigs_adam_step_dyn: per-step scalars read from a device table) replayed from a hipGraph gives the
+    parameters, moments and step counts of FusedAdam.step() bit for bit, with a learning-rate schedule, two optimizers and
+    a parameter that has no gradient buffer."""
+    import optim
+    dev = _dev()
+    torch.manual_seed(5)
+    shapes = [(1237, 3), (1237, 8, 3), (1237, 1), (3,), (6, 64, 64, 3), (77, 4)]
+    init = [torch.randn(s) for s in shapes]
+
+    def make():
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        a = optim.FusedAdam([{"params": [p], "lr": 1e-3 * (i + 1), "name": str(i)} for i, p in enumerate(ps[:4])], lr=0.0, eps=1e-15)
+        b = optim.FusedAdam([{"params": ps[4:], "lr": 0.05}], lr=0.05)
+        return ps, a, b
+
+    ref_p, ref_a, ref_b = make()
+    got_p, got_a, got_b = make()
+    bufs = [torch.zeros_like(p) for p in got_p]
+    bufs[5] = None  # no gradient buffer: untouched, like a parameter whose .grad is None
+    cap = optim.CapturedAdam([got_a, got_b], got_p, bufs)
+    cap.warmup()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cap.launch()
+    for it in range(1, 7):
+        for ga, gb in zip(ref_a.param_groups, got_a.param_groups):
+            ga["lr"] = gb["lr"] = ga["lr"] * 0.8
+        for i, (pr, pg) in enumerate(zip(ref_p, got_p)):
+            g = (torch.randn(pr.shape) * (10.0 ** (it % 3 - 1))).to(dev)
+            pr.grad = None if i == 5 else g.clone()
+            if bufs[i] is not None:
+                bufs[i].copy_(g)
+        ref_a.step()
+        ref_b.step()
+        cap.advance()
+        graph.replay()
+        torch.cuda.synchronize()
+        for i, (pr, pg) in enumerate(zip(ref_p, got_p)):
+            assert torch.equal(pr.detach(), pg.detach()), (it, i)
+        for ro, go in ((ref_a, got_a), (ref_b, got_b)):
+            for gr_, gg_ in zip(ro.param_groups, go.param_groups):
+                for pr, pg in zip(gr_["params"], gg_["params"]):
+                    sr, sg = ro.state.get(pr, {}), go.state.get(pg, {})
+                    if not sr:
+                        assert not sg or int(sg["step"]) == 0
+                        continue
+                    assert int(sr["step"]) == int(sg["step"]) == it
+                    assert torch.equal(sr["exp_avg"], sg["exp_avg"]) and torch.equal(sr["exp_avg_sq"], sg["exp_avg_sq"])
+    cap.retreat()
+    assert int(got_a.state[got_p[0]]["step"]) == 5

@@ -478,6 +478,17 @@ def test_whole_step_graph_gradient_semantics_and_recapture(monkeypatch):
     for k in acc:
         want = (ref[0][1][k] + ref[1][1][k]).cpu().numpy()
         assert rel_peak(acc[k].cpu().numpy(), want) < 2e-3, k
+    # (2b) accumulation WITHOUT re-assignment (ordinary gradient accumulation over views): the parameters still hold the
+    # buffers the previous step handed out, which the next replay overwrites -- the sum must come out all the same
+    for t in list(g.values()) + [light.base]:
+        t.grad = None
+    step(camts[0], g, gt, vds[0])
+    step(camts[1], g, gt, vds[1])
+    torch.cuda.synchronize()
+    acc = grads(g, light)
+    for k in acc:
+        want = (ref[0][1][k] + ref[1][1][k]).cpu().numpy()
+        assert rel_peak(acc[k].cpu().numpy(), want) < 2e-3, ("accumulate in place", k)
     # (3) a replaced parameter tensor (same values): one re-capture, same results
     g["albedo"] = g["albedo"].detach().clone().requires_grad_(True)
     for t in list(g.values()) + [light.base]:
@@ -595,3 +606,48 @@ def test_whole_step_graph_writes_gradients_into_the_all_reduce_slab(monkeypatch)
     for a, b in zip(eager, graph):
         assert rel_peak(b.cpu().numpy(), a.cpu().numpy()) < 2e-3
     assert float((graph[0] - graph[1]).abs().max()) > 0  # two views, two different gradients in the same slab
+
+
+def test_grad_slab_attach_with_sink_does_not_double_gradients():
+    """dp.GradSlab.attach() + grad_sink on the EAGER path: a parameter whose .grad already aliases the sink tensor would
+    be added to itself by AccumulateGrad (the rasterizer's backward overwrites the view and returns it).  attach(skip=sink)
+    leaves sinked parameters at .grad = None; after _gather_stray the slab holds exactly the plain backward's gradients."""
+    import diff_gaussian_rasterization as dgr
+    import dp
+    import pbr
+    import pipeline
+    sc = scenes.surface_scene(P=5000, sh_degree=2, seed=33, scale_mu=0.025)
+    gi = scenes.GI_DEFAULTS
+    H, W = 128, 160
+    cam = scenes.orbit_camera(1, 6, W, H, radius=3.5)
+    camt = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    torch.manual_seed(3)
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    vd = pipeline.view_dirs_for(camt, pipeline.canonical_rays(cam, DEV), DEV)
+    order = ["means3D", "opacities", "normal", "shs", "scales", "rotations", "albedo", "roughness", "metallic"]
+    names = {"opacities": "opacity", "shs": "sh"}
+
+    def run(mode):
+        torch.manual_seed(9)
+        light = pbr.CubemapLight(base_res=64, device=DEV)
+        g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        params = [g[k] for k in order] + [light.base]
+        step = pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=False)
+        if mode == "plain":
+            step(camt, g, gt, vd)
+            torch.cuda.synchronize()
+            return torch.cat([p.grad.reshape(-1) for p in params])
+        slab = dp.GradSlab(params)
+        sink = slab.sink([names.get(k, k) for k in order])
+        slab.attach(skip=sink)
+        assert all(g[k].grad is None for k in order) and light.base.grad is not None  # the light accumulates in place
+        with dgr.grad_sink(sink):
+            step(camt, g, gt, vd)
+        slab._gather_stray()
+        torch.cuda.synchronize()
+        return slab.flat.clone()
+
+    plain, slab = run("plain"), run("slab")
+    assert rel_peak(slab.cpu().numpy(), plain.cpu().numpy()) < 2e-3
+    assert float(plain.abs().max()) > 0

@@ -84,3 +84,113 @@ def test_stage1_optimisation_recovers_a_perturbed_scene():
     assert all(torch.isfinite(p).all() for p in raw.values())
     assert last < 0.6 * first, (first, last)                      # the objective went down ...
     assert psnr1 > psnr0 + 3.0, (psnr0, psnr1)                    # ... and the renders moved towards the targets
+
+
+def test_stage2_optimisation_recovers_materials_and_light():
+    """Stage 2 end to end (train.py:330-420, 517-522 in miniature) on the fast path: targets are stage-2 images
+    (direct + indirect) of a scene under a known light; albedo / roughness / metallic and the light are perturbed; the
+    COMPLETE iteration -- activations, rasterizer + SSAO, build_mips, shade, SSR, L1 + lamb + masked BRDF TV + envmap TV,
+    backward through shade / SSR closed form / GGX pre-filter, FusedAdam on the Gaussians and on the light, clamp --
+    replayed from three hipGraphs has to bring the images back.  The first iterations are also run through the eager
+    formulation of the same iteration: both must take the same trajectory."""
+    import activations
+    import pbr
+    import pipeline
+    import scenes
+    import train_iteration as ti
+    dev = torch.device("cuda:0")
+    H = W = 112
+    deg = 1
+    sc = scenes.surface_scene(P=6000, sh_degree=deg, seed=4, scale_mu=0.035)
+    n_views = 6
+    cams = [scenes.orbit_camera(i, n_views, W, H, radius=3.5) for i in range(n_views)]
+    cams = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    gi = scenes.GI_DEFAULTS
+    lut = pbr.get_brdf_lut().to(dev)
+    rays = pipeline.canonical_rays(cams[0], dev)
+    vds = [pipeline.view_dirs_for(c, rays, dev) for c in cams]
+
+    def make_light(seed, flat=None):
+        torch.manual_seed(seed)
+        light = pbr.CubemapLight(base_res=64, device=dev)
+        with torch.no_grad():
+            if flat is not None:
+                light.base.fill_(flat)
+            else:  # a smooth, coloured environment: bright "sky" on one side
+                d = torch.stack(torch.meshgrid(torch.linspace(-1, 1, 64, device=dev), torch.linspace(-1, 1, 64, device=dev),
+                                               indexing="ij"), -1)
+                for f in range(6):
+                    light.base[f] = (0.35 + 0.3 * torch.sin(2.0 * d[..., :1] + f) + 0.25 * torch.cos(1.5 * d[..., 1:] - f)
+                                     ) * torch.tensor([1.0, 0.85, 0.6], device=dev) * (1.6 if f == 2 else 0.8)
+                light.base.clamp_(min=0.02)
+        return light
+
+    truth_light = make_light(0)
+    truth = {k: v.detach() for k, v in ti.raw_from_scene(sc, dev).items()}
+
+    def images(raw, light):
+        step = pipeline.Stage2Step(light, lut, gi, deg, fused=True, graphs=False)
+        out = []
+        for c, vd in zip(cams, vds):
+            g = {k: v.detach().requires_grad_(True) for k, v in activations.activate(raw).items()}
+            out.append(step(c, g, torch.zeros(3, H, W, device=dev), vd)["render_rgb"].detach().clone())
+        light.base.grad = None
+        return out
+
+    targets = images(truth, truth_light)
+
+    def perturbed():
+        gen = torch.Generator(device=dev).manual_seed(1)
+        raw = {k: torch.nn.Parameter(v.clone()) for k, v in truth.items()}
+        with torch.no_grad():
+            for k, s in (("albedo", 1.0), ("roughness", 1.0), ("metallic", 1.0)):
+                raw[k].add_(torch.randn(raw[k].shape, device=dev, generator=gen) * s)
+        return raw, make_light(0, flat=0.5)
+
+    def psnr_of(raw, light):
+        return float(np.mean([_psnr(a, b) for a, b in zip(images({k: v.detach() for k, v in raw.items()}, light), targets)]))
+
+    # (1) the same five iterations, eager and from the graphs: one trajectory
+    traj = {}
+    for graphs in (False, True):
+        raw, light = perturbed()
+        tr = ti.Stage2Trainer(raw, light, lut, gi, deg, graphs=graphs)
+        losses_ = []
+        for it in range(5):
+            losses_.append(float(tr.iteration(cams[it % n_views], targets[it % n_views], vds[it % n_views])["loss"]))
+        torch.cuda.synchronize()
+        assert all(p.grad is None for p in raw.values()) and light.base.grad is None  # zero_grad(set_to_none=True)
+        traj[graphs] = (losses_, {k: v.detach().clone() for k, v in raw.items()}, light.base.detach().clone(), tr)
+    assert traj[True][3].stepper.whole is not None and traj[True][3].stepper.whole.go is not None
+    for a, b in zip(traj[False][0], traj[True][0]):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (traj[False][0], traj[True][0])
+    for k in ("albedo", "roughness", "metallic"):
+        d = (traj[False][1][k] - traj[True][1][k]).abs().max().item()
+        assert d <= 2e-3, (k, d)  # five Adam steps of 0.05 each moved them by up to 0.25
+    assert (traj[False][2] - traj[True][2]).abs().max().item() <= 2e-3
+    for k in ("xyz", "scaling", "rotation", "opacity", "f_dc", "normal"):  # stage 2 reaches none of these (exact zeros)
+        assert torch.equal(traj[True][1][k], truth[k]), k
+    assert int(traj[True][3].optimizer.state[traj[True][3].raw["albedo"]]["step"]) == 5
+
+    # (2) the optimisation itself, from the graphs
+    raw, light = perturbed()
+    psnr0 = psnr_of(raw, light)
+    tr = ti.Stage2Trainer(raw, light, lut, gi, deg, graphs=True)
+    first = last = 0.0
+    n_it = 360
+    for it in range(n_it):
+        v = it % n_views
+        loss = tr.iteration(cams[v], targets[v], vds[v])["loss"]
+        if it < 6:
+            first += float(loss) / 6
+        if it >= n_it - 6:
+            last += float(loss) / 6
+    torch.cuda.synchronize()
+    psnr1 = psnr_of(raw, light)
+    print(f"\nstage-2 miniature: loss {first:.4f} -> {last:.4f}, PSNR {psnr0:.2f} -> {psnr1:.2f} dB, "
+          f"light mean {float(light.base.mean()):.3f} (truth {float(truth_light.base.mean()):.3f})")
+    assert tr.stepper.whole is not None and tr.stepper.whole.recaptures == 1
+    assert all(torch.isfinite(p).all() for p in raw.values()) and torch.isfinite(light.base).all()
+    assert float(light.base.min()) >= 0.0                      # cubemap.clamp_(min=0)
+    assert last < 0.5 * first, (first, last)
+    assert psnr1 > psnr0 + 4.0, (psnr0, psnr1)
