@@ -64,7 +64,9 @@ size_t sort_size_cached(int R) {
   std::lock_guard<std::mutex> lk(g_size_mu);
   auto it = g_sort_sizes.find(bucket);
   if (it != g_sort_sizes.end()) return it->second;
-  const size_t v = gigs::sort_temp_bytes(bucket);
+  // the dense-scene path keeps its (tile, depth bucket) tables in the same space instead (binning.hip): NB <= 2 R / 1024
+  const size_t nb = std::min<size_t>((size_t)gigs::kSplitMaxBins, (size_t)bucket / 512 + 8);
+  const size_t v = std::max(gigs::sort_temp_bytes(bucket), gigs::split_space_bytes(nb));
   g_sort_sizes[bucket] = v;
   return v;
 }
@@ -321,46 +323,76 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
   const bool bucket = binning_bucketed() && T <= (size_t)gigs::kBinMaxTiles;
   bool dense = false;
   if (async_cap > 0 && !bucket) return fail(GIGS_ERR_INVALID, "asynchronous binning needs the tile-bucketed path (GIGS_BINNING, <= %d tiles)", gigs::kBinMaxTiles);
+  static const int max_mean = [] { const char* e = getenv("GIGS_BUCKET_MAX_MEAN"); return e ? atoi(e) : gigs::kBucketMaxMeanList; }();
+  int split = 1;  // depth buckets per tile (binning.hip, "depth-split bins"): > 1 for dense scenes
+  auto carve_binning = [&](int R) -> bool {
+    const size_t sort_sz = sort_size_cached(R);
+    const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)R, sort_sz);
+    char* bin_chunk = binningBuffer(bin_bytes, binning_user);
+    if (!bin_chunk) { fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes); return false; }
+    bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)R, sort_sz);
+    return true;
+  };
+  auto pick_split = [&](size_t est_mean) {
+    const char* e = getenv("GIGS_BIN_SPLIT");  // 2 / 4 / 8: forced (tests); 1: never split
+    const bool forced = e && atoi(e) > 1;
+    if (est_mean <= (size_t)max_mean && !forced) return 1;
+    const int B = gigs::split_buckets(est_mean, T);
+    return (B > 1 && gigs::split_space_bytes((size_t)B * T) <= bin.sort_size) ? B : 1;
+  };
   if (bucket) {
     // Tile-bucketed binning (binning.hip): count -> prefix -> scatter -> per-tile sort, the instance count stays on
     // the device.  Synchronous calls (the reference's API returns num_rendered) read it back once, BEFORE the scatter,
     // to size the binning chunk exactly; with gigs_set_async_binning the chunk has the caller's capacity and nothing
-    // is read back.
-    {
-      StageScope sc(kDuplicate, s);
-      gigs::launch_bin_count(P, radii, a.gx, a.gy, geom, img, s);
-      gigs::launch_bin_prefix(P, (int)T, async_cap > 0 ? async_cap : 0x7fffffffu, img, (unsigned*)g_async_counters.load(), s);
-    }
-    STAGE_CHECK("bin count / prefix");
+    // is read back.  Dense scenes (mean list above kBucketMaxMeanList) bin into (tile, depth bucket) pairs instead of
+    // tiles so that the sub-lists fit the LDS sorts; an asynchronous call judges that from its capacity (the caller sizes
+    // it at twice a probed instance count), a synchronous one from the count it has just read.
     if (async_cap > 0) {
       num_rendered = (int)async_cap;
-    } else {
+      if (!carve_binning(num_rendered)) return GIGS_ERR_ALLOC;
+      split = pick_split((size_t)async_cap / (2 * T));
+    }
+    {
+      StageScope sc(kDuplicate, s);
+      if (split > 1) {
+        gigs::launch_split_count(P, (int)T, split, async_cap, radii, a.gx, a.gy, geom, bin, img, (unsigned*)g_async_counters.load(), s);
+      } else {
+        gigs::launch_bin_count(P, radii, a.gx, a.gy, geom, img, s);
+        gigs::launch_bin_prefix(P, (int)T, async_cap > 0 ? async_cap : 0x7fffffffu, img, (unsigned*)g_async_counters.load(), s);
+      }
+    }
+    STAGE_CHECK("bin count / prefix");
+    if (async_cap == 0) {
       uint32_t num_rendered_u = 0;
       HIP_TRY(hipMemcpyAsync(&num_rendered_u, img.bin_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       if (num_rendered_u > 0x7fffffffu) return fail(GIGS_ERR_INVALID, "num_rendered overflows int");
       num_rendered = (int)num_rendered_u;
-      // The per-tile LDS sort is O(n log^2 n) in the list length: for dense scenes (mean list above kBucketMaxMeanList
-      // instances; 3 M Gaussians at 1237x822 average 7000) the global radix sort of the reference-shaped path wins
-      // (measured: 9.2 vs 1.6 ms at that size), so a synchronous call -- which knows R here -- switches over.
-      static const int max_mean = [] { const char* e = getenv("GIGS_BUCKET_MAX_MEAN"); return e ? atoi(e) : gigs::kBucketMaxMeanList; }();
-      if ((size_t)num_rendered > (size_t)max_mean * T) dense = true;
+      if (!carve_binning(num_rendered)) return GIGS_ERR_ALLOC;
+      split = pick_split((size_t)num_rendered / T);
+      if (split > 1) {
+        // the plain count above only served to learn R (a synchronous call cannot know the density before): count again
+        // into the split bins.  The asynchronous path -- the one that is timed -- counts once.
+        StageScope sc(kDuplicate, s);
+        gigs::launch_split_count(P, (int)T, split, (unsigned)num_rendered, radii, a.gx, a.gy, geom, bin, img, nullptr, s);
+      } else if ((size_t)num_rendered > (size_t)max_mean * T) {
+        dense = true;  // too many tiles for the split tables (or GIGS_BIN_SPLIT=1): the reference-shaped global sort
+      }
     }
   }
   if (bucket && !dense) {
-    const size_t sort_sz = sort_size_cached(num_rendered);
-    const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)num_rendered, sort_sz);
-    char* bin_chunk = binningBuffer(bin_bytes, binning_user);
-    if (!bin_chunk) return fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
-    bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, sort_sz);
     {
       StageScope sc(kRanges, s);
       gigs::launch_tile_order((int)T, img.ranges, img.tile_order, s);
     }
     {
       StageScope sc(kSort, s);
-      gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, geom, bin, img, s);
-      if (gigs::launch_bin_sort((int)T, P, bin, img, s) != 0) return fail(GIGS_ERR_HIP, "bin_sort: cannot fork the sort streams");
+      if (split > 1) {
+        gigs::launch_split_scatter_sort(P, (int)T, split, (unsigned)num_rendered, radii, a.gx, a.gy, geom, bin, s);
+      } else {
+        gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, geom, bin, img, s);
+        if (gigs::launch_bin_sort((int)T, P, bin, img, s) != 0) return fail(GIGS_ERR_HIP, "bin_sort: cannot fork the sort streams");
+      }
     }
     STAGE_CHECK("bin scatter / sort");
   } else {

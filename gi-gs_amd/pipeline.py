@@ -222,12 +222,21 @@ class RasterFront(torch.nn.Module):
 
 
 BUCKET_MAX_MEAN_LIST = int(os.environ.get("GIGS_BUCKET_MAX_MEAN", "2500"))  # csrc/gigs_common.h kBucketMaxMeanList
+SPLIT_MAX_BINS = 38912  # csrc/gigs_common.h kSplitMaxBins
 
 
 class DenseScene(RuntimeError):
-    """The scene averages more instances per tile than the tile-bucketed binning sorts efficiently (its per-tile sort is
-    O(n log^2 n)); asynchronous binning / graph capture of the rasterizer is declined and the caller keeps the
-    synchronous path, which switches to the global radix sort for such scenes."""
+    """The scene averages more instances per tile than one workgroup sorts in LDS AND the library cannot split its tiles
+    into depth buckets (more than kSplitMaxBins / 2 tiles, or GIGS_BIN_SPLIT=1): asynchronous binning / graph capture of
+    the rasterizer is declined and the caller keeps the synchronous path with the global radix sort.  Ordinary dense
+    scenes (3 M Gaussians at the Mip-NeRF360 images_4 sizes: 7 000 instances per tile) are NOT declined: the library
+    bins them into (tile, depth bucket) pairs (csrc/binning.hip) and they take the asynchronous, captured path."""
+
+
+def _declined_as_dense(probe: int, tiles: int) -> bool:
+    if probe <= BUCKET_MAX_MEAN_LIST * tiles:
+        return False
+    return os.environ.get("GIGS_BIN_SPLIT", "") == "1" or 2 * tiles > SPLIT_MAX_BINS
 
 
 class GraphedRaster:
@@ -266,7 +275,7 @@ class GraphedRaster:
         tiles = ((H_ + 15) // 16) * ((W_ + 15) // 16)
         if self.capacity <= 0:
             probe = self._probe(cam, g, bg)
-            if probe > BUCKET_MAX_MEAN_LIST * tiles:
+            if _declined_as_dense(probe, tiles):
                 raise DenseScene(f"{probe} instances over {tiles} tiles")
             self.capacity = max(65536, -(-2 * probe // 65536) * 65536)
         self.bin = AsyncBinning(self.capacity, self.dev)
@@ -335,6 +344,9 @@ def _graphed_inference(mod, sample):
     return run
 
 
+_RETIRED = []
+
+
 class WholeStepGraph:
     """One stage-2 iteration -- rasterizer, SSAO, light filter, shade, SSR, loss, and the whole backward -- captured by
     hand into TWO hipGraphs (forward, backward) that share one memory pool:
@@ -395,7 +407,7 @@ class WholeStepGraph:
         if self.capacity <= 0:
             probe = GraphedRaster(cam, ga, o.gi, o.sh_degree)._probe(cam, ga, bg)
             tiles = ((H + 15) // 16) * ((W + 15) // 16)
-            if probe > BUCKET_MAX_MEAN_LIST * tiles:
+            if _declined_as_dense(probe, tiles):
                 raise DenseScene(f"{probe} instances over {tiles} tiles")
             self.capacity = max(65536, -(-2 * probe // 65536) * 65536)
         self.bin = AsyncBinning(self.capacity, self.dev)
@@ -416,7 +428,9 @@ class WholeStepGraph:
         self.s_vd, self.s_gt = view_dirs.detach().clone(), gt_image.detach().clone()
         self._src = {}  # static buffer -> (data_ptr, version) of the tensor it was last filled from
         params = self._params(g)
-        self.gf = self.gb = None
+        if os.environ.get("GIGS_RETIRE_GRAPHS") == "1":  # diagnostic
+            _RETIRED.append((self.gf, self.gb, self.go))
+        self.gf = self.gb = self.go = None
         torch.cuda.synchronize()
         # warm-up on a side stream: builds every cached table / library buffer outside the capture
         side = torch.cuda.Stream()
@@ -816,7 +830,7 @@ def _eager_async(self, cam, g, background):
     if getattr(self, "_abin", None) is None:
         probe = GraphedRaster(cam, g, self.gi, self.sh_degree)._probe(cam, g, background)
         tiles = ((int(cam["image_height"]) + 15) // 16) * ((int(cam["image_width"]) + 15) // 16)
-        if probe > BUCKET_MAX_MEAN_LIST * tiles:
+        if _declined_as_dense(probe, tiles):
             self._dense = True
             return None
         self._abin = AsyncBinning(max(65536, -(-2 * probe // 65536) * 65536), g["means3D"].device)

@@ -11,6 +11,9 @@ for p in (ROOT, os.path.join(ROOT, "gi-gs_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("GIGS_TEST_NOGC") == "1":  # diagnostic: no cyclic-GC passes at arbitrary points of the session
+        import gc
+        gc.disable()
 
 
 @pytest.fixture(scope="session")

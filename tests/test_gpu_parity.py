@@ -566,12 +566,15 @@ def test_fused_derive_normal_is_bit_identical_to_the_four_kernel_chain(W, H, mon
 # ------------------------------------------------------------------------------------------
 # binning paths
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["legacy", "bucket"])
+@pytest.mark.parametrize("mode", ["legacy", "bucket", "split2", "split8"])
 def test_binning_paths_match_oracle(orc, mode, monkeypatch):
-    """Both binning paths -- the reference-shaped scan / duplicate / global radix sort (legacy) and the default
-    tile-bucketed count / prefix / scatter / per-tile sort -- give the oracle's keys, point_list and ranges bit for bit,
+    """All binning paths -- the reference-shaped scan / duplicate / global radix sort (legacy), the default
+    tile-bucketed count / prefix / scatter / per-tile sort, and the dense-scene form of the latter with 2 or 8 depth
+    buckets per tile (forced here: GIGS_BIN_SPLIT) -- give the oracle's keys, point_list and ranges bit for bit,
     on a cloud with large footprints (wave-expanded), exact depth ties (duplicated Gaussians) and a ragged image."""
-    monkeypatch.setenv("GIGS_BINNING", mode)
+    monkeypatch.setenv("GIGS_BINNING", "legacy" if mode == "legacy" else "bucket")
+    if mode.startswith("split"):
+        monkeypatch.setenv("GIGS_BIN_SPLIT", mode[5:])
     sc = scenes.random_scene(P=6000, sh_degree=1, seed=21, scale_mu=0.12)
     # exact depth ties inside tiles: the same Gaussian several times (ties must come out in index order)
     for k in GAUSS_KEYS:
@@ -620,6 +623,75 @@ def test_async_binning_capacity_and_overflow(orc):
     assert int(sv["ranges"].max()) <= small and torch.all(guard == 0x5A)
     for k, v in hip_planes(over).items():
         assert np.isfinite(np.nan_to_num(v)).all(), k
+
+
+@pytest.mark.parametrize("split", ["4", "auto"])
+def test_dense_scene_split_binning_sync_and_async(orc, split, monkeypatch):
+    """A dense view (mean list above the split threshold: sub-lists of every length class, incl. one tile beyond 16 384
+    keys) through the depth-split binning, synchronous (the reference's API: R read back) and asynchronous (fixed
+    capacity, device counters): keys / point_list / ranges equal the oracle's, the planes equal the legacy path's bit for
+    bit, and an undersized capacity raises the flag without writing out of bounds."""
+    import gigs_lib
+    dgr = _dgr()
+    lib = gigs_lib.lib()
+    if split != "auto":
+        monkeypatch.setenv("GIGS_BIN_SPLIT", split)
+    # ~3 000 instances per tile on average at 96x80 (30 tiles), one screen-filling cluster in front: a very long list
+    sc = scenes.surface_scene(P=44_000, sh_degree=1, seed=9, scale_mu=0.08)
+    cam = scenes.orbit_camera(1, 5, 96, 80, radius=3.0)
+    # the last 20 000 Gaussians: a cluster of small splats on a plane facing the camera, 2 units in front of it -- one
+    # tile's worth of screen, (nearly) one depth: they land in ONE (tile, depth bucket) bin whatever the thresholds are
+    rng = np.random.default_rng(3)
+    fwd = -cam["campos"] / np.linalg.norm(cam["campos"])
+    side = np.cross(fwd, [0.0, 0.0, 1.0]); side /= np.linalg.norm(side)
+    up = np.cross(side, fwd)
+    n_cl = 20_000
+    lat = rng.uniform(-0.012, 0.012, size=(n_cl, 2))
+    sc["means3D"][-n_cl:] = (cam["campos"] + 2.0 * fwd + lat[:, :1] * side + lat[:, 1:] * up
+                             + rng.uniform(-2e-4, 2e-4, size=(n_cl, 1)) * fwd).astype(np.float32)
+    sc["scales"][-n_cl:] = 0.002
+    sc["opacities"][-n_cl:] = 0.02  # faint: the walk goes through all of them
+    check_forward(orc, sc, cam, tag="split " + split + " ")
+    got = hip_raw_forward(dgr, sc, cam)
+    R = got[0]
+    P, W, H = sc["means3D"].shape[0], cam["image_width"], cam["image_height"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    assert R > 2500 * T, (R, T)  # dense by the library's own criterion
+    monkeypatch.setenv("GIGS_BINNING", "legacy")
+    ref = hip_raw_forward(dgr, sc, cam)
+    monkeypatch.setenv("GIGS_BINNING", "bucket")
+    assert ref[0] == R
+    sa, sb = scratch_views(dgr, ref, P, W, H), scratch_views(dgr, got, P, W, H)
+    for k in ("keys", "point_list", "ranges", "n_contrib"):
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    for a, b in zip(hip_planes(ref).items(), hip_planes(got).items()):
+        np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32), err_msg=a[0])
+    lengths = (sb["ranges"].reshape(T, 2)[:, 1] - sb["ranges"].reshape(T, 2)[:, 0])
+    print("dense test: R", R, "mean list", R // T, "longest", int(lengths.max()))
+    counters = torch.zeros(2, dtype=torch.int32, device=DEV)
+    cap = 2 * R  # what pipeline.WholeStepGraph sizes: the library reads the density off the capacity
+    lib.gigs_set_async_binning(cap, counters.data_ptr())
+    try:
+        asy = hip_raw_forward(dgr, sc, cam)
+    finally:
+        lib.gigs_set_async_binning(0, None)
+    assert asy[0] == cap and counters.tolist() == [R, 0]
+    sc_ = scratch_views(dgr, (cap,) + tuple(asy[1:]), P, W, H)
+    np.testing.assert_array_equal(sa["point_list"], sc_["point_list"][:R])
+    np.testing.assert_array_equal(sa["keys"], sc_["keys"][:R])
+    np.testing.assert_array_equal(sa["ranges"], sc_["ranges"])
+    for a, b in zip(hip_planes(ref).items(), hip_planes(asy).items()):
+        np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32), err_msg=a[0])
+    small = max(65536, R // 3)
+    guard = torch.full((1024,), 0x5A, dtype=torch.uint8, device=DEV)
+    lib.gigs_set_async_binning(small, counters.data_ptr())
+    try:
+        over = hip_raw_forward(dgr, sc, cam)
+    finally:
+        lib.gigs_set_async_binning(0, None)
+    assert over[0] == small and counters.tolist() == [R, R]
+    sv = scratch_views(dgr, over, P, W, H)
+    assert int(sv["ranges"].max()) <= small and torch.all(guard == 0x5A)
 
 
 @pytest.mark.parametrize("case", ["c2ish", "ragged", "gi_settings", "blocks32", "blocks64"])
