@@ -58,12 +58,24 @@ def make_settings(cam: Dict, sh_degree: int, bg: torch.Tensor, gi: Dict, device,
         debug=debug, inference=inference, argmax_depth=False)
 
 
+def _collect_idle():
+    """Destroy whatever hipGraph-owning garbage exists (WholeStepGraph <-> Stage2Step is a reference cycle: only a
+    cyclic-GC pass frees it) NOW, with the device idle before and after -- never between a capture and its replays.
+    Measured on ROCm 7.0 (round 3): a collector pass that destroyed a batch of older graph execs right before a new
+    capture, with no synchronisation after it, left the NEW exec with a dead internal stream and its first replay
+    crashed in hip::Graph::UpdateStreams."""
+    import gc
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 def graphed(callable_, sample_args):
     """torch.cuda.make_graphed_callables with the garbage collector parked: a cyclic-GC pass that runs while
     the stream is capturing may destroy older HIP objects (graphs, events, pooled blocks), which HIP refuses
     during capture and aborts the process."""
     import gc
-    gc.collect()
+    _collect_idle()
     was_enabled = gc.isenabled()
     gc.disable()
     try:
@@ -322,8 +334,7 @@ def _graphed_inference(mod, sample):
         for _ in range(3):
             mod(*static_in)
     torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    gc.collect()
+    _collect_idle()
     was = gc.isenabled()
     gc.disable()
     try:
@@ -342,9 +353,6 @@ def _graphed_inference(mod, sample):
         return static_out
 
     return run
-
-
-_RETIRED = []
 
 
 class WholeStepGraph:
@@ -428,10 +436,8 @@ class WholeStepGraph:
         self.s_vd, self.s_gt = view_dirs.detach().clone(), gt_image.detach().clone()
         self._src = {}  # static buffer -> (data_ptr, version) of the tensor it was last filled from
         params = self._params(g)
-        if os.environ.get("GIGS_RETIRE_GRAPHS") == "1":  # diagnostic
-            _RETIRED.append((self.gf, self.gb, self.go))
         self.gf = self.gb = self.go = None
-        torch.cuda.synchronize()
+        _collect_idle()
         # warm-up on a side stream: builds every cached table / library buffer outside the capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -450,7 +456,7 @@ class WholeStepGraph:
                 with torch.no_grad():
                     o.post_update()  # idempotent (a clamp): run once outside the capture as its warm-up
             torch.cuda.synchronize()
-        gc.collect()
+        _collect_idle()
         was = gc.isenabled()
         gc.disable()  # see graphed(): a cyclic-GC pass during capture may destroy HIP objects, which HIP refuses
         try:

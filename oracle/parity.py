@@ -201,14 +201,8 @@ def march_noise(orc, sc, cam, gi, sh_degree, gpu: Dict, ref: Dict, light=None, b
     A reader sees whether the default march's isolated outliers (max ~1e-3) are as rare as the reference's own compile
     noise."""
     rep = {"default_vs_oracle": diff_planes(gpu, ref)}
-    import os as _os
-    _diag = _os.environ.get("GIGS_DIAG_NOISE", "")
-    if _diag == "none":
-        return rep
-    if light is not None and _diag != "twin":
+    if light is not None:
         rep["exact_vs_oracle"] = diff_planes(gpu_exact_march(sc, cam, gi, sh_degree, light, brdf_lut, dev), ref)
-    if _diag == "exact":
-        return rep
     twin = orc.variant("fma")
     twin.set_threads(orc.max_threads())
     if "light_base" in gpu:

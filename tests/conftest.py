@@ -11,9 +11,6 @@ for p in (ROOT, os.path.join(ROOT, "gi-gs_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    if os.environ.get("GIGS_TEST_NOGC") == "1":  # diagnostic: no cyclic-GC passes at arbitrary points of the session
-        import gc
-        gc.disable()
 
 
 @pytest.fixture(scope="session")
@@ -22,3 +19,18 @@ def orc():
     _orc.build()
     _orc.set_threads(min(8, _orc.max_threads()))
     return _orc
+
+
+@pytest.fixture(autouse=True)
+def _gpu_teardown(request):
+    """GPU tests: objects that own hipGraphs (pipeline.WholeStepGraph <-> its Stage2Step: a reference cycle) die HERE, at
+    the test boundary with the device idle, not at whatever later moment a cyclic-GC pass happens to run."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.synchronize()

@@ -169,11 +169,9 @@ def _oracle_parity(orc, sc, cam, deg, light_res, tag, grads_only=None, per_pixel
         # (floor: 2e-5 of the plane), the exact march likewise; everything else is within 1e-4 by the definition of the
         # fraction, and the means are asserted below.
         rep["gi_per_pixel"] = noise
-        for k, tw in noise.get("oracle_vs_fma_twin", {}).items():
+        for k, tw in noise["oracle_vs_fma_twin"].items():
             bar = 2.0 * max(tw["frac_over_1e-4"], 1e-5)
             for who in ("default_vs_oracle", "exact_vs_oracle"):
-                if who not in noise:
-                    continue
                 got = noise[who][k]
                 print(tag, k, who, "frac>1e-4 %.2e (twin %.2e) max %.2e" % (got["frac_over_1e-4"], tw["frac_over_1e-4"], got["max"]))
                 assert got["frac_over_1e-4"] <= bar, (tag, k, who, got, tw)
