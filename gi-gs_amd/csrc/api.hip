@@ -64,9 +64,8 @@ size_t sort_size_cached(int R) {
   std::lock_guard<std::mutex> lk(g_size_mu);
   auto it = g_sort_sizes.find(bucket);
   if (it != g_sort_sizes.end()) return it->second;
-  // the dense-scene path keeps its (tile, depth bucket) tables in the same space instead (binning.hip): NB <= 2 R / 1024
-  const size_t nb = std::min<size_t>((size_t)gigs::kSplitMaxBins, (size_t)bucket / 512 + 8);
-  const size_t v = std::max(gigs::sort_temp_bytes(bucket), gigs::split_space_bytes(nb));
+  // the tile-bucketed path keeps the tables of its long-list partition in the same space instead (binning.hip)
+  const size_t v = std::max(gigs::sort_temp_bytes(bucket), gigs::long_space_bytes((size_t)gigs::kBinMaxTiles, (size_t)bucket));
   g_sort_sizes[bucket] = v;
   return v;
 }
@@ -321,78 +320,51 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
   gigs::BinningState bin;
   const unsigned async_cap = g_async_capacity.load();
   const bool bucket = binning_bucketed() && T <= (size_t)gigs::kBinMaxTiles;
-  bool dense = false;
   if (async_cap > 0 && !bucket) return fail(GIGS_ERR_INVALID, "asynchronous binning needs the tile-bucketed path (GIGS_BINNING, <= %d tiles)", gigs::kBinMaxTiles);
   static const int max_mean = [] { const char* e = getenv("GIGS_BUCKET_MAX_MEAN"); return e ? atoi(e) : gigs::kBucketMaxMeanList; }();
-  int split = 1;  // depth buckets per tile (binning.hip, "depth-split bins"): > 1 for dense scenes
-  auto carve_binning = [&](int R) -> bool {
-    const size_t sort_sz = sort_size_cached(R);
-    const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)R, sort_sz);
-    char* bin_chunk = binningBuffer(bin_bytes, binning_user);
-    if (!bin_chunk) { fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes); return false; }
-    bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)R, sort_sz);
-    return true;
+  // dense scene (mean list above kBucketMaxMeanList): lists beyond 8192 keys are partitioned by sampled splitters before the
+  // LDS sorts (binning.hip).  GIGS_LONG_LISTS=1 / 0 forces / forbids it.
+  auto long_lists = [&](size_t est_mean) {
+    if (const char* e = getenv("GIGS_LONG_LISTS")) return e[0] == '1';
+    return est_mean > (size_t)max_mean;
   };
-  auto pick_split = [&](size_t est_mean) {
-    const char* e = getenv("GIGS_BIN_SPLIT");  // 2 / 4 / 8: forced (tests); 1: never split
-    const bool forced = e && atoi(e) > 1;
-    if (est_mean <= (size_t)max_mean && !forced) return 1;
-    const int B = gigs::split_buckets(est_mean, T);
-    return (B > 1 && gigs::split_space_bytes((size_t)B * T) <= bin.sort_size) ? B : 1;
-  };
+  bool dense = false;
   if (bucket) {
     // Tile-bucketed binning (binning.hip): count -> prefix -> scatter -> per-tile sort, the instance count stays on
     // the device.  Synchronous calls (the reference's API returns num_rendered) read it back once, BEFORE the scatter,
     // to size the binning chunk exactly; with gigs_set_async_binning the chunk has the caller's capacity and nothing
-    // is read back.  Dense scenes (mean list above kBucketMaxMeanList) bin into (tile, depth bucket) pairs instead of
-    // tiles so that the sub-lists fit the LDS sorts; an asynchronous call judges that from its capacity (the caller sizes
-    // it at twice a probed instance count), a synchronous one from the count it has just read.
-    if (async_cap > 0) {
-      num_rendered = (int)async_cap;
-      if (!carve_binning(num_rendered)) return GIGS_ERR_ALLOC;
-      split = pick_split((size_t)async_cap / (2 * T));
-    }
+    // is read back (the caller sizes it at twice a probed instance count: the density is judged from that).
     {
       StageScope sc(kDuplicate, s);
-      if (split > 1) {
-        gigs::launch_split_count(P, (int)T, split, async_cap, radii, a.gx, a.gy, geom, bin, img, (unsigned*)g_async_counters.load(), s);
-      } else {
-        gigs::launch_bin_count(P, radii, a.gx, a.gy, geom, img, s);
-        gigs::launch_bin_prefix(P, (int)T, async_cap > 0 ? async_cap : 0x7fffffffu, img, (unsigned*)g_async_counters.load(), s);
-      }
+      gigs::launch_bin_count(P, radii, a.gx, a.gy, geom, img, s);
+      gigs::launch_bin_prefix(P, (int)T, async_cap > 0 ? async_cap : 0x7fffffffu, img, (unsigned*)g_async_counters.load(), s);
     }
     STAGE_CHECK("bin count / prefix");
-    if (async_cap == 0) {
+    if (async_cap > 0) {
+      num_rendered = (int)async_cap;
+      dense = long_lists((size_t)async_cap / (2 * T));
+    } else {
       uint32_t num_rendered_u = 0;
       HIP_TRY(hipMemcpyAsync(&num_rendered_u, img.bin_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       if (num_rendered_u > 0x7fffffffu) return fail(GIGS_ERR_INVALID, "num_rendered overflows int");
       num_rendered = (int)num_rendered_u;
-      if (!carve_binning(num_rendered)) return GIGS_ERR_ALLOC;
-      split = pick_split((size_t)num_rendered / T);
-      if (split > 1) {
-        // the plain count above only served to learn R (a synchronous call cannot know the density before): count again
-        // into the split bins.  The asynchronous path -- the one that is timed -- counts once.
-        StageScope sc(kDuplicate, s);
-        gigs::launch_split_count(P, (int)T, split, (unsigned)num_rendered, radii, a.gx, a.gy, geom, bin, img, nullptr, s);
-      } else if ((size_t)num_rendered > (size_t)max_mean * T) {
-        dense = true;  // too many tiles for the split tables (or GIGS_BIN_SPLIT=1): the reference-shaped global sort
-      }
+      dense = long_lists((size_t)num_rendered / T);
     }
-  }
-  if (bucket && !dense) {
+    const size_t sort_sz = sort_size_cached(num_rendered);
+    const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)num_rendered, sort_sz);
+    char* bin_chunk = binningBuffer(bin_bytes, binning_user);
+    if (!bin_chunk) return fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
+    bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, sort_sz);
     {
       StageScope sc(kRanges, s);
       gigs::launch_tile_order((int)T, img.ranges, img.tile_order, s);
     }
     {
       StageScope sc(kSort, s);
-      if (split > 1) {
-        gigs::launch_split_scatter_sort(P, (int)T, split, (unsigned)num_rendered, radii, a.gx, a.gy, geom, bin, s);
-      } else {
-        gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, geom, bin, img, s);
-        if (gigs::launch_bin_sort((int)T, P, bin, img, s) != 0) return fail(GIGS_ERR_HIP, "bin_sort: cannot fork the sort streams");
-      }
+      gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, geom, bin, img, s);
+      if (gigs::launch_bin_sort((int)T, P, dense && num_rendered > 0, (unsigned)num_rendered, bin, img, s) != 0)
+        return fail(GIGS_ERR_HIP, "bin_sort: cannot fork the sort streams");
     }
     STAGE_CHECK("bin scatter / sort");
   } else {

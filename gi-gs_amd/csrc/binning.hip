@@ -211,16 +211,19 @@ __device__ __forceinline__ void bin_walk(int P, const int* __restrict__ radii, c
 }
 struct NoPay { __device__ __forceinline__ unsigned operator()(int) const { return 0u; } };
 
-__global__ void __launch_bounds__(256)
+// kLanes = 256, or 1024 for large clouds (3 M Gaussians: 0.44 -> 0.15 ms; sixteen waves per CU instead of four cover the
+// latency of the walk's loads)
+template <int kLanes>
+__global__ void __launch_bounds__(kLanes)
 bin_count_kernel(int P, int T, const int* __restrict__ radii, const float* __restrict__ means2D, unsigned gx, unsigned gy,
                  uint32_t* __restrict__ bin_hist) {
   extern __shared__ uint32_t s_hist[];
-  for (int t = threadIdx.x; t < T; t += 256) s_hist[t] = 0;
+  for (int t = threadIdx.x; t < T; t += kLanes) s_hist[t] = 0;
   __syncthreads();
   bin_walk(P, radii, means2D, gx, gy, NoPay(), [&](int, unsigned tile, unsigned) { atomicAdd(&s_hist[tile], 1u); });
   __syncthreads();
   uint32_t* row = bin_hist + (size_t)blockIdx.x * T;
-  for (int t = threadIdx.x; t < T; t += 256) row[t] = s_hist[t];
+  for (int t = threadIdx.x; t < T; t += kLanes) row[t] = s_hist[t];
 }
 
 // per tile: exclusive prefix over the chunk counts (in place) and the total
@@ -285,14 +288,15 @@ bin_prefix_tiles_kernel(int T, unsigned capacity, const uint32_t* __restrict__ t
   }
 }
 
-__global__ void __launch_bounds__(256)
+template <int kLanes>
+__global__ void __launch_bounds__(kLanes)
 bin_scatter_kernel(int P, int T, const int* __restrict__ radii, const float* __restrict__ means2D,
                    const float* __restrict__ depths, unsigned gx, unsigned gy, unsigned capacity, unsigned idx_bits,
                    const uint32_t* __restrict__ bin_hist, const uint32_t* __restrict__ tile_start,
                    uint64_t* __restrict__ keys) {
   extern __shared__ uint32_t s_cur[];
   const uint32_t* row = bin_hist + (size_t)blockIdx.x * T;
-  for (int t = threadIdx.x; t < T; t += 256) s_cur[t] = tile_start[t] + row[t];
+  for (int t = threadIdx.x; t < T; t += kLanes) s_cur[t] = tile_start[t] + row[t];
   __syncthreads();
   bin_walk(P, radii, means2D, gx, gy, NoPay(), [&](int idx, unsigned tile, unsigned) {
     const uint32_t slot = atomicAdd(&s_cur[tile], 1u);
@@ -343,6 +347,7 @@ __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t
                                                 uint64_t tile_hi, uint32_t base, uint64_t* __restrict__ keys_out,
                                                 uint32_t* __restrict__ point_list) {
   using sorter = rocprim::block_radix_sort<uint64_t, kBlock, kItems, rocprim::empty_type, 1, 1, 8>;
+  static_assert(sizeof(Storage) >= sizeof(uint64_t) * kBlock * kItems, "the sorted keys are staged in the sorter's storage");
   const uint64_t idx_mask = (1ull << idx_bits) - 1;
   uint64_t k[kItems];
 #pragma unroll
@@ -350,14 +355,49 @@ __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t
     const unsigned idx = threadIdx.x * kItems + i;
     k[i] = idx < n ? src[idx] : ~0ull;  // padding sorts to the end (all ones in every sorted bit)
   }
-  sorter().sort(k, storage, 0, 32 + idx_bits);  // keys are depth bits << idx_bits | index: one contiguous field
+  // The key is depth bits << idx_bits | index.  Radix passes are spent on the 32 DEPTH bits only (4 passes instead of the 7
+  // that all 32 + idx_bits bits take); the sort is stable, so keys of equal depth come out adjacent, in their (arbitrary)
+  // input order, and are put into index order by the fix-up below -- which finds nothing to do unless two Gaussians of a tile
+  // have bit-identical depths.
+  sorter().sort(k, storage, idx_bits, idx_bits + 32);
+  __syncthreads();
+  uint64_t* s_k = reinterpret_cast<uint64_t*>(&storage);
+#pragma unroll
+  for (int i = 0; i < kItems; i++) s_k[threadIdx.x * kItems + i] = k[i];
+  __syncthreads();
+  bool tie = false;
 #pragma unroll
   for (int i = 0; i < kItems; i++) {
     const unsigned idx = threadIdx.x * kItems + i;
-    if (idx < n) {
-      point_list[base + idx] = (uint32_t)(k[i] & idx_mask);
-      keys_out[base + idx] = tile_hi | (k[i] >> idx_bits);
+    if (idx > 0 && idx < n) {
+      const uint64_t prev = i > 0 ? k[i - 1] : s_k[idx - 1];
+      tie |= (prev >> idx_bits) == (k[i] >> idx_bits) && prev > k[i];
     }
+  }
+  if (__syncthreads_or(tie)) {
+    // odd-even transposition restricted to neighbours of equal depth: runs of equal depth are sorted by index, nothing else
+    // moves; as many rounds as the longest run is long (bit-identical depths inside one tile: duplicated Gaussians)
+    constexpr unsigned kPairs = (unsigned)kBlock * kItems / 2;
+    for (;;) {
+      bool swapped = false;
+#pragma unroll
+      for (int phase = 0; phase < 2; phase++) {
+        for (unsigned p = threadIdx.x; p < kPairs; p += kBlock) {
+          const unsigned a = 2 * p + phase, c = a + 1;
+          if (c < n) {
+            const uint64_t x = s_k[a], y = s_k[c];
+            if ((x >> idx_bits) == (y >> idx_bits) && x > y) { s_k[a] = y; s_k[c] = x; swapped = true; }
+          }
+        }
+        __syncthreads();
+      }
+      if (!__syncthreads_or(swapped)) break;
+    }
+  }
+  for (unsigned idx = threadIdx.x; idx < n; idx += kBlock) {  // coalesced
+    const uint64_t kk = s_k[idx];
+    point_list[base + idx] = (uint32_t)(kk & idx_mask);
+    keys_out[base + idx] = tile_hi | (kk >> idx_bits);
   }
   __syncthreads();  // the storage is reused by the next tile of this workgroup
 }
@@ -433,259 +473,228 @@ bin_sort_kernel(int T, unsigned idx_bits, const uint32_t* __restrict__ tile_orde
 }
 
 // ------------------------------------------------------------------------------------------
-// Dense scenes: depth-split bins (the tile-bucketed binning with B depth buckets per tile)
+// Dense scenes: long tile lists are partitioned by sampled splitters before the LDS sorts
 // ------------------------------------------------------------------------------------------
-// A scene that averages thousands of instances per tile (Mip-NeRF360 at images_4 with 3 M Gaussians: 7 000, single tiles
-// beyond 30 000) overflows what ONE workgroup sorts in LDS (8 192 keys at full speed, 16 384 at half), and the reference's
-// answer -- one global 44-bit radix sort of all R pairs, six passes over 24 B, after reading R back -- costs 2.4 ms of a
-// 9 ms step there and keeps the host in the loop.  Here the first scatter already IS the most significant radix pass
-// (by tile); it is widened to (tile, depth bucket): B <= 8 buckets per tile, bounded by B - 1 depth thresholds that are
-// the instance-weighted B-quantiles of the frame's depth distribution (a 8192-bin histogram over the Gaussians -- 12 B
-// per Gaussian, not per instance -- and a one-workgroup scan; no host).  Bin (tile * B + b) is a contiguous stretch of
-// the tile's range, buckets are in depth order, so sorting every bin's keys by (depth, index) IN PLACE yields the
-// tile's list exactly as the reference's stable sort does: keys are unique, the order is total, and it does not matter
-// where the thresholds fall -- they only balance the work.  Sub-lists are a B-th of the tile's list on average, so
-// nearly all of them take the 256-lane LDS sort; a sub-list that is still long (a tile whose depths cluster) takes the
-// 8- or 16-keys-per-lane kernels or, beyond 16 384 keys, the global-memory network: slower, never wrong.
-constexpr int kDepthBins = 8192;      // 16 octaves [2^-3, 2^13) x 512 bins: the top 18 bits of the depth's float bits
-constexpr int kDepthShift = 14;
-constexpr int kDepthRows = 64;        // workgroups (and rows of partial histograms) of the depth histogram
-constexpr unsigned kDepthBase = 0x3E000000u >> kDepthShift;  // float bits of 0.125 (the cull keeps z > 0.2)
-__device__ __forceinline__ unsigned depth_bin(float d) {
-  const int k = (int)(__float_as_uint(d) >> kDepthShift) - (int)kDepthBase;
-  return (unsigned)min(max(k, 0), kDepthBins - 1);
-}
+// A scene that averages thousands of instances per tile (Mip-NeRF360 at images_4 with 3 M Gaussians: mean 7 000, median
+// 1 900, 1 % of the tiles above 30 000) overflows what ONE workgroup sorts in LDS (8 192 keys at full speed, 16 384 at
+// half), and the reference's answer -- one global 44-bit radix sort of all R pairs, six passes over 24 B, after reading R
+// back -- costs 2.4 ms of a 9 ms step there and keeps the host in the loop.  Here the scatter by tile already IS the
+// most significant radix pass; a tile whose list is long (> kLongList keys) gets ONE more most-significant pass, with
+// splitters drawn from its own keys (a sample sort): after the scatter a tile's stretch of `keys_unsorted` is in
+// arbitrary order, so every (n / 1024)-th key is a uniform sample; its sorted sample yields B - 1 = ceil(n / 1536) - 1
+// splitters, the tile's keys are partitioned into B buckets (histogram per 4096-key chunk, prefix, scatter into the
+// tile's stretch of the output array -- runs of hundreds of keys: coalesced), and every bucket is sorted in place by the
+// same LDS kernels as a short list.  Buckets are key ranges, keys are unique and totally ordered by (depth, index), so
+// the concatenation is the tile's list exactly as the reference's stable sort produces it, wherever the splitters fall;
+// they only balance the work (a bucket that comes out long takes the 8- / 16-keys-per-lane kernels or, beyond 16 384
+// keys, the global-memory network: slower, never wrong).  No host anywhere: work lists and counts stay on the device.
+constexpr unsigned kLongList = 8192;     // lists above this are partitioned (below: sorted directly, as in sparse scenes)
+constexpr unsigned kBucketTarget = 1536;  // keys per bucket aimed at (the 256-lane LDS sort takes up to 2048)
+constexpr unsigned kMaxBuckets = 32;
+constexpr unsigned kPartChunk = 4096;    // keys per workgroup pass of the histogram / partition kernels
+constexpr unsigned kSampleMax = 1024;
 
-struct SplitState {
-  uint32_t* hist;        // [kBinGroups][NB] instances of chunk g in bin i, then (in place) their exclusive prefix over g
-  uint32_t* totals;      // [NB]
-  uint32_t* bin_start;   // [NB + 1] exclusive prefix of the totals (unclamped)
-  uint2* sub_ranges;     // [NB] a bin's stretch of the instance arrays, clamped to the capacity
-  uint32_t* cls_list;    // [4][NB] bins by length class: <= 2048, <= 8192, <= 16384, longer
-  uint32_t* cls_count;   // [4]
-  uint32_t* splits;      // [8] depth-bin thresholds: bucket = #{k : depth_bin >= splits[k]}
-  uint32_t* depth_hist;  // [kDepthRows][kDepthBins]
-  static SplitState fromChunk(char* chunk, size_t NB) {
-    SplitState st;
-    carve(chunk, st.hist, (size_t)kBinGroups * NB);
-    carve(chunk, st.totals, NB);
-    carve(chunk, st.bin_start, NB + 1);
-    carve(chunk, st.sub_ranges, NB);
-    carve(chunk, st.cls_list, 4 * NB);
-    carve(chunk, st.cls_count, 4);
-    carve(chunk, st.splits, 8);
-    carve(chunk, st.depth_hist, (size_t)kDepthRows * kDepthBins);
+struct LongTile { uint32_t tile, B, first_chunk, nchunks; };
+struct LongState {
+  uint32_t* counts;        // [0] long tiles, [1] chunks, [4..7] buckets by length class
+  LongTile* tiles;         // [T]
+  uint64_t* splitters;     // [T][kMaxBuckets] (B - 1 used)
+  uint32_t* bucket_start;  // [T][kMaxBuckets] offsets inside the tile's stretch
+  uint2* chunk_desc;       // [max_chunks] (slot in `tiles`, chunk index inside the tile)
+  uint32_t* chunk_hist;    // [max_chunks][kMaxBuckets] keys of the chunk per bucket, then their exclusive prefix over the tile's chunks
+  uint4* cls_list;         // [4][max_buckets] (start, n, tile, 0) by length class: <= 2048, <= 8192, <= 16384, longer
+  size_t max_chunks, max_buckets;
+  static LongState fromChunk(char*& chunk, size_t T, size_t R) {
+    LongState st;
+    st.max_chunks = R / kPartChunk + T + 1;
+    st.max_buckets = (R / kLongList + 1) * kMaxBuckets;  // at most R / kLongList long tiles, kMaxBuckets buckets each
+    carve(chunk, st.counts, 8);
+    carve(chunk, st.tiles, T);
+    carve(chunk, st.splitters, T * kMaxBuckets);
+    carve(chunk, st.bucket_start, T * kMaxBuckets);
+    carve(chunk, st.chunk_desc, st.max_chunks);
+    carve(chunk, st.chunk_hist, st.max_chunks * kMaxBuckets);
+    carve(chunk, st.cls_list, 4 * st.max_buckets);
     return st;
   }
 };
-size_t split_space_bytes(size_t NB) {
-  return ((size_t)kBinGroups + 8) * NB * sizeof(uint32_t) + (size_t)kDepthRows * kDepthBins * sizeof(uint32_t) + 16 * kAlign;
+size_t long_space_bytes(size_t T, size_t R) {
+  char* p = nullptr;
+  (void)LongState::fromChunk(p, T, R);
+  return reinterpret_cast<size_t>(p) + kAlign;
 }
 
-__global__ void __launch_bounds__(1024)
-split_depth_hist_kernel(int P, const int* __restrict__ radii, const float* __restrict__ depths,
-                        const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_hist) {
-  __shared__ uint32_t s_h[kDepthBins];
-  for (int i = threadIdx.x; i < kDepthBins; i += 1024) s_h[i] = 0;
-  __syncthreads();
-  const int chunk = (P + kDepthRows - 1) / kDepthRows;
-  const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
-  for (int idx = begin + threadIdx.x; idx < end; idx += 1024)
-    if (radii[idx] > 0) atomicAdd(&s_h[depth_bin(depths[idx])], tiles_touched[idx]);
-  __syncthreads();
-  uint32_t* row = depth_hist + (size_t)blockIdx.x * kDepthBins;
-  for (int i = threadIdx.x; i < kDepthBins; i += 1024) row[i] = s_h[i];
-}
+__device__ __forceinline__ unsigned buckets_for(unsigned n, unsigned target) { return min(kMaxBuckets, (n + target - 1) / target); }
 
-// instance-weighted B-quantiles of the depth histogram -> splits[0 .. B-2]; the rest never matches.  One workgroup.
-__global__ void __launch_bounds__(1024)
-split_pick_kernel(unsigned B, const uint32_t* __restrict__ depth_hist, uint32_t* __restrict__ splits) {
-  __shared__ unsigned long long s_sum[1024];
-  constexpr int kPer = kDepthBins / 1024;
-  unsigned long long c[kPer], local = 0;
-#pragma unroll
-  for (int k = 0; k < kPer; k++) {
-    unsigned long long v = 0;
-    for (int r = 0; r < kDepthRows; r++) v += depth_hist[(size_t)r * kDepthBins + threadIdx.x * kPer + k];
-    c[k] = v;
-    local += v;
-  }
-  s_sum[threadIdx.x] = local;
-  if (threadIdx.x < 8) splits[threadIdx.x] = 0xFFFFFFFFu;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const unsigned long long v = threadIdx.x >= (unsigned)off ? s_sum[threadIdx.x - off] : 0ull;
-    __syncthreads();
-    s_sum[threadIdx.x] += v;
-    __syncthreads();
-  }
-  const unsigned long long W = s_sum[1023];
-  unsigned long long run = s_sum[threadIdx.x] - local;
-#pragma unroll
-  for (int k = 0; k < kPer; k++) {
-    const unsigned long long incl = run + c[k];
-    for (unsigned q = 1; q < B; q++) {
-      const unsigned long long target = (W * q) / B;
-      // the first bin whose inclusive count reaches the q-th quantile closes bucket q - 1
-      if (run < target && target <= incl) splits[q - 1] = (uint32_t)(threadIdx.x * kPer + k + 1);
-    }
-    run = incl;
-  }
-}
-
-struct DepthBucket {
-  const float* __restrict__ depths;
-  uint32_t sp[7];
-  __device__ __forceinline__ unsigned operator()(int idx) const {
-    const unsigned db = depth_bin(depths[idx]);
-    unsigned b = 0;
-#pragma unroll
-    for (int k = 0; k < 7; k++) b += db >= sp[k] ? 1u : 0u;
-    return b;
-  }
-};
-__device__ __forceinline__ DepthBucket load_buckets(const float* depths, const uint32_t* __restrict__ splits) {
-  DepthBucket d;
-  d.depths = depths;
-#pragma unroll
-  for (int k = 0; k < 7; k++) d.sp[k] = splits[k];
-  return d;
-}
-
-__global__ void __launch_bounds__(1024)
-split_count_kernel(int P, int NB, unsigned B, const int* __restrict__ radii, const float* __restrict__ means2D,
-                   const float* __restrict__ depths, unsigned gx, unsigned gy, const uint32_t* __restrict__ splits,
-                   uint32_t* __restrict__ hist) {
-  extern __shared__ uint32_t s_hist[];
-  for (int i = threadIdx.x; i < NB; i += 1024) s_hist[i] = 0;
-  __syncthreads();
-  bin_walk(P, radii, means2D, gx, gy, load_buckets(depths, splits),
-           [&](int, unsigned tile, unsigned b) { atomicAdd(&s_hist[tile * B + b], 1u); });
-  __syncthreads();
-  uint32_t* row = hist + (size_t)blockIdx.x * NB;
-  for (int i = threadIdx.x; i < NB; i += 1024) row[i] = s_hist[i];
-}
-
-// exclusive scan of the bin totals -> bin starts, clamped sub-ranges, the tiles' ranges, R / overflow, and the bins
-// listed by length class for the sort kernels.  One workgroup.
-__global__ void __launch_bounds__(1024)
-split_prefix_bins_kernel(int NB, unsigned B, int T, unsigned capacity, const uint32_t* __restrict__ totals,
-                         uint32_t* __restrict__ bin_start, uint2* __restrict__ sub_ranges, uint2* __restrict__ ranges,
-                         uint32_t* __restrict__ cls_list, uint32_t* __restrict__ cls_count,
-                         uint32_t* __restrict__ counters, uint32_t* __restrict__ user_counters) {
-  __shared__ uint32_t s_sum[1024];
-  __shared__ uint32_t s_cnt[4];
-  const int per = (NB + 1023) / 1024;
-  const int i0 = min(NB, (int)threadIdx.x * per), i1 = min(NB, i0 + per);
-  uint32_t local = 0;
-  for (int i = i0; i < i1; i++) local += totals[i];
-  s_sum[threadIdx.x] = local;
-  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const uint32_t v = threadIdx.x >= (unsigned)off ? s_sum[threadIdx.x - off] : 0u;
-    __syncthreads();
-    s_sum[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = s_sum[threadIdx.x] - local;
-  for (int i = i0; i < i1; i++) {
-    const uint32_t c = totals[i];
-    bin_start[i] = run;
-    const uint32_t a = min(run, capacity), e = min(run + c, capacity);
-    sub_ranges[i] = make_uint2(a, e);
-    const uint32_t n = e - a;
-    if (n) {
-      const int cls = n <= 2048u ? 0 : n <= 8192u ? 1 : n <= 16384u ? 2 : 3;
-      cls_list[(size_t)cls * NB + atomicAdd(&s_cnt[cls], 1u)] = (uint32_t)i;
-    }
-    run += c;
-  }
-  const uint32_t R = s_sum[1023];
-  if (threadIdx.x == 1023) {
-    bin_start[NB] = R;
-    counters[0] = R;
-    counters[1] = R > capacity ? R : 0u;
-    if (user_counters) { user_counters[0] = R; user_counters[1] = R > capacity ? R : 0u; }
-  }
-  __syncthreads();  // bin_start is complete (and visible to this workgroup)
-  if (threadIdx.x < 4) cls_count[threadIdx.x] = s_cnt[threadIdx.x];
-  for (int t = threadIdx.x; t < T; t += 1024) {
-    const uint32_t a = bin_start[(size_t)t * B], e = bin_start[(size_t)(t + 1) * B];
-    // an empty tile keeps (0, 0), what the reference's memset leaves there (rasterizer_impl.cu:621)
-    ranges[t] = e > a ? make_uint2(min(a, capacity), min(e, capacity)) : make_uint2(0u, 0u);
-  }
-}
-
-__global__ void __launch_bounds__(1024)
-split_scatter_kernel(int P, int NB, unsigned B, const int* __restrict__ radii, const float* __restrict__ means2D,
-                     const float* __restrict__ depths, unsigned gx, unsigned gy, unsigned capacity, unsigned idx_bits,
-                     const uint32_t* __restrict__ splits, const uint32_t* __restrict__ hist,
-                     const uint32_t* __restrict__ bin_start, uint64_t* __restrict__ keys) {
-  extern __shared__ uint32_t s_cur[];
-  const uint32_t* row = hist + (size_t)blockIdx.x * NB;
-  for (int i = threadIdx.x; i < NB; i += 1024) s_cur[i] = bin_start[i] + row[i];
-  __syncthreads();
-  bin_walk(P, radii, means2D, gx, gy, load_buckets(depths, splits), [&](int idx, unsigned tile, unsigned b) {
-    const uint32_t slot = atomicAdd(&s_cur[tile * B + b], 1u);
-    if (slot < capacity) keys[slot] = ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint32_t)idx;
-  });
-}
-
-// the sort kernels of the split path: persistent grids over one length class's list of bins
+// one workgroup per tile (most return at once): sample, sort the sample, publish splitters and the chunk descriptors
+using SampleSort = rocprim::block_radix_sort<uint64_t, 256, 4, rocprim::empty_type, 1, 1, 8>;
 __global__ void __launch_bounds__(256)
-split_sort_small_kernel(int NB, unsigned B, unsigned idx_bits, const uint32_t* __restrict__ cls_list,
-                        const uint32_t* __restrict__ cls_count, const uint2* __restrict__ sub_ranges,
-                        const uint64_t* __restrict__ keys_unsorted, uint64_t* __restrict__ keys_out,
-                        uint32_t* __restrict__ point_list) {
-  __shared__ SortSmall storage;
-  const unsigned count = cls_count[0];
-  for (unsigned i = blockIdx.x; i < count; i += gridDim.x) {
-    const uint32_t bin = cls_list[i];
-    const uint2 rg = sub_ranges[bin];
-    sort_tile_radix<8, SortSmall, 256>(storage, keys_unsorted + rg.x, rg.y - rg.x, idx_bits, (uint64_t)(bin / B) << 32, rg.x,
-                                       keys_out, point_list);
+long_plan_kernel(int T, unsigned idx_bits, unsigned target, const uint2* __restrict__ ranges,
+                 const uint64_t* __restrict__ keys_unsorted, LongState st) {
+  __shared__ SampleSort::storage_type storage;
+  __shared__ uint64_t s_sorted[kSampleMax];
+  __shared__ uint32_t s_slot, s_first;
+  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    const uint2 rg = ranges[tile];
+    const unsigned n = rg.y - rg.x;
+    if (n <= kLongList) continue;
+    const unsigned B = buckets_for(n, target), nch = (n + kPartChunk - 1) / kPartChunk;
+    if (threadIdx.x == 0) {
+      s_slot = atomicAdd(&st.counts[0], 1u);
+      s_first = atomicAdd(&st.counts[1], nch);
+    }
+    // a uniform sample of the tile's keys (their order after the scatter is arbitrary): every (n / S)-th one
+    const unsigned S = kSampleMax;  // n > kLongList > S
+    uint64_t k[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const unsigned j = threadIdx.x * 4 + i;
+      k[i] = keys_unsorted[rg.x + (unsigned)(((unsigned long long)j * n) / S)];
+    }
+    SampleSort().sort(k, storage, 0, 32 + idx_bits);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s_sorted[threadIdx.x * 4 + i] = k[i];
+    __syncthreads();
+    const unsigned slot = s_slot, first = s_first;
+    if (threadIdx.x < kMaxBuckets) {
+      const unsigned j = threadIdx.x;  // splitter j closes bucket j: bucket(x) = #{j < B - 1 : splitter[j] <= x}
+      st.splitters[(size_t)slot * kMaxBuckets + j] = (j + 1 < B) ? s_sorted[((j + 1) * S) / B] : ~0ull;
+    }
+    if (threadIdx.x == 0) st.tiles[slot] = LongTile{(uint32_t)tile, B, first, nch};
+    for (unsigned c = threadIdx.x; c < nch; c += 256) st.chunk_desc[first + c] = make_uint2(slot, c);
+    __syncthreads();
   }
 }
 
-template <bool kBig>
+__device__ __forceinline__ unsigned bucket_of(uint64_t x, const uint64_t* __restrict__ s_split) {
+  // upper bound over the 31 splitter slots (unused ones are ~0 > every key): 5 steps
+  unsigned lo = 0;
+#pragma unroll
+  for (unsigned step = 16; step; step >>= 1)
+    if (s_split[lo + step - 1] <= x) lo += step;
+  return lo;
+}
+
+// histogram (kScatter = false) and partition (kScatter = true) over the 4096-key chunks of the long tiles
+template <bool kScatter>
+__global__ void __launch_bounds__(256)
+long_chunks_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys_unsorted, uint64_t* __restrict__ keys_tmp,
+                   LongState st) {
+  __shared__ uint64_t s_split[kMaxBuckets];
+  __shared__ uint32_t s_cnt[kMaxBuckets];
+  const unsigned nchunks = st.counts[1];
+  for (unsigned ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const uint2 d = st.chunk_desc[ch];
+    const LongTile lt = st.tiles[d.x];
+    const uint2 rg = ranges[lt.tile];
+    const unsigned n = rg.y - rg.x, c0 = d.y * kPartChunk, c1 = min(n, c0 + kPartChunk);
+    if (threadIdx.x < kMaxBuckets) {
+      s_split[threadIdx.x] = st.splitters[(size_t)d.x * kMaxBuckets + threadIdx.x];
+      // partition: the bucket's start inside the tile + what the tile's earlier chunks put into it
+      s_cnt[threadIdx.x] = kScatter ? st.bucket_start[(size_t)d.x * kMaxBuckets + threadIdx.x] +
+                                          st.chunk_hist[(size_t)ch * kMaxBuckets + threadIdx.x]
+                                    : 0u;
+    }
+    __syncthreads();
+    const uint64_t* src = keys_unsorted + rg.x;
+    for (unsigned i = c0 + threadIdx.x; i < c1; i += 256) {
+      const uint64_t x = src[i];
+      const unsigned b = bucket_of(x, s_split);
+      const unsigned pos = atomicAdd(&s_cnt[b], 1u);
+      if (kScatter) keys_tmp[rg.x + pos] = x;
+    }
+    __syncthreads();
+    if (!kScatter && threadIdx.x < kMaxBuckets) st.chunk_hist[(size_t)ch * kMaxBuckets + threadIdx.x] = s_cnt[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// per long tile (one wave): prefix of the chunk histograms over the tile's chunks, bucket starts, and the buckets listed by
+// length class for the sort kernels
+__global__ void __launch_bounds__(64)
+long_prefix_kernel(const uint2* __restrict__ ranges, LongState st) {
+  const unsigned nlong = st.counts[0];
+  for (unsigned slot = blockIdx.x; slot < nlong; slot += gridDim.x) {
+    const LongTile lt = st.tiles[slot];
+    const uint2 rg = ranges[lt.tile];
+    const unsigned b = threadIdx.x;
+    uint32_t run = 0;
+    if (b < kMaxBuckets)
+      for (unsigned c = 0; c < lt.nchunks; c++) {
+        uint32_t* h = st.chunk_hist + (size_t)(lt.first_chunk + c) * kMaxBuckets + b;
+        const uint32_t v = *h;
+        *h = run;
+        run += v;
+      }
+    // exclusive scan of the bucket totals over the 32 bucket lanes
+    uint32_t incl = run;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off);
+      if ((int)(b & 31) >= off) incl += v;
+    }
+    const uint32_t start = incl - run;
+    if (b < kMaxBuckets) st.bucket_start[(size_t)slot * kMaxBuckets + b] = start;
+    // append the non-empty buckets to their length class's list: one atomic per (tile, class), not per bucket
+    const int cls = (b < kMaxBuckets && run) ? (run <= 2048u ? 0 : run <= 8192u ? 1 : run <= 16384u ? 2 : 3) : -1;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
+      if (m == 0) continue;
+      uint32_t base = 0;
+      if (threadIdx.x == 0) base = atomicAdd(&st.counts[4 + c], (uint32_t)__popcll(m));
+      base = __shfl(base, 0);
+      if (cls == c)
+        st.cls_list[(size_t)c * st.max_buckets + base + (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1))] =
+            make_uint4(rg.x + start, run, lt.tile, 0u);
+    }
+  }
+}
+
+// sorts of the buckets (in place in keys_out, where the partition left them)
+__global__ void __launch_bounds__(256)
+long_sort_small_kernel(unsigned idx_bits, LongState st, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ point_list) {
+  __shared__ SortSmall storage;
+  const unsigned count = st.counts[4];
+  for (unsigned i = blockIdx.x; i < count; i += gridDim.x) {
+    const uint4 d = st.cls_list[i];
+    sort_tile_radix<8, SortSmall, 256>(storage, keys_out + d.x, d.y, idx_bits, (uint64_t)d.z << 32, d.x, keys_out, point_list);
+  }
+}
+
+// kHuge = false: buckets of 2049 .. 8192 keys (64 KB of LDS, two workgroups per CU); true: the longer ones (132 KB)
+template <bool kHuge>
 __global__ void __launch_bounds__(1024)
-split_sort_kernel(int NB, unsigned B, unsigned idx_bits, const uint32_t* __restrict__ cls_list,
-                  const uint32_t* __restrict__ cls_count, const uint2* __restrict__ sub_ranges,
-                  uint64_t* __restrict__ keys_unsorted, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ point_list) {
+long_sort_kernel(unsigned idx_bits, LongState st, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ point_list) {
   __shared__ union SortStorage {
     SortS4 s4; SortS8 s8;
-    char big[kBig ? sizeof(SortS16) : 8];
+    char big[kHuge ? sizeof(SortS16) : 8];
     __device__ SortStorage() {}
   } storage;
-  // kBig: classes 2 (<= 16384 keys) and 3 (longer) in one list walk; else class 1
-  const unsigned n2 = kBig ? cls_count[2] : 0u, count = kBig ? n2 + cls_count[3] : cls_count[1];
+  const unsigned n2 = kHuge ? st.counts[6] : 0u, count = kHuge ? n2 + st.counts[7] : st.counts[5];
   for (unsigned i = blockIdx.x; i < count; i += gridDim.x) {
-    const uint32_t bin = kBig ? (i < n2 ? cls_list[(size_t)2 * NB + i] : cls_list[(size_t)3 * NB + (i - n2)])
-                              : cls_list[(size_t)NB + i];
-    const uint2 rg = sub_ranges[bin];
-    const unsigned n = rg.y - rg.x;
-    uint64_t* src = keys_unsorted + rg.x;
-    const uint64_t tile_hi = (uint64_t)(bin / B) << 32;
-    if constexpr (kBig) {
-      if (n <= 16384) {
-        sort_tile_radix<16>(*reinterpret_cast<SortS16*>(storage.big), src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
-      } else {
-        const uint64_t idx_mask = (1ull << idx_bits) - 1;
-        unsigned npad = 0;
-        while ((1u << npad) < n) npad++;
-        bitonic_sort_asc(n, npad, 1024u, [&](unsigned k) { return __builtin_nontemporal_load(src + k); },
-                         [&](unsigned k, uint64_t v) { __builtin_nontemporal_store(v, src + k); });
-        for (unsigned k = threadIdx.x; k < n; k += 1024) {
-          const uint64_t kk = __builtin_nontemporal_load(src + k);
-          point_list[rg.x + k] = (uint32_t)(kk & idx_mask);
-          keys_out[rg.x + k] = tile_hi | (kk >> idx_bits);
-        }
-        __syncthreads();
-      }
+    const uint4 d = !kHuge ? st.cls_list[st.max_buckets + i]
+                           : i < n2 ? st.cls_list[2 * st.max_buckets + i] : st.cls_list[3 * st.max_buckets + (i - n2)];
+    const unsigned n = d.y;
+    uint64_t* src = keys_out + d.x;
+    const uint64_t tile_hi = (uint64_t)d.z << 32;
+    if constexpr (!kHuge) {
+      if (n <= 4096) sort_tile_radix<4>(storage.s4, src, n, idx_bits, tile_hi, d.x, keys_out, point_list);
+      else sort_tile_radix<8>(storage.s8, src, n, idx_bits, tile_hi, d.x, keys_out, point_list);
+    } else if (n <= 16384) {
+      sort_tile_radix<16>(*reinterpret_cast<SortS16*>(storage.big), src, n, idx_bits, tile_hi, d.x, keys_out, point_list);
     } else {
-      if (n <= 4096) sort_tile_radix<4>(storage.s4, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
-      else sort_tile_radix<8>(storage.s8, src, n, idx_bits, tile_hi, rg.x, keys_out, point_list);
+      const uint64_t idx_mask = (1ull << idx_bits) - 1;
+      unsigned npad = 0;
+      while ((1u << npad) < n) npad++;
+      bitonic_sort_asc(n, npad, 1024u, [&](unsigned k) { return __builtin_nontemporal_load(src + k); },
+                       [&](unsigned k, uint64_t v) { __builtin_nontemporal_store(v, src + k); });
+      for (unsigned k = threadIdx.x; k < n; k += 1024) {
+        const uint64_t kk = __builtin_nontemporal_load(src + k);
+        point_list[d.x + k] = (uint32_t)(kk & idx_mask);
+        keys_out[d.x + k] = tile_hi | (kk >> idx_bits);
+      }
+      __syncthreads();
     }
   }
 }
@@ -710,11 +719,16 @@ static unsigned bin_index_bits(int P) {  // bits that hold every Gaussian index
 }
 
 static int bin_groups(int P) { return std::min((int)kBinGroups, (P + 255) / 256); }
+constexpr int kWideWalk = 1 << 20;  // clouds from this size on are walked by 1024-lane workgroups
 
 void launch_bin_count(int P, const int* radii, unsigned gx, unsigned gy, const GeomState& g, const ImageState& img, hipStream_t s) {
   const int T = (int)(gx * gy);
-  hipLaunchKernelGGL(bin_count_kernel, dim3(bin_groups(P)), dim3(256), (size_t)T * sizeof(uint32_t), s, P, T, radii, g.means2D,
-                     gx, gy, img.bin_hist);
+  if (P >= kWideWalk)
+    hipLaunchKernelGGL(bin_count_kernel<1024>, dim3(bin_groups(P)), dim3(1024), (size_t)T * sizeof(uint32_t), s, P, T, radii,
+                       g.means2D, gx, gy, img.bin_hist);
+  else
+    hipLaunchKernelGGL(bin_count_kernel<256>, dim3(bin_groups(P)), dim3(256), (size_t)T * sizeof(uint32_t), s, P, T, radii,
+                       g.means2D, gx, gy, img.bin_hist);
 }
 
 // the tile totals and the unclamped tile starts live in the two extra rows of bin_hist (ImageState carves kBinGroups + 2)
@@ -730,73 +744,42 @@ void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsig
                         const BinningState& b, const ImageState& img, hipStream_t s) {
   const int T = (int)(gx * gy);
   const uint32_t* tile_start = img.bin_hist + (size_t)(kBinGroups + 1) * T;
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(bin_groups(P)), dim3(256), (size_t)T * sizeof(uint32_t), s, P, T, radii,
-                     g.means2D, g.depths, gx, gy, capacity, bin_index_bits(P), img.bin_hist, tile_start, b.keys_unsorted);
+  if (P >= kWideWalk)
+    hipLaunchKernelGGL(bin_scatter_kernel<1024>, dim3(bin_groups(P)), dim3(1024), (size_t)T * sizeof(uint32_t), s, P, T, radii,
+                       g.means2D, g.depths, gx, gy, capacity, bin_index_bits(P), img.bin_hist, tile_start, b.keys_unsorted);
+  else
+    hipLaunchKernelGGL(bin_scatter_kernel<256>, dim3(bin_groups(P)), dim3(256), (size_t)T * sizeof(uint32_t), s, P, T, radii,
+                       g.means2D, g.depths, gx, gy, capacity, bin_index_bits(P), img.bin_hist, tile_start, b.keys_unsorted);
 }
 
-// ---- split path launchers.  NB = T * B bins; the tables live in the binning chunk's sort_space (the split path
-// does not use the global radix sort that space is sized for; sort_size_cached() covers both)
-int split_buckets(size_t est_mean_list, size_t T) {
-  // B such that a sub-list averages ~1000 keys: the 256-lane LDS sort's size; NB * 4 B of LDS per counting workgroup
-  if (const char* e = getenv("GIGS_BIN_SPLIT")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4 || v == 8) return ((size_t)v * T <= (size_t)kSplitMaxBins) ? v : 1;
-  }
-  int B = 1;
-  while (B < 8 && (size_t)B * 1024 < est_mean_list) B <<= 1;
-  while (B > 1 && (size_t)B * T > (size_t)kSplitMaxBins) B >>= 1;
-  return B;
-}
-
-static void split_lds_attr() {
-  // more than 64 KB of dynamic LDS per workgroup has to be granted per kernel
-  static const bool once = [] {
-    const int bytes = kSplitMaxBins * (int)sizeof(uint32_t);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(split_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(split_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    return true;
-  }();
-  (void)once;
-}
-
-void launch_split_count(int P, int T, int B, unsigned capacity, const int* radii, unsigned gx, unsigned gy, const GeomState& g,
-                        const BinningState& b, const ImageState& img, unsigned* user_counters, hipStream_t s) {
-  const int NB = T * B;
-  SplitState st = SplitState::fromChunk(b.sort_space, (size_t)NB);
-  split_lds_attr();
-  hipLaunchKernelGGL(split_depth_hist_kernel, dim3(kDepthRows), dim3(1024), 0, s, P, radii, g.depths, g.tiles_touched,
-                     st.depth_hist);
-  hipLaunchKernelGGL(split_pick_kernel, dim3(1), dim3(1024), 0, s, (unsigned)B, st.depth_hist, st.splits);
-  hipLaunchKernelGGL(split_count_kernel, dim3(bin_groups(P)), dim3(1024), (size_t)NB * sizeof(uint32_t), s, P, NB, (unsigned)B,
-                     radii, g.means2D, g.depths, gx, gy, st.splits, st.hist);
-  hipLaunchKernelGGL(bin_prefix_groups_kernel, dim3((NB + 63) / 64), dim3(1024), 0, s, bin_groups(P), NB, st.hist, st.totals);
-  hipLaunchKernelGGL(split_prefix_bins_kernel, dim3(1), dim3(1024), 0, s, NB, (unsigned)B, T, capacity, st.totals, st.bin_start,
-                     st.sub_ranges, img.ranges, st.cls_list, st.cls_count, img.bin_counters, user_counters);
-}
-
-void launch_split_scatter_sort(int P, int T, int B, unsigned capacity, const int* radii, unsigned gx, unsigned gy,
-                               const GeomState& g, const BinningState& b, hipStream_t s) {
-  const int NB = T * B;
-  SplitState st = SplitState::fromChunk(b.sort_space, (size_t)NB);
+// ---- dense scenes: the long lists' partition + bucket sorts (tables in the binning chunk's sort_space, which the
+// bucketed path does not otherwise use; sort_size_cached() covers both uses)
+void launch_long_lists(int T, int P, unsigned capacity, const BinningState& b, const ImageState& img, hipStream_t s) {
+  char* space = b.sort_space;
+  LongState st = LongState::fromChunk(space, (size_t)T, (size_t)capacity);
   const unsigned ib = bin_index_bits(P);
-  split_lds_attr();
-  hipLaunchKernelGGL(split_scatter_kernel, dim3(bin_groups(P)), dim3(1024), (size_t)NB * sizeof(uint32_t), s, P, NB, (unsigned)B,
-                     radii, g.means2D, g.depths, gx, gy, capacity, ib, st.splits, st.hist, st.bin_start, b.keys_unsorted);
-  hipLaunchKernelGGL(split_sort_kernel<true>, dim3(256), dim3(1024), 0, s, NB, (unsigned)B, ib, st.cls_list, st.cls_count,
-                     st.sub_ranges, b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL(split_sort_kernel<false>, dim3(512), dim3(1024), 0, s, NB, (unsigned)B, ib, st.cls_list, st.cls_count,
-                     st.sub_ranges, b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL(split_sort_small_kernel, dim3(2048), dim3(256), 0, s, NB, (unsigned)B, ib, st.cls_list, st.cls_count,
-                     st.sub_ranges, b.keys_unsorted, b.keys, b.point_list);
+  launch_zero_words(st.counts, 8, s);
+  static const unsigned target = [] { const char* e = getenv("GIGS_BUCKET_TARGET"); return e ? (unsigned)std::max(256, atoi(e)) : kBucketTarget; }();
+  hipLaunchKernelGGL(long_plan_kernel, dim3(std::min(T, 1024)), dim3(256), 0, s, T, ib, target, img.ranges, b.keys_unsorted, st);
+  hipLaunchKernelGGL(long_chunks_kernel<false>, dim3(2048), dim3(256), 0, s, img.ranges, b.keys_unsorted, b.keys, st);
+  hipLaunchKernelGGL(long_prefix_kernel, dim3(std::min(T, 1024)), dim3(64), 0, s, img.ranges, st);
+  hipLaunchKernelGGL(long_chunks_kernel<true>, dim3(2048), dim3(256), 0, s, img.ranges, b.keys_unsorted, b.keys, st);
+  hipLaunchKernelGGL(long_sort_kernel<true>, dim3(256), dim3(1024), 0, s, ib, st, b.keys, b.point_list);
+  hipLaunchKernelGGL(long_sort_kernel<false>, dim3(512), dim3(1024), 0, s, ib, st, b.keys, b.point_list);
+  hipLaunchKernelGGL(long_sort_small_kernel, dim3(2048), dim3(256), 0, s, ib, st, b.keys, b.point_list);
 }
 
-int launch_bin_sort(int T, int P, const BinningState& b, const ImageState& img, hipStream_t s) {
+int launch_bin_sort(int T, int P, bool long_lists, unsigned capacity, const BinningState& b, const ImageState& img, hipStream_t s) {
   // (Running size classes concurrently on forked streams was tried: with the light's side stream and two sort streams
   // the runtime ran out of hardware queues and folded the light filter onto the main queue -- 25 % slower.  Hence one
-  // kernel that holds lists of every length up to 8192 keys, and a second, usually empty-handed, for the longer ones.)
+  // kernel that holds lists of every length up to 8192 keys, and a second for the longer ones: in a sparse scene it
+  // sorts them whole (usually there are none), in a dense one they are partitioned first (launch_long_lists).)
   const unsigned ib = bin_index_bits(P);
-  hipLaunchKernelGGL(bin_sort_kernel<true>, dim3(std::min(T, 256)), dim3(1024), 0, s, T, ib, img.tile_order, img.ranges,
-                     b.keys_unsorted, b.keys, b.point_list);
+  if (long_lists)
+    launch_long_lists(T, P, capacity, b, img, s);
+  else
+    hipLaunchKernelGGL(bin_sort_kernel<true>, dim3(std::min(T, 256)), dim3(1024), 0, s, T, ib, img.tile_order, img.ranges,
+                       b.keys_unsorted, b.keys, b.point_list);
   hipLaunchKernelGGL(bin_sort_kernel<false>, dim3(std::min(T, 512)), dim3(1024), 0, s, T, ib, img.tile_order, img.ranges,
                      b.keys_unsorted, b.keys, b.point_list);
   hipLaunchKernelGGL(bin_sort_small_kernel, dim3(std::min(T, 2048)), dim3(256), 0, s, T, ib, img.tile_order, img.ranges,

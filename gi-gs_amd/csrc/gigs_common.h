@@ -175,7 +175,6 @@ struct GeomState {
 // their exclusive prefix over the chunks.
 constexpr int kBinGroups = 256;
 constexpr int kBinMaxTiles = 16384;
-constexpr int kSplitMaxBins = 38912;   // (tile, depth bucket) bins of the dense-scene path: 152 KB of LDS counters
 constexpr int kBucketMaxMeanList = 2500;  // mean instances per tile above which synchronous calls use the global radix sort  // the per-workgroup tile histogram lives in LDS (64 KB at this size)
 
 struct ImageState {
@@ -243,14 +242,9 @@ void launch_bin_count(int P, const int* radii, unsigned gx, unsigned gy, const G
 void launch_bin_prefix(int P, int T, unsigned capacity, const ImageState& img, unsigned* user_counters, hipStream_t s);
 void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, const GeomState& g,
                         const BinningState& b, const ImageState& img, hipStream_t s);
-int launch_bin_sort(int T, int P, const BinningState& b, const ImageState& img, hipStream_t s);
-// dense scenes: the same with B depth buckets per tile (binning.hip, "depth-split bins")
-int split_buckets(size_t est_mean_list, size_t T);
-size_t split_space_bytes(size_t NB);
-void launch_split_count(int P, int T, int B, unsigned capacity, const int* radii, unsigned gx, unsigned gy, const GeomState& g,
-                        const BinningState& b, const ImageState& img, unsigned* user_counters, hipStream_t s);
-void launch_split_scatter_sort(int P, int T, int B, unsigned capacity, const int* radii, unsigned gx, unsigned gy,
-                               const GeomState& g, const BinningState& b, hipStream_t s);
+// long_lists: tiles above 8192 keys are partitioned by sampled splitters and sorted bucket by bucket (dense scenes)
+int launch_bin_sort(int T, int P, bool long_lists, unsigned capacity, const BinningState& b, const ImageState& img, hipStream_t s);
+size_t long_space_bytes(size_t T, size_t R);
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                          hipStream_t s);
 hipError_t scan_tiles(const GeomState& g, int P, hipStream_t s);

@@ -234,21 +234,17 @@ class RasterFront(torch.nn.Module):
 
 
 BUCKET_MAX_MEAN_LIST = int(os.environ.get("GIGS_BUCKET_MAX_MEAN", "2500"))  # csrc/gigs_common.h kBucketMaxMeanList
-SPLIT_MAX_BINS = 38912  # csrc/gigs_common.h kSplitMaxBins
 
 
 class DenseScene(RuntimeError):
-    """The scene averages more instances per tile than one workgroup sorts in LDS AND the library cannot split its tiles
-    into depth buckets (more than kSplitMaxBins / 2 tiles, or GIGS_BIN_SPLIT=1): asynchronous binning / graph capture of
-    the rasterizer is declined and the caller keeps the synchronous path with the global radix sort.  Ordinary dense
-    scenes (3 M Gaussians at the Mip-NeRF360 images_4 sizes: 7 000 instances per tile) are NOT declined: the library
-    bins them into (tile, depth bucket) pairs (csrc/binning.hip) and they take the asynchronous, captured path."""
+    """Raised by the graph-capturing steppers only under GIGS_LONG_LISTS=0 for a scene that averages more instances per
+    tile than one workgroup sorts in LDS: the caller then keeps the synchronous path.  By default dense scenes (3 M
+    Gaussians at the Mip-NeRF360 images_4 sizes: 7 000 instances per tile) are NOT declined: the library partitions
+    their long tile lists by sampled splitters (csrc/binning.hip) and they take the asynchronous, captured path."""
 
 
 def _declined_as_dense(probe: int, tiles: int) -> bool:
-    if probe <= BUCKET_MAX_MEAN_LIST * tiles:
-        return False
-    return os.environ.get("GIGS_BIN_SPLIT", "") == "1" or 2 * tiles > SPLIT_MAX_BINS
+    return probe > BUCKET_MAX_MEAN_LIST * tiles and os.environ.get("GIGS_LONG_LISTS", "") == "0"
 
 
 class GraphedRaster:

@@ -566,20 +566,24 @@ def test_fused_derive_normal_is_bit_identical_to_the_four_kernel_chain(W, H, mon
 # ------------------------------------------------------------------------------------------
 # binning paths
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["legacy", "bucket", "split2", "split8"])
+@pytest.mark.parametrize("mode", ["legacy", "bucket", "long_lists"])
 def test_binning_paths_match_oracle(orc, mode, monkeypatch):
     """All binning paths -- the reference-shaped scan / duplicate / global radix sort (legacy), the default
-    tile-bucketed count / prefix / scatter / per-tile sort, and the dense-scene form of the latter with 2 or 8 depth
-    buckets per tile (forced here: GIGS_BIN_SPLIT) -- give the oracle's keys, point_list and ranges bit for bit,
-    on a cloud with large footprints (wave-expanded), exact depth ties (duplicated Gaussians) and a ragged image."""
+    tile-bucketed count / prefix / scatter / per-tile sort, and the latter in its dense-scene configuration (forced here:
+    GIGS_LONG_LISTS=1; these scenes have no list long enough to be partitioned, the kernels run empty-handed) -- give the
+    oracle's keys, point_list and ranges bit for bit, on a cloud with large footprints (wave-expanded), exact depth ties
+    (duplicated Gaussians) and a ragged image."""
     monkeypatch.setenv("GIGS_BINNING", "legacy" if mode == "legacy" else "bucket")
-    if mode.startswith("split"):
-        monkeypatch.setenv("GIGS_BIN_SPLIT", mode[5:])
+    if mode == "long_lists":
+        monkeypatch.setenv("GIGS_LONG_LISTS", "1")
     sc = scenes.random_scene(P=6000, sh_degree=1, seed=21, scale_mu=0.12)
     # exact depth ties inside tiles: the same Gaussian several times (ties must come out in index order)
     for k in GAUSS_KEYS:
         sc[k][3000:3400] = sc[k][100:500]
         sc[k][3400:3800] = sc[k][100:500]
+    # ... and a long run of bit-identical depths: one Gaussian 300 times (its tiles see 300 keys that differ in the index only)
+    for k in GAUSS_KEYS:
+        sc[k][5000:5300] = sc[k][777]
     cam = scenes.orbit_camera(2, 7, 333, 211)
     check_forward(orc, sc, cam, tag=mode + " ")
     sc = scenes.surface_scene(P=40_000, sh_degree=1, seed=5, scale_mu=0.02)
@@ -625,17 +629,18 @@ def test_async_binning_capacity_and_overflow(orc):
         assert np.isfinite(np.nan_to_num(v)).all(), k
 
 
-@pytest.mark.parametrize("split", ["4", "auto"])
-def test_dense_scene_split_binning_sync_and_async(orc, split, monkeypatch):
-    """A dense view (mean list above the split threshold: sub-lists of every length class, incl. one tile beyond 16 384
-    keys) through the depth-split binning, synchronous (the reference's API: R read back) and asynchronous (fixed
-    capacity, device counters): keys / point_list / ranges equal the oracle's, the planes equal the legacy path's bit for
-    bit, and an undersized capacity raises the flag without writing out of bounds."""
+@pytest.mark.parametrize("split", ["auto", "off"])
+def test_dense_scene_long_lists_sync_and_async(orc, split, monkeypatch):
+    """A dense view (mean list 6 000, two tiles near 30 000 keys of which 20 000 share nearly one depth) through the
+    tile-bucketed binning with its long lists partitioned by sampled splitters ("auto": the library's own criterion) and
+    sorted whole ("off": GIGS_LONG_LISTS=0, the global-memory network), synchronous (the reference's API: R read back) and
+    asynchronous (fixed capacity, device counters): keys / point_list / ranges equal the oracle's, the planes equal the
+    legacy path's bit for bit, and an undersized capacity raises the flag without writing out of bounds."""
     import gigs_lib
     dgr = _dgr()
     lib = gigs_lib.lib()
-    if split != "auto":
-        monkeypatch.setenv("GIGS_BIN_SPLIT", split)
+    if split == "off":
+        monkeypatch.setenv("GIGS_LONG_LISTS", "0")
     # ~3 000 instances per tile on average at 96x80 (30 tiles), one screen-filling cluster in front: a very long list
     sc = scenes.surface_scene(P=44_000, sh_degree=1, seed=9, scale_mu=0.08)
     cam = scenes.orbit_camera(1, 5, 96, 80, radius=3.0)
