@@ -779,6 +779,7 @@ struct ShadeArgs {
   const float* lut; int lut_w, lut_h;
   int tone, gamma;
   int ablate;  // diagnostic only (env GIGS_ABLATE): bit 0 skips the diffuse-map atomics, bit 1 the specular ones
+  int part;    // backward: 0 = everything; 1 = the material gradients only; 2 = the light-texture gradients only (gigs_shade_ext)
   // backward: gradient textures small enough to be accumulated per workgroup in LDS
   int lds_total;        // floats of dynamic LDS
   int lds_diffuse_off;  // offset (floats) of the diffuse-map accumulator, or -1
@@ -1034,21 +1035,24 @@ shade_bwd_kernel(ShadeArgs A) {
       }
       if (q.l1 != q.l0) d_lvl += g_sp[c] * (s1v[c] - s0v[c]);
     }
+    if (A.part != 2) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      if (A.g_albedo_mul_a) d_alb[c] += (A.g_albedo_mul_a[e + c * cs] * gscale) * A.g_albedo_mul_b[e + c * cs];
-      A.d_albedo[e + c * cs] = d_alb[c];
+      for (int c = 0; c < 3; c++) {
+        if (A.g_albedo_mul_a) d_alb[c] += (A.g_albedo_mul_a[e + c * cs] * gscale) * A.g_albedo_mul_b[e + c * cs];
+        A.d_albedo[e + c * cs] = d_alb[c];
+      }
+      float add_r = A.g_roughness_add ? A.g_roughness_add[p] : 0.0f, add_m = A.g_metallic_add ? A.g_metallic_add[p] : 0.0f;
+      if (A.lamb_mask) {  // stage2_loss_bwd_kernel's two lines
+        const float m = A.lamb_mask[p], cnt = A.lamb_acc4[3];
+        add_r += -m / cnt * (0.001f * gscale);
+        add_m += m / cnt * (0.001f * gscale);
+      }
+      if (A.d_metallic) A.d_metallic[p] = d_m + add_m;
+      const float d_r = d_fgx * q.dfgx_dv + d_fgy * q.dfgy_dv + (q.lvl_inside ? d_lvl * q.dmdr : 0.0f);
+      A.d_roughness[p] = (d_r + add_r) * A.rough_scale;
     }
-    float add_r = A.g_roughness_add ? A.g_roughness_add[p] : 0.0f, add_m = A.g_metallic_add ? A.g_metallic_add[p] : 0.0f;
-    if (A.lamb_mask) {  // stage2_loss_bwd_kernel's two lines
-      const float m = A.lamb_mask[p], cnt = A.lamb_acc4[3];
-      add_r += -m / cnt * (0.001f * gscale);
-      add_m += m / cnt * (0.001f * gscale);
-    }
-    if (A.d_metallic) A.d_metallic[p] = d_m + add_m;
-    const float d_r = d_fgx * q.dfgx_dv + d_fgy * q.dfgy_dv + (q.lvl_inside ? d_lvl * q.dmdr : 0.0f);
-    A.d_roughness[p] = (d_r + add_r) * A.rough_scale;
   }
+  if (A.part == 1) continue;  // the material gradients only (uniform over the grid)
   // ---- light textures (wave-uniform control flow from here on) ----
   if (A.d_diffuse && !(A.ablate & 1)) {
     float* base = A.lds_diffuse_off >= 0 ? s_lds + A.lds_diffuse_off : A.d_diffuse;
@@ -1423,8 +1427,10 @@ int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs
   const int rc = fill_shade(A, H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, nullptr,
                             diffuse, diffuse_res, n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma);
   if (rc) return rc;
-  if (!d_albedo || !d_roughness) return gigs_internal_fail(GIGS_ERR_INVALID, "shade_bwd: null output");
   if (apply_shade_ext(A, ext, true)) return GIGS_ERR_INVALID;
+  A.part = (ext && ext->part >= 0 && ext->part <= 2) ? ext->part : 0;
+  if (A.part != 2 && (!d_albedo || !d_roughness)) return gigs_internal_fail(GIGS_ERR_INVALID, "shade_bwd: null output");
+  if (A.part == 1) { d_diffuse = nullptr; d_spec = nullptr; }
   A.g_render = g_render; A.g_diffuse_rgb = g_diffuse_rgb; A.g_specular_rgb = g_specular_rgb; A.g_diffuse_light = g_diffuse_light;
   A.d_albedo = d_albedo; A.d_roughness = d_roughness; A.d_metallic = d_metallic; A.d_diffuse = d_diffuse;
   for (int i = 0; i < n_levels; i++) A.d_spec[i] = d_spec ? d_spec[i] : nullptr;
@@ -1460,8 +1466,10 @@ int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return cus;
   }();
-  hipLaunchKernelGGL(gigs::shade_bwd_kernel, dim3(n_chunks < max_blocks ? n_chunks : max_blocks),
-                     dim3(gigs::kShadeBwdBlock), (size_t)used * sizeof(float), (hipStream_t)stream, A);
+  // part 1 (materials only) keeps no LDS accumulators: one workgroup per chunk instead of the persistent grid
+  const int blocks = (A.part == 1 || n_chunks < max_blocks) ? n_chunks : max_blocks;
+  hipLaunchKernelGGL(gigs::shade_bwd_kernel, dim3(blocks), dim3(gigs::kShadeBwdBlock), (size_t)used * sizeof(float),
+                     (hipStream_t)stream, A);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;

@@ -121,7 +121,7 @@ class ShadeExt(C.Structure):
                 ("out_F0", C.c_void_p), ("out_linear", C.c_void_p), ("out_roughness", C.c_void_p),
                 ("g_albedo_mul_a", C.c_void_p), ("g_albedo_mul_b", C.c_void_p),
                 ("g_roughness_add", C.c_void_p), ("g_metallic_add", C.c_void_p),
-                ("g_scale", C.c_void_p), ("lamb_mask", C.c_void_p), ("lamb_acc4", C.c_void_p)]
+                ("g_scale", C.c_void_p), ("lamb_mask", C.c_void_p), ("lamb_acc4", C.c_void_p), ("part", C.c_int)]
 
 
 class SpecLevel(C.Structure):

@@ -924,8 +924,10 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     args = (normal_map.detach(), out_normal_view.detach(), albedo_map, roughness_map, metallic_map,
             occlusion_map.detach(), depth_pos.detach(), st.viewmatrix, view_dirs, gt_image, *lights)
     if self.back is None:
+        # light_stream: the fused node's backward issues its light-texture gradient scatter there (stage2_fused.py); not
+        # under make_graphed_callables, whose per-callable capture cannot leave a forked stream unjoined
         cfg = dict(H=H, W=W, gi=self.gi, focal_x=W / (2.0 * cam["tanfovx"]), focal_y=H / (2.0 * cam["tanfovy"]),
-                   **self.flags)
+                   light_stream=None if self.graphs else self.side, **self.flags)
         self.back = Stage2FusedBack(self.brdf_lut, cfg)
         if self.graphs:
             # pooled rasterizer planes (fixed addresses) become the graph's static inputs themselves: no staging copies

@@ -15,6 +15,7 @@ tests/test_gpu_pbr.py::test_stage2_fused_matches_unfused compares the two formul
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict
 
 import torch
@@ -118,16 +119,42 @@ class _Stage2Fused(torch.autograd.Function):
         spec_ptr, dspec_ptr = _ptr_array(specular), _ptr_array(d_spec)
         spec_res = (C.c_int * len(specular))(*[int(s.shape[1]) for s in specular])
         # unit-gradient planes from the forward, scaled by g_loss inside the kernel; lamb terms formed there too
-        ext = gigs_lib.ShadeExt(planar=1, rough_scale=1.0 - 0.04, rough_bias=0.04, g_albedo_mul_a=_p(d_irr_u),
-                                g_albedo_mul_b=_p(abd), g_scale=_p(g_loss), lamb_mask=_p(mask_f), lamb_acc4=_p(acc4))
-        with torch.cuda.device(dev):
-            s = _stream()
+        def launch(part, stream):
+            ext = gigs_lib.ShadeExt(planar=1, rough_scale=1.0 - 0.04, rough_bias=0.04, g_albedo_mul_a=_p(d_irr_u),
+                                    g_albedo_mul_b=_p(abd), g_scale=_p(g_loss), lamb_mask=_p(mask_f), lamb_acc4=_p(acc4), part=part)
             gigs_lib.check(_lib.gigs_shade_bwd_ex(
                 H, W, _p(normals_view), _p(view_dirs), _p(albedo_map), _p(roughness_map), _p(mask_u8), _p(occlusion),
                 _p(metallic_map), _p(diffuse), int(diffuse.shape[1]), len(specular), spec_ptr, spec_res, _p(lut),
                 int(lut.shape[-2]), int(lut.shape[-3]), int(bool(cfg["tone"])), int(bool(cfg["gamma"])), _p(d_direct_u),
-                None, None, None, _p(d_albedo), _p(d_rough), _p(d_metal), _p(d_diffuse), dspec_ptr, C.addressof(ext), s),
+                None, None, None, _p(d_albedo), _p(d_rough), _p(d_metal), _p(d_diffuse), dspec_ptr, C.addressof(ext), stream),
                 "shade_bwd_ex")
+
+        light_stream = cfg.get("light_stream")
+        any_light = need_d or any(need_s)
+        with torch.cuda.device(dev):
+            if light_stream is None or not any_light or os.environ.get("GIGS_SHADE_BWD_SPLIT", "0") != "1":
+                launch(0, _stream())
+            else:
+                # Two launches of the same kernel.  The material gradients (to the rasterizer's backward) are one cheap pass;
+                # the light-texture gradients are the float-atomic scatter that dominates this node (0.14 of 0.21 ms at C2) and
+                # feed the light filters' backward, which runs on the light's stream anyway: issued there, they leave the
+                # step's critical path (shade backward -> blend backward -> preprocess backward) and run beside it.
+                main = torch.cuda.current_stream()
+                light_stream.wait_stream(main)  # the inputs, the zero-filled gradient slab
+                launch(1, main.cuda_stream)
+                with torch.cuda.stream(light_stream):
+                    head = int(1e3 * float(os.environ.get("GIGS_SHADE_LIGHT_HEAD_START_US", "0")))
+                    if head > 0:
+                        gigs_lib.check(_lib.gigs_stream_delay(head, light_stream.cuda_stream), "stream_delay")
+                    launch(2, light_stream.cuda_stream)
+                slab.record_stream(light_stream)
+                for t in (normals_view, view_dirs, albedo_map, roughness_map, mask_u8, occlusion, metallic_map, lut, diffuse,
+                          d_direct_u, d_irr_u, abd, acc4, g_loss, mask_f, *specular):
+                    if t is not None:
+                        t.record_stream(light_stream)
+                # no join here: the only consumer of the light gradients is the light filters' backward, which autograd
+                # runs on the stream of its forward -- light_stream itself (pipeline._fused_begin) -- i.e. behind part 2 in
+                # stream order; the engine joins that stream with the caller's when the backward ends
         return (None, None, None, d_albedo, d_rough, d_metal, None, None, None, None, None, None, d_diffuse, *d_spec)
 
 

@@ -251,7 +251,8 @@ int gigs_shade_bwd(int H, int W, const float* normals, const float* view_dirs, c
  *                  g_scale (device scalar, NULL = 1): g_render and g_albedo_mul_a are gradients for a UNIT upstream
  *                  gradient (gigs_stage2_loss_fwd_grad writes them in the forward) and are multiplied by it here;
  *                  lamb_mask [H,W] + lamb_acc4 (gigs_stage2_loss_fwd's acc4): the lamb regulariser's gradients
- *                  -/+ mask / acc4[3] * 0.001 * g_scale are formed here instead of being read from g_*_add.
+ *                  -/+ mask / acc4[3] * 0.001 * g_scale are formed here instead of being read from g_*_add;
+ *                  part: see the member.
  * With ext != NULL diffuse_rgb / specular_rgb / diffuse_light may be NULL (not written). */
 typedef struct gigs_shade_ext {
   int planar;
@@ -259,6 +260,9 @@ typedef struct gigs_shade_ext {
   float *out_F0, *out_linear, *out_roughness;
   const float *g_albedo_mul_a, *g_albedo_mul_b, *g_roughness_add, *g_metallic_add;
   const float *g_scale, *lamb_mask, *lamb_acc4;
+  int part; /* gigs_shade_bwd_ex: 0 = all gradients; 1 = d_albedo / d_roughness / d_metallic only (d_diffuse / d_spec are not
+               touched); 2 = d_diffuse / d_spec only (the material outputs may be NULL).  The two parts of one backward may run
+               on different streams: the material gradients feed the rasterizer's backward, the light's feed its filters'. */
 } gigs_shade_ext;
 int gigs_shade_fwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
                       const float* roughness, const uint8_t* mask, const float* occlusion,

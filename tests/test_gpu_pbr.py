@@ -651,3 +651,41 @@ def test_grad_slab_attach_with_sink_does_not_double_gradients():
     plain, slab = run("plain"), run("slab")
     assert rel_peak(slab.cpu().numpy(), plain.cpu().numpy()) < 2e-3
     assert float(plain.abs().max()) > 0
+
+
+def test_shade_backward_in_two_launches_equals_one(monkeypatch):
+    """GIGS_SHADE_BWD_SPLIT=1: the fused node's backward issues the material gradients on the main stream and the
+    light-texture scatter on the light's stream (gigs_shade_ext.part = 1 / 2): same gradients as the single launch, eager and
+    from the whole-step graphs."""
+    import pbr
+    import pipeline
+    sc = scenes.surface_scene(P=6000, sh_degree=2, seed=41, scale_mu=0.025)
+    gi = scenes.GI_DEFAULTS
+    H, W = 144, 176
+    cam = scenes.orbit_camera(1, 6, W, H, radius=3.5)
+    camt = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    torch.manual_seed(2)
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    vd = pipeline.view_dirs_for(camt, pipeline.canonical_rays(cam, DEV), DEV)
+
+    def run(split, graphs):
+        monkeypatch.setenv("GIGS_SHADE_BWD_SPLIT", split)
+        torch.manual_seed(9)
+        light = pbr.CubemapLight(base_res=64, device=DEV)
+        g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        step = pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=graphs)
+        for _ in range(2):
+            for t in list(g.values()) + [light.base]:
+                t.grad = None
+            o = step(camt, g, gt, vd)
+        torch.cuda.synchronize()
+        return float(o["loss"]), {k: g[k].grad.clone() for k in ("albedo", "roughness", "metallic")}, light.base.grad.clone()
+
+    ref = run("0", False)
+    for graphs in (False, True):
+        got = run("1", graphs)
+        assert abs(got[0] - ref[0]) <= 2e-6 * max(1.0, abs(ref[0]))
+        for k in ref[1]:
+            assert torch.equal(got[1][k], ref[1][k]) or rel_peak(got[1][k].cpu().numpy(), ref[1][k].cpu().numpy()) < 1e-6, k
+        assert rel_peak(got[2].cpu().numpy(), ref[2].cpu().numpy()) < 2e-3  # float atomics: order-dependent rounding
