@@ -415,6 +415,47 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
   return num_rendered;
 }
 
+// Rasterizer::lite_forward (R/cuda_rasterizer/rasterizer.h:90-117, rasterizer_impl.cu:338-482; liteRenderCUDA forward.cu:279-418):
+// colour / opacity / depth only.  The lite kernel composites exactly like the full one (same tests, same depth = view-space
+// z), so this is the full forward over zero material attributes, with the planes the caller did not ask for in scratch: the
+// geometry chunk is requested 8 floats per Gaussian larger (the zero attributes) and the image chunk 14 planes larger.
+namespace {
+struct LiteChunk { char* base; size_t bytes; };
+char* lite_chunk_alloc(size_t n, void* user) {
+  LiteChunk* c = static_cast<LiteChunk*>(user);
+  return n <= c->bytes ? c->base : nullptr;
+}
+}  // namespace
+
+int gigs_lite_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer, void* binning_user,
+                      gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M, const float* background, int width,
+                      int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                      int prefiltered, int argmax_depth, float* out_color, float* out_opacity, float* out_depth, int* radii,
+                      int debug, void* stream) {
+  if (P < 0 || width <= 0 || height <= 0) return fail(GIGS_ERR_INVALID, "bad P / image size");
+  if (P == 0) return 0;
+  if (!geometryBuffer || !binningBuffer || !imageBuffer) return fail(GIGS_ERR_INVALID, "null allocation callback");
+  if (!out_color || !out_opacity || !out_depth) return fail(GIGS_ERR_INVALID, "null output");
+  const size_t N = (size_t)width * height;
+  const size_t geom_bytes = gigs_required_geom(P), img_bytes = gigs_required_image(width, height);
+  const size_t geom_extra = 8 * (size_t)P * sizeof(float) + gigs::kAlign, img_extra = 14 * N * sizeof(float) + gigs::kAlign;
+  char* gb = geometryBuffer(geom_bytes + geom_extra, geom_user);
+  char* ib = imageBuffer(img_bytes + img_extra, image_user);
+  if (!gb || !ib) return fail(GIGS_ERR_ALLOC, "lite_forward: scratch allocation failed");
+  auto up = [](char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + gigs::kAlign - 1) & ~(uintptr_t)(gigs::kAlign - 1)); };
+  float* zeros = reinterpret_cast<float*>(up(gb + geom_bytes));   // normal 3P | albedo 3P | roughness P | metallic P
+  float* spare = reinterpret_cast<float*>(up(ib + img_bytes));    // normal 3N | normal_view 3N | pos 3N | albedo 3N | roughness N | metallic N
+  gigs::launch_zero_words(reinterpret_cast<uint32_t*>(zeros), 8 * (size_t)P, (hipStream_t)stream);
+  LiteChunk gc{gb, geom_bytes}, ic{ib, img_bytes};
+  return gigs_forward(lite_chunk_alloc, &gc, binningBuffer, binning_user, lite_chunk_alloc, &ic, P, D, M, background, width, height,
+                      means3D, shs, colors_precomp, opacities, zeros, zeros + 3 * (size_t)P, zeros + 6 * (size_t)P,
+                      zeros + 7 * (size_t)P, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                      tan_fovx, tan_fovy, prefiltered, argmax_depth, 0, out_color, out_opacity, out_depth, spare, spare + 3 * N,
+                      spare + 6 * N, spare + 9 * N, spare + 12 * N, spare + 13 * N, radii, debug, stream);
+}
+
 int gigs_backward(int P, int D, int M, int R, const float* background, int width, int height,
                   const float* means3D, const float* shs, const float* colors_precomp,
                   const float* normal, const float* albedo, const float* roughness,
@@ -562,6 +603,25 @@ int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, 
              const float* metallic, const float* F0, float* color, float* abd, void* stream) {
   return gigs_ssr_ex(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, normal_view, pos, rgb,
                      albedo, roughness, metallic, F0, color, abd, nullptr, stream);
+}
+
+// Gaussian_SSR's backward as the reference's autograd function computes it (R/diff_gaussian_rasterization/__init__.py:671-693):
+// grad_albedo = grad_color * abd, nothing to roughness / metallic / F0 (the CUDA `SSR_BACKWARD` the reference also exports is
+// unreachable -- its call is commented out -- and is not what this entry restates).
+namespace gigs {
+__global__ void __launch_bounds__(256) ssr_backward_kernel(size_t n, const float* __restrict__ g, const float* __restrict__ abd,
+                                                           float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = g[i] * abd[i];
+}
+}  // namespace gigs
+int gigs_ssr_backward(int width, int height, const float* grad_color, const float* abd, float* grad_albedo, void* stream) {
+  if (width <= 0 || height <= 0 || !grad_color || !abd || !grad_albedo) return fail(GIGS_ERR_INVALID, "bad argument");
+  const size_t n = 3 * (size_t)width * height;
+  hipLaunchKernelGGL(gigs::ssr_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, grad_color,
+                     abd, grad_albedo);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int gigs_median3x3(int channels, int height, int width, const float* in, float* out, void* stream) {

@@ -455,17 +455,39 @@ def _lite_rasterize_gaussians(background, means3D, colors, opacity, scales, rota
                               degree, prefiltered, argmax_depth):
     """_C.lite_rasterize_gaussians: colour / opacity / depth only "for baking" (R/rasterize_points.cu:39-127,
     liteRenderCUDA forward.cu:279-418) -> (rendered, out_color, out_opacity, radii, out_depth).  The lite kernel
-    composites exactly like the full one (same tests, same depth = view-space z), so this runs the full forward
-    with zero material attributes and returns the three planes; the reference never calls it from Python."""
+    composites exactly like the full one (same tests, same depth = view-space z): gigs_lite_forward runs the full
+    forward over zero material attributes and returns the three planes; the reference never calls it from Python."""
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _need_gpu(means3D, "means3D")
-    P = int(means3D.size(0))
-    z = lambda c: torch.zeros((P, c), dtype=torch.float32, device=means3D.device)  # noqa: E731
-    res = _rasterize_gaussians(background, means3D, colors, opacity, z(3), z(3), z(1), z(1), scales, rotations,
-                               cov3D_precomp, sh, campos, viewmatrix, projmatrix, scale_modifier, tan_fovx, tan_fovy,
-                               image_height, image_width, degree, prefiltered, argmax_depth, False, False)
-    rendered, out_color, radii, out_opacity, out_depth = res[0], res[1], res[2], res[6], res[7]
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    zero = P == 0
+    mk = torch.zeros if zero else torch.empty
+    out_color = mk((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_opacity = mk((1, H, W), dtype=torch.float32, device=dev)
+    out_depth = mk((1, H, W), dtype=torch.float32, device=dev)
+    radii = mk((P,), dtype=torch.int32, device=dev)
+    rendered = 0
+    if not zero:
+        M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
+        geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+        keep = []
+
+        def p(t, name):
+            ptr, k = _fptr(t, name)
+            keep.append(k)
+            return ptr
+
+        with torch.cuda.device(dev):
+            rendered = _lib.gigs_lite_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, p(background, "background"), W, H,
+                p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors"), p(opacity, "opacity"), p(scales, "scales"),
+                float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"), p(viewmatrix, "viewmatrix"),
+                p(projmatrix, "projmatrix"), p(campos, "campos"), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                int(bool(argmax_depth)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(), radii.data_ptr(),
+                0, _stream())
+        gigs_lib.check(rendered, "lite_rasterize_gaussians")
     return rendered, out_color, out_opacity, radii, out_depth
 
 
@@ -715,8 +737,12 @@ class _SSR(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, grad_abd=None):
         roughness, metallic, abd = ctx.saved_tensors
-        # closed form, R/…/__init__.py:671-673
-        grad_albedo = grad_out_color * abd
+        # closed form, R/…/__init__.py:671-673 (gigs_ssr_backward)
+        g = grad_out_color.contiguous().float()
+        grad_albedo = torch.empty_like(abd)
+        with torch.cuda.device(abd.device):
+            gigs_lib.check(_lib.gigs_ssr_backward(int(abd.shape[2]), int(abd.shape[1]), g.data_ptr(), abd.data_ptr(),
+                                                  grad_albedo.data_ptr(), _stream()), "SSR backward")
         grad_roughness = torch.zeros_like(roughness)
         grad_metallic = torch.zeros_like(metallic)
         return (None, None, None, None, None, None, None, None, None, None, None, None, None,

@@ -41,6 +41,14 @@ SIGNATURES = {
                            _f, _f, _f, _f, _f, _f, _f,       # 7 incoming grads
                            _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,  # 14 outputs
                            _i, C.c_void_p]),
+    "gigs_lite_forward": (_i, [ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
+                               _i, _i, _i, _f, _i, _i,            # P D M background width height
+                               _f, _f, _f, _f,                    # means3D shs colors opacities
+                               _f, _fl, _f, _f,                   # scales scale_modifier rotations cov3D
+                               _f, _f, _f, _fl, _fl,              # view proj campos tanfovx tanfovy
+                               _i, _i,                            # prefiltered argmax_depth
+                               _f, _f, _f, _f, _i, C.c_void_p]),  # color opacity depth radii debug stream
+    "gigs_ssr_backward": (_i, [_i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_mark_visible": (_i, [_i, _f, _f, _f, _f, C.c_void_p]),
     "gigs_depth_to_normal": (_i, [_i, _i, _fl, _fl, _f, _f, _f, _f, C.c_void_p]),
     "gigs_derive_normal": (_i, [_i, _i, C.c_float, C.c_float, _f, _f, C.c_float, C.c_float, C.c_float, _f, _f, C.c_void_p]),

@@ -452,6 +452,23 @@ int gigs_selftest_div2(int n, const float* nx, const float* ny, const float* d, 
  * pixel or decide "inside the image" differently for some image side < 2^15.  Expected: 0. */
 int gigs_selftest_round(unsigned long long* mismatches, void* stream);
 
+/* Rasterizer::lite_forward (R/cuda_rasterizer/rasterizer.h:90-117; bound as _C.lite_rasterize_gaussians,
+ * R/rasterize_points.cu:39-127): colour [3,H,W], opacity [1,H,W] and depth [1,H,W] only, "for baking".  Composites exactly
+ * like gigs_forward; the geometry / image callbacks are asked for somewhat more than gigs_required_geom / _image
+ * (zero material attributes and the planes that are not returned live there).  Returns num_rendered. */
+int gigs_lite_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer, void* binning_user,
+                      gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M, const float* background, int width,
+                      int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                      int prefiltered, int argmax_depth, float* out_color, float* out_opacity, float* out_depth, int* radii,
+                      int debug, void* stream);
+
+/* The backward of Gaussian_SSR as the reference's autograd function defines it (R/diff_gaussian_rasterization/__init__.py:
+ * 671-693): grad_albedo [3,H,W] = grad_color * abd; roughness / metallic / F0 receive nothing.  (The reference also exports
+ * a CUDA SSR_BACKWARD whose only call is commented out; this entry is the live arithmetic, not that kernel.) */
+int gigs_ssr_backward(int width, int height, const float* grad_color, const float* abd, float* grad_albedo, void* stream);
+
 /* Optional scheduling hook: a hipEvent_t (caller-owned, NULL = none) that gigs_forward records on its stream right
  * before it launches the alpha-blend kernel, so that a caller can start independent work on another stream next to
  * that kernel (it is latency-bound and leaves most CUs idle) rather than next to the bandwidth-bound binning kernels.
