@@ -97,21 +97,32 @@ _PMC_NAMES = {"ssao": "ssao_kernel", "ssr": "ssr_kernel", "blend_fwd": "blend_fw
               "preprocess_bwd": "preprocess_bwd_kernel", "sort": "bin_sort_kernel"}
 
 
-def _pmc_file():
+_PMC_CONFIG = "c2"  # set by run(): the committed PMC summary of THIS configuration is the one quoted
+
+
+def _pmc_path():
+    """Newest committed PMC summary (profiles/rNN/pmc_summary*.json, by name order), preferring the one collected on this
+    configuration (…_c2.json / …_c4.json; c3 / c5 run c2's / c4's kernels on the same sizes)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")))
-    return os.path.relpath(files[-1], ROOT) if files else None
+    want = {"c3": "c2", "c5": "c4"}.get(_PMC_CONFIG, _PMC_CONFIG)
+    mine = [f for f in files if f.endswith("_%s.json" % want)]
+    return (mine or files or [None])[-1]
+
+
+def _pmc_file():
+    f = _pmc_path()
+    return os.path.relpath(f, ROOT) if f else None
 
 
 def _pmc_entry(stage: str):
     """Counters of `stage`'s kernel from the newest committed summary (profiles/rNN/pmc_summary*.json, by name order);
     template instantiations of one kernel are matched by prefix and the one with the most launches is taken."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.json")))
-    if not files or stage not in _PMC_NAMES:
+    f = _pmc_path()
+    if f is None or stage not in _PMC_NAMES:
         return {}
     try:
-        d = json.load(open(files[-1]))
+        d = json.load(open(f))
     except Exception:  # noqa: BLE001
         return {}
     cands = [v for k, v in d.items() if k.startswith(_PMC_NAMES[stage])]
@@ -333,6 +344,8 @@ def main(argv=None):
 
 
 def run(args):
+    global _PMC_CONFIG
+    _PMC_CONFIG = args.config
     _imports()
     W, H, cname = args.W, args.H, args.cname
     world = int(os.environ.get("WORLD_SIZE", "1"))
