@@ -103,6 +103,37 @@ class Stage2Trainer:
     def iteration(self, cam: Dict, gt_image: torch.Tensor, view_dirs: torch.Tensor) -> Dict[str, torch.Tensor]:
         return self.stepper(cam, self.raw, gt_image, view_dirs)
 
+    # the tensors a stage-2 iteration's loss reaches (train.py:330-420): everything else gets exact zeros
+    STAGE2_TRAINABLE = ("albedo", "roughness", "metallic", "cubemap")
+
+    def grad_buffers(self, names=STAGE2_TRAINABLE) -> Dict[str, torch.Tensor]:
+        """The gradient tensors the NEXT update will read, by name ("cubemap" = light.base): the whole-step graphs' static
+        buffers once they are captured (the captured Adam launch reads exactly these addresses), `.grad` otherwise.  Valid
+        inside `before_update` (after the backward, before the update)."""
+        leaves = dict(self.raw, cubemap=self.light.base)
+        wsg = self.stepper.whole
+        if wsg is not None and wsg.gf is not None:
+            params = wsg._params(self.raw)
+            by_id = {id(p): g for p, g in zip(params, wsg.grads)}
+            return {n: by_id[id(leaves[n])] for n in names if by_id.get(id(leaves[n])) is not None}
+        return {n: leaves[n].grad for n in names if leaves[n].grad is not None}
+
+    def data_parallel(self, group=None, names=STAGE2_TRAINABLE, average: bool = False) -> None:
+        """View-parallel training: every rank runs `iteration` on its own view; between the backward and the
+        update the gradients of `names` are summed over the ranks IN PLACE -- in the buffers the (captured) Adam launch
+        reads -- so identically initialised ranks take identical updates.  A stage-2 iteration reaches only the default
+        `names`; pass every raw name for stage-1 style losses.  (bench.py's metric step, whose rasterizer inputs ARE the
+        leaves, uses dp.GradSlab + grad_sink instead: one flat collective.)"""
+        import torch.distributed as dist
+
+        def hook():
+            world = dist.get_world_size(group)
+            for t in self.grad_buffers(names).values():
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                if average:
+                    t.div_(world)
+        self.stepper.before_update = hook
+
 
 def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_image, steps=40, warmup=5) -> Dict:
     """bench.py's `iteration` field: complete iterations/s of the C-config workload on the fast path (three hipGraphs)."""
