@@ -172,8 +172,13 @@ class CapturedAdam:
 
     def key(self):
         """What a capture depends on: the tensors' addresses (a replaced parameter / moment needs a re-capture)."""
-        return tuple((p.data_ptr(), gr.data_ptr(), o.state[p]["exp_avg"].data_ptr(), o.state[p]["exp_avg_sq"].data_ptr())
-                     for o, _, p, gr in self.entries)
+        out = []
+        for o, _, p, gr in self.entries:
+            st = o.state.get(p)
+            if not st:  # the optimizer no longer holds this tensor (densification replaced it): the capture is stale
+                return ("stale", id(self))
+            out.append((p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
+        return tuple(out)
 
     def launch(self) -> None:
         with torch.cuda.device(self.device):

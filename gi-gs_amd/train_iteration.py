@@ -103,6 +103,18 @@ class Stage2Trainer:
     def iteration(self, cam: Dict, gt_image: torch.Tensor, view_dirs: torch.Tensor) -> Dict[str, torch.Tensor]:
         return self.stepper(cam, self.raw, gt_image, view_dirs)
 
+    def replace_parameters(self, raw: Dict[str, torch.Tensor]) -> None:
+        """After densification / pruning / opacity reset (densify.py on `self.optimizer`, as the reference's
+        GaussianModel methods do, scene/gaussian_model.py:580-931): the optimizer's groups hold NEW tensor objects and
+        moments; hand the new dictionary over.  The next iteration re-captures the graphs (once) around them."""
+        missing = [k for k in RAW_KEYS if k not in raw]
+        if missing:
+            raise KeyError("replace_parameters: missing " + ", ".join(missing))
+        held = {id(g["params"][0]) for g in self.optimizer.param_groups}
+        if any(id(raw[k]) not in held for k in RAW_KEYS):
+            raise ValueError("replace_parameters: the tensors must be the ones the optimizer's groups hold")
+        self.raw = {k: raw[k] for k in RAW_KEYS}
+
     # the tensors a stage-2 iteration's loss reaches (train.py:330-420; SURVEY App. D): everything else gets exact zeros
     STAGE2_TRAINABLE = ("albedo", "roughness", "metallic", "cubemap")
 

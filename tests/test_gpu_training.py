@@ -194,3 +194,64 @@ def test_stage2_optimisation_recovers_materials_and_light():
     assert float(light.base.min()) >= 0.0                      # cubemap.clamp_(min=0)
     assert last < 0.5 * first, (first, last)
     assert psnr1 > psnr0 + 4.0, (psnr0, psnr1)
+
+
+def test_stage2_trainer_follows_pruning_and_learning_rate_changes():
+    """The training loop's other moving parts around the captured iteration: a prune in the middle (densify.prune_points
+    replaces every parameter tensor and its Adam moments, as the reference's prune_points does) -> one re-capture, the moments
+    of the surviving rows carried over, training continues; a learning-rate change (update_learning_rate) reaches the
+    captured Adam launch without a re-capture."""
+    import densify
+    import pbr
+    import pipeline
+    import scenes
+    import train_iteration as ti
+    dev = torch.device("cuda:0")
+    H = W = 96
+    sc = scenes.surface_scene(P=5000, sh_degree=1, seed=8, scale_mu=0.035)
+    cams = [scenes.orbit_camera(i, 4, W, H, radius=3.5) for i in range(4)]
+    cams = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    gi = scenes.GI_DEFAULTS
+    lut = pbr.get_brdf_lut().to(dev)
+    rays = pipeline.canonical_rays(cams[0], dev)
+    vds = [pipeline.view_dirs_for(c, rays, dev) for c in cams]
+    torch.manual_seed(1)
+    gts = [torch.rand(3, H, W, device=dev) * 0.6 for _ in cams]
+    light = pbr.CubemapLight(base_res=64, device=dev)
+    raw = ti.raw_from_scene(sc, dev)
+    tr = ti.Stage2Trainer(raw, light, lut, gi, 1, graphs=True)
+    for it in range(4):
+        tr.iteration(cams[it % 4], gts[it % 4], vds[it % 4])
+    torch.cuda.synchronize()
+    assert tr.stepper.whole.recaptures == 1
+    # (1) learning rate: zero for albedo from now on -> albedo stops moving, no re-capture
+    before = raw["albedo"].detach().clone()
+    m_before = tr.optimizer.state[raw["albedo"]]["exp_avg"].clone()
+    tr.set_lr("albedo", 0.0)
+    tr.iteration(cams[0], gts[0], vds[0])
+    torch.cuda.synchronize()
+    assert torch.equal(raw["albedo"].detach(), before) and tr.stepper.whole.recaptures == 1
+    assert not torch.equal(tr.optimizer.state[raw["albedo"]]["exp_avg"], m_before)  # the moments still follow the gradients
+    tr.set_lr("albedo", 0.05)
+    # (2) prune every third Gaussian
+    P0 = raw["xyz"].shape[0]
+    mask = torch.zeros(P0, dtype=torch.bool, device=dev)
+    mask[::3] = True
+    keep_rows = raw["roughness"].detach()[~mask].clone()
+    keep_m = tr.optimizer.state[raw["roughness"]]["exp_avg"][~mask].clone()
+    steps_before = int(tr.optimizer.state[raw["roughness"]]["step"])
+    new, _ = densify.prune_points(tr.optimizer, densify.DensifyState(P0, dev), mask)
+    tr.replace_parameters(dict(new))
+    P1 = tr.raw["xyz"].shape[0]
+    assert P1 == P0 - int(mask.sum()) and torch.equal(tr.raw["roughness"].detach(), keep_rows)
+    assert torch.equal(tr.optimizer.state[tr.raw["roughness"]]["exp_avg"], keep_m)
+    losses_ = []
+    for it in range(6):
+        losses_.append(float(tr.iteration(cams[it % 4], gts[it % 4], vds[it % 4])["loss"]))
+    torch.cuda.synchronize()
+    assert tr.stepper.whole.recaptures == 2                      # one re-capture for the new tensors, then replays
+    assert int(tr.optimizer.state[tr.raw["roughness"]]["step"]) == steps_before + 6
+    assert all(np.isfinite(losses_)) and all(torch.isfinite(p).all() for p in tr.raw.values())
+    assert not torch.equal(tr.raw["roughness"].detach(), keep_rows)  # the pruned model keeps training
+    with pytest.raises(ValueError):
+        tr.replace_parameters({k: v.detach().clone() for k, v in tr.raw.items()})  # not the optimizer's tensors
