@@ -171,6 +171,17 @@ def test_stage2_optimisation_recovers_materials_and_light():
     for k in ("xyz", "scaling", "rotation", "opacity", "f_dc", "normal"):  # stage 2 reaches none of these (exact zeros)
         assert torch.equal(traj[True][1][k], truth[k]), k
     assert int(traj[True][3].optimizer.state[traj[True][3].raw["albedo"]]["step"]) == 5
+    # ... and the same iteration written as the reference writes it (torch op chains for the getters and the glue between
+    # the operators, torch.optim.Adam): the op-by-op formulation is the checker of the fused one
+    raw, light = perturbed()
+    tr = ti.Stage2Trainer(raw, light, lut, gi, deg, glue="torch")
+    losses_t = [float(tr.iteration(cams[it % n_views], targets[it % n_views], vds[it % n_views])["loss"]) for it in range(5)]
+    torch.cuda.synchronize()
+    for a, b in zip(traj[False][0], losses_t):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (traj[False][0], losses_t)
+    for k in ("albedo", "roughness", "metallic"):
+        d = (traj[False][1][k] - raw[k].detach()).abs().max().item()
+        assert d <= 5e-3, ("torch glue", k, d)
 
     # (2) the optimisation itself, from the graphs
     raw, light = perturbed()
@@ -188,7 +199,7 @@ def test_stage2_optimisation_recovers_materials_and_light():
     torch.cuda.synchronize()
     psnr1 = psnr_of(raw, light)
     print(f"\nstage-2 miniature: loss {first:.4f} -> {last:.4f}, PSNR {psnr0:.2f} -> {psnr1:.2f} dB, "
-          f"light mean {float(light.base.mean()):.3f} (truth {float(truth_light.base.mean()):.3f})")
+          f"light mean {float(light.base.detach().mean()):.3f} (truth {float(truth_light.base.detach().mean()):.3f})")
     assert tr.stepper.whole is not None and tr.stepper.whole.recaptures == 1
     assert all(torch.isfinite(p).all() for p in raw.values()) and torch.isfinite(light.base).all()
     assert float(light.base.min()) >= 0.0                      # cubemap.clamp_(min=0)
