@@ -661,6 +661,7 @@ def secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n
                     chain runs, which the stage-2 pattern of the headline step skips); no shade / SSR
     iteration       a COMPLETE stage-2 training iteration of train.py:247-523: activations of the raw parameter groups,
                     the headline step, BRDF TV + lamb + envmap TV, backward, Adam on Gaussians and light, clamp
+    iteration_stage1  a complete stage-1 iteration (train.py:266-331): L1 + D-SSIM + normal losses, full backward, Adam
     """
     out = {}
     leaves = list(g.values()) + list(light.parameters())
@@ -697,6 +698,8 @@ def secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n
         import train_iteration
         out["iteration"] = train_iteration.bench_iteration(sc, light, brdf_lut, gi, args.sh_degree, cams_t, view_dirs, gt_image,
                                                            steps=max(20, args.steps), warmup=5)
+        out["iteration_stage1"] = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image,
+                                                                         steps=max(20, args.steps), warmup=5)
     except ImportError:
         pass
     return out

@@ -391,7 +391,8 @@ class WholeStepGraph:
     CAM_TENSORS = ("viewmatrix", "projmatrix", "campos")
 
     def _params(self, g):
-        return [g[k] for k in g] + [p for p in self.owner.light.parameters()]
+        light = getattr(self.owner, "light", None)
+        return [g[k] for k in g] + ([p for p in light.parameters()] if light is not None else [])
 
     def _key(self, g):
         import diff_gaussian_rasterization as dgr
@@ -415,8 +416,7 @@ class WholeStepGraph:
                 raise DenseScene(f"{probe} instances over {tiles} tiles")
             self.capacity = max(65536, -(-2 * probe // 65536) * 65536)
         self.bin = AsyncBinning(self.capacity, self.dev)
-        self.inner = Stage2Step(o.light, o.brdf_lut, o.gi, o.sh_degree, graphs=False, fused=True, regularizer=o.regularizer,
-                                **o.flags)
+        self.inner = o._make_inner()  # the eager step that is captured: returns its attached loss instead of differentiating
         self.inner._defer_backward = True
         self.inner._static_bg = bg
         self.inner._static_m2d = torch.zeros_like(ga["means3D"], requires_grad=True)
@@ -953,6 +953,14 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     return res
 
 
+def _make_inner(self):
+    return Stage2Step(self.light, self.brdf_lut, self.gi, self.sh_degree, graphs=False, fused=True, regularizer=self.regularizer,
+                      **self.flags)
+
+
+Stage2Step._make_inner = _make_inner
+
+
 def _leaves(self, g):
     out, seen = [], set()
     for t in list(g.values()) + list(self.light.parameters()):
@@ -968,6 +976,84 @@ Stage2Step._eager_async = _eager_async
 Stage2Step._graphed_step = _graphed_step
 Stage2Step._fused_begin = _fused_begin
 Stage2Step._fused_step = _fused_step
+
+
+class _Stage1Inner:
+    """One stage-1 iteration of train.py (:266-331) up to the loss: render -> fused G-buffer post-processing ->
+    0.8 L1 + 0.2 D-SSIM + masked normal L1 + normal TV (losses.stage1_loss: one autograd node)."""
+
+    def __init__(self, gi: Dict, sh_degree: int, lambda_dssim: float, normal_loss_weight: float, normal_tv_weight: float):
+        self.gi, self.sh_degree = gi, sh_degree
+        self.w = (float(lambda_dssim), float(normal_loss_weight), float(normal_tv_weight))
+        self._defer_backward = False
+        self._static_bg = self._static_m2d = None
+
+    def __call__(self, cam, g, gt_image, view_dirs=None):
+        import losses
+        dev = g["means3D"].device
+        bg = self._static_bg if self._static_bg is not None else torch.zeros(3, device=dev)
+        out, screenspace_points, st = rasterize(cam, g, self.sh_degree, bg, self.gi, means2D=self._static_m2d)
+        (image, radii, _, _, normal_map_from_depth, normal_map, _, _, _, _, out_normal_view, _) = out
+        nfd, nfd_mask, normals_view, _, _ = gbuffer_post_fused(normal_map_from_depth, normal_map, out_normal_view, st.viewmatrix)
+        loss, ll1, normal_loss = losses.stage1_loss(image, gt_image, normals_view, nfd, nfd_mask, *self.w)
+        res = dict(loss=loss.detach(), Ll1=ll1.detach(), normal_loss=normal_loss.detach(), render=image.detach(),
+                   viewspace_points=screenspace_points, radii=radii)
+        if self._defer_backward:
+            res["_loss"] = loss
+            return res
+        loss.backward()
+        return res
+
+
+class Stage1Step:
+    """One stage-1 iteration (`iteration <= pbr_iteration`, train.py:266-331, 517-520) with Stage2Step's interface and
+    formulations: eager, or -- graphs=True -- the whole iteration from hipGraphs (WholeStepGraph: forward, backward and,
+    with `optimizers`, the update), the rasterizer under asynchronous binning.  No light, no shade: the loss reaches
+    colour and normals, i.e. every Gaussian group."""
+
+    light = None
+    regularizer = None
+    post_update = None
+
+    def __init__(self, gi: Dict, sh_degree: int, lambda_dssim: float = 0.2, normal_loss_weight: float = 1.0,
+                 normal_tv_weight: float = 1.0, graphs: bool = False, prepare=None, optimizers=None, before_update=None):
+        self.gi, self.sh_degree, self.graphs = gi, sh_degree, graphs
+        self.weights = (lambda_dssim, normal_loss_weight, normal_tv_weight)
+        self.prepare, self.optimizers, self.before_update = prepare, list(optimizers or []), before_update
+        self.whole, self._wholes = None, {}
+        self._eager = self._make_inner()
+
+    def _make_inner(self):
+        return _Stage1Inner(self.gi, self.sh_degree, *self.weights)
+
+    def __call__(self, cam: Dict, g: Dict[str, torch.Tensor], gt_image: torch.Tensor, view_dirs=None):
+        raw = g
+        if self.graphs and os.environ.get("GIGS_STEP_GRAPH", "1") == "1" and not getattr(self, "_dense", False):
+            try:
+                cfg = (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"]))
+                if self.whole is None or self.whole.cfg != cfg:
+                    self.whole = self._wholes.get(cfg)
+                    if self.whole is None and len(self._wholes) < 4:
+                        self.whole = self._wholes[cfg] = WholeStepGraph(self, cam, g)
+                if self.whole is not None:
+                    if getattr(self, "_no_vd", None) is None:
+                        self._no_vd = torch.zeros(1, device=gt_image.device)  # the graph's (unused) view_dirs input
+                    return self.whole(cam, raw, gt_image, view_dirs if view_dirs is not None else self._no_vd)
+            except DenseScene:
+                self._dense = True
+                self.whole = None
+                self._wholes.clear()
+        if self.prepare is not None:
+            g = self.prepare(raw)
+        res = self._eager(cam, g, gt_image)
+        if self.optimizers:
+            if self.before_update is not None:
+                self.before_update()
+            for o in self.optimizers:
+                o.step()
+            for leaf in raw.values():
+                leaf.grad = None
+        return res
 
 
 def stage2_step(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, gi: Dict, light, brdf_lut: torch.Tensor,

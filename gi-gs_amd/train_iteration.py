@@ -147,6 +147,55 @@ class Stage2Trainer:
         self.stepper.before_update = hook
 
 
+class Stage1Trainer:
+    """The same for stage 1 (`iteration <= pbr_iteration`, train.py:266-331, 517-520): activations -> rasterizer (+ in-op
+    filters + SSAO, computed as in the reference although stage 1 does not read it) -> fused G-buffer post-processing ->
+    0.8 L1 + 0.2 D-SSIM + masked normal L1 + normal TV -> backward -> Adam over the ten Gaussian groups; three hipGraphs
+    with graphs=True.  `gi` with start >= step (the README's --start 64) skips the march: same losses and gradients."""
+
+    def __init__(self, raw: Dict[str, torch.Tensor], gi: Dict, sh_degree: int, lrs: Optional[Dict[str, float]] = None,
+                 lambda_dssim: float = 0.2, normal_loss_weight: float = 1.0, normal_tv_weight: float = 1.0, graphs: bool = True,
+                 before_update=None):
+        self.raw = raw
+        lrs = dict(DEFAULT_LRS, **(lrs or {}))
+        self.optimizer = optim.FusedAdam([{"params": [raw[k]], "lr": lrs[k], "name": k} for k in RAW_KEYS], lr=0.0, eps=1e-15)
+        self.stepper = pipeline.Stage1Step(gi, sh_degree, lambda_dssim, normal_loss_weight, normal_tv_weight, graphs=graphs,
+                                           prepare=activations.activate, optimizers=[self.optimizer], before_update=before_update)
+
+    def set_lr(self, name: str, lr: float) -> None:
+        for group in self.optimizer.param_groups:
+            if group["name"] == name:
+                group["lr"] = lr
+
+    def iteration(self, cam: Dict, gt_image: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return self.stepper(cam, self.raw, gt_image)
+
+    def replace_parameters(self, raw: Dict[str, torch.Tensor]) -> None:
+        held = {id(g["params"][0]) for g in self.optimizer.param_groups}
+        if any(k not in raw or id(raw[k]) not in held for k in RAW_KEYS):
+            raise ValueError("replace_parameters: pass the tensors the optimizer's groups hold, under the reference's names")
+        self.raw = {k: raw[k] for k in RAW_KEYS}
+
+
+def bench_stage1_iteration(sc, gi, sh_degree, cams_t, gt_image, steps=40, warmup=5) -> Dict:
+    """bench.py's `iteration_stage1` field."""
+    raw = raw_from_scene(sc, gt_image.device)
+    tr = Stage1Trainer(raw, gi, sh_degree, graphs=True)
+    n = len(cams_t)
+    for i in range(warmup):
+        tr.iteration(cams_t[i % n], gt_image)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = tr.iteration(cams_t[(warmup + i) % n], gt_image)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"iterations_per_s": round(1.0 / dt, 2), "ms_per_iteration": round(1e3 * dt, 3), "steps": steps, "final_loss": float(out["loss"]),
+            "what": "activations + rasterizer + in-op filters + SSAO + G-buffer post-processing + L1 + D-SSIM + masked normal L1 + "
+                    "normal TV + backward (colour and normal gradients: the blend backward's full chain) + Adam (train.py:266-331, 517-520)",
+            "formulation": "3 hipGraphs (fwd, bwd, update)" if tr.stepper.whole is not None else "eager"}
+
+
 def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_image, steps=40, warmup=5) -> Dict:
     """bench.py's `iteration` field: complete iterations/s of the C-config workload on the fast path (three hipGraphs)."""
     dev = gt_image.device

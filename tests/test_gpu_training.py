@@ -266,3 +266,36 @@ def test_stage2_trainer_follows_pruning_and_learning_rate_changes():
     assert not torch.equal(tr.raw["roughness"].detach(), keep_rows)  # the pruned model keeps training
     with pytest.raises(ValueError):
         tr.replace_parameters({k: v.detach().clone() for k, v in tr.raw.items()})  # not the optimizer's tensors
+
+
+def test_stage1_iterations_from_the_graphs_follow_the_eager_trajectory():
+    """train_iteration.Stage1Trainer: the complete stage-1 iteration (activations, rasterizer + filters, L1 + D-SSIM + masked
+    normal L1 + normal TV, backward, FusedAdam) replayed from three hipGraphs takes the eager formulation's trajectory, and the
+    objective goes down."""
+    import scenes
+    import train_iteration as ti
+    dev = torch.device("cuda:0")
+    H = W = 96
+    sc = scenes.surface_scene(P=5000, sh_degree=1, seed=12, scale_mu=0.035)
+    cams = [scenes.orbit_camera(i, 4, W, H, radius=3.5) for i in range(4)]
+    cams = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    gi = dict(scenes.GI_DEFAULTS, start=16)  # empty march: stage 1 does not read the occlusion
+    torch.manual_seed(2)
+    gts = [torch.rand(3, H, W, device=dev) * 0.7 for _ in cams]
+    runs = {}
+    for graphs in (False, True):
+        raw = ti.raw_from_scene(sc, dev)
+        tr = ti.Stage1Trainer(raw, gi, 1, graphs=graphs)
+        losses_ = [float(tr.iteration(cams[it % 4], gts[it % 4])["loss"]) for it in range(12)]
+        torch.cuda.synchronize()
+        assert all(p.grad is None for p in raw.values())
+        runs[graphs] = (losses_, {k: v.detach().clone() for k, v in raw.items()}, tr)
+    assert runs[True][2].stepper.whole is not None and runs[True][2].stepper.whole.go is not None
+    assert runs[True][2].stepper.whole.recaptures == 1
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert abs(a - b) <= 5e-5 * max(1.0, abs(a)), (runs[False][0], runs[True][0])
+    for k, lim in (("f_dc", 5e-4), ("opacity", 5e-3), ("xyz", 5e-5), ("normal", 5e-3), ("scaling", 1e-3)):
+        d = (runs[False][1][k] - runs[True][1][k]).abs().max().item()
+        assert d <= lim, (k, d)
+    first, last = np.mean(runs[True][0][:4]), np.mean(runs[True][0][-4:])
+    assert last < first, (first, last)
