@@ -173,6 +173,7 @@ struct GiParams {
   float inv_step;  // exact 1/step when step is a power of two
   int nrays;
   int tile_log2w;  // the 64 pixels of a workgroup form a (1 << tile_log2w) x (64 >> tile_log2w) rectangle
+  int ray_interleave;  // fast marches: wave w takes ray pairs w, w + 4, ... instead of the w-th quarter of the ray set
   int cert_shift;      // certification blocks are (1 << cert_shift)^2 pixels; 0 = no certification table
   int cert_w, cert_h;  // blocks per row / column of the image; the table is (cert_w + 1) x (cert_h + 1): last column / row = border
   float cert_d0;       // certification needs den > cert_d0 (CertK::d0)
@@ -932,8 +933,13 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
           const float inv_scale = kCert ? __uint_as_float((127u - (unsigned)p.cert_shift) << 23) : 1.0f;  // 2^-shift
           const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a, inv_scale);
           const CertPix cp = make_cert(p, c, inv_scale);
-          for (int r = r0; r < r1; r += 2) {
-            const int rb = min(r + 1, r1 - 1);  // an odd chunk marches its last ray twice and counts it once
+          // the four waves of a workgroup share its 64 pixels and split the ray set: contiguous quarters (a quarter of the
+          // azimuths each), or interleaved pairs (every wave sees every direction: equal work per wave -- the workgroup
+          // holds its slots until its slowest wave is done)
+          const int rs = p.ray_interleave ? 2 * wave : r0, re = p.ray_interleave ? p.nrays : r1;
+          const int rstep = p.ray_interleave ? 2 * kGiWaves : 2;
+          for (int r = rs; r < re; r += rstep) {
+            const int rb = min(r + 1, re - 1);  // an odd chunk marches its last ray twice and counts it once
             f32x2 Bxy[2], Bz2;
             float bz0, bz1;
             fast_ray<kMode>(p, tbn, ft, a, rays[2 * r], Bxy[0], bz0);
@@ -1029,8 +1035,10 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
         const float inv_scale = kCert ? __uint_as_float((127u - (unsigned)p.cert_shift) << 23) : 1.0f;  // 2^-shift
         const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a, inv_scale);
         const CertPix cp = make_cert(p, c, inv_scale);
-        for (int r = r0; r < r1; r += 2) {
-          const int rb = min(r + 1, r1 - 1);
+        const int rs = p.ray_interleave ? 2 * wave : r0, re = p.ray_interleave ? p.nrays : r1;
+        const int rstep = p.ray_interleave ? 2 * kGiWaves : 2;
+        for (int r = rs; r < re; r += rstep) {
+          const int rb = min(r + 1, re - 1);
           const float4 ra0 = rays[2 * r], ra1 = rays[2 * rb];
           f32x2 Bxy[2], Bz2;
           float bz0, bz1;
@@ -1134,6 +1142,8 @@ static GiParams make_params(int W, int H, float fx, float fy, float radius, floa
   // GIGS_GI_TILE_LOG2W: tuning knob for the pixel rectangle of a workgroup (3 = 8x8 ... 6 = 64x1)
   const char* e = getenv("GIGS_GI_TILE_LOG2W");
   p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
+  const char* il = getenv("GIGS_GI_INTERLEAVE");
+  p.ray_interleave = (il && il[0] == '0') ? 0 : 1;  // measured at C2: SSAO 0.94 -> 0.89, SSR 0.93 -> 0.90 ms (GIGS_GI_INTERLEAVE=0: quarters)
   return p;
 }
 // Certification table, (bw + 1) x (bh + 1) entries.  Per (1 << shift)^2 block of the z plane: the minimum over its non-zero
