@@ -700,6 +700,9 @@ def secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n
                                                            steps=max(20, args.steps), warmup=5)
         out["iteration_stage1"] = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image,
                                                                          steps=max(20, args.steps), warmup=5)
+        lean = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image, steps=max(20, args.steps),
+                                                      warmup=5, compute_occlusion=False)
+        out["iteration_stage1"]["without_the_unused_ssao_march"] = {k: lean[k] for k in ("iterations_per_s", "ms_per_iteration")}
     except ImportError:
         pass
     return out

@@ -155,8 +155,14 @@ class Stage1Trainer:
 
     def __init__(self, raw: Dict[str, torch.Tensor], gi: Dict, sh_degree: int, lrs: Optional[Dict[str, float]] = None,
                  lambda_dssim: float = 0.2, normal_loss_weight: float = 1.0, normal_tv_weight: float = 1.0, graphs: bool = True,
-                 before_update=None):
+                 before_update=None, compute_occlusion: bool = True):
+        """compute_occlusion=False: the operator's SSAO march is switched off for these iterations (start = step in the raster
+        settings, what the README's --start 64 does): stage 1 neither reads occlusion_map nor differentiates through it, so
+        losses, gradients and updates are unchanged (tested) while the iteration loses its largest kernel.  The default keeps
+        the reference's work."""
         self.raw = raw
+        if not compute_occlusion:
+            gi = dict(gi, start=gi["step"])
         lrs = dict(DEFAULT_LRS, **(lrs or {}))
         self.optimizer = optim.FusedAdam([{"params": [raw[k]], "lr": lrs[k], "name": k} for k in RAW_KEYS], lr=0.0, eps=1e-15)
         self.stepper = pipeline.Stage1Step(gi, sh_degree, lambda_dssim, normal_loss_weight, normal_tv_weight, graphs=graphs,
@@ -177,10 +183,10 @@ class Stage1Trainer:
         self.raw = {k: raw[k] for k in RAW_KEYS}
 
 
-def bench_stage1_iteration(sc, gi, sh_degree, cams_t, gt_image, steps=40, warmup=5) -> Dict:
+def bench_stage1_iteration(sc, gi, sh_degree, cams_t, gt_image, steps=40, warmup=5, compute_occlusion=True) -> Dict:
     """bench.py's `iteration_stage1` field."""
     raw = raw_from_scene(sc, gt_image.device)
-    tr = Stage1Trainer(raw, gi, sh_degree, graphs=True)
+    tr = Stage1Trainer(raw, gi, sh_degree, graphs=True, compute_occlusion=compute_occlusion)
     n = len(cams_t)
     for i in range(warmup):
         tr.iteration(cams_t[i % n], gt_image)
