@@ -234,13 +234,14 @@ bin_prefix_groups_kernel(int groups, int T, uint32_t* __restrict__ bin_hist, uin
   const int tl = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + tl;
   const int per = (groups + 15) / 16, g0 = min(groups, q * per), g1 = min(groups, g0 + per);
-  uint32_t c[16];
+  constexpr int kPer = (kBinGroups + 15) / 16;  // chunks per part (per <= kPer)
+  uint32_t c[kPer];
   uint32_t run = 0;
   if (t < T) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) c[k] = (g0 + k < g1) ? bin_hist[(size_t)(g0 + k) * T + t] : 0u;  // per <= 16 (kBinGroups = 256)
+    for (int k = 0; k < kPer; k++) c[k] = (g0 + k < g1) ? bin_hist[(size_t)(g0 + k) * T + t] : 0u;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { const uint32_t v = c[k]; c[k] = run; run += v; }
+    for (int k = 0; k < kPer; k++) { const uint32_t v = c[k]; c[k] = run; run += v; }
   }
   s_q[q][tl] = run;
   __syncthreads();
@@ -248,7 +249,7 @@ bin_prefix_groups_kernel(int groups, int T, uint32_t* __restrict__ bin_hist, uin
   for (int k = 0; k < q; k++) add += s_q[k][tl];
   if (t < T) {
 #pragma unroll
-    for (int k = 0; k < 16; k++)
+    for (int k = 0; k < kPer; k++)
       if (g0 + k < g1) bin_hist[(size_t)(g0 + k) * T + t] = c[k] + add;
     if (q == 15) totals[t] = add + run;
   }

@@ -173,7 +173,12 @@ struct GeomState {
 // Tile-bucketed binning (binning.hip): the Gaussians are cut into at most kBinGroups contiguous chunks, one workgroup
 // each; bin_hist[g * T + t] holds first the number of instances chunk g contributes to tile t and then (in place)
 // their exclusive prefix over the chunks.
-constexpr int kBinGroups = 256;
+#ifndef GIGS_BIN_GROUPS
+// measured at C4 (3 M Gaussians, count / scatter in ms): 64 groups 0.52 / 1.32, 128: 0.27 / 0.79, 256: 0.14 / 0.51,
+// 512: 0.11 / 0.44, 1024: 0.11 / 0.45 -- the walks are bound by the parallelism in flight, two 1024-lane groups fill a CU
+#define GIGS_BIN_GROUPS 512
+#endif
+constexpr int kBinGroups = GIGS_BIN_GROUPS;
 constexpr int kBinMaxTiles = 16384;
 constexpr int kBucketMaxMeanList = 2500;  // mean instances per tile above which synchronous calls use the global radix sort  // the per-workgroup tile histogram lives in LDS (64 KB at this size)
 
