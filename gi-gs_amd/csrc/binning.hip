@@ -356,11 +356,28 @@ __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t
     const unsigned idx = threadIdx.x * kItems + i;
     k[i] = idx < n ? src[idx] : ~0ull;  // padding sorts to the end (all ones in every sorted bit)
   }
-  // The key is depth bits << idx_bits | index.  Radix passes are spent on the 32 DEPTH bits only (4 passes instead of the 7
+  // The key is depth bits << idx_bits | index.  Radix passes are spent on the DEPTH bits only (4 passes instead of the 7
   // that all 32 + idx_bits bits take); the sort is stable, so keys of equal depth come out adjacent, in their (arbitrary)
   // input order, and are put into index order by the fix-up below -- which finds nothing to do unless two Gaussians of a tile
-  // have bit-identical depths.
-  sorter().sort(k, storage, idx_bits, idx_bits + 32);
+  // have bit-identical depths.  Of the depth bits, only those that differ anywhere in THIS list are sorted: the depths of
+  // one tile -- let alone of one bucket of it -- share their sign, most of their exponent and often some mantissa bits, which
+  // usually saves the fourth pass.
+  __shared__ unsigned long long s_diff;
+  if (threadIdx.x == 0) s_diff = 0ull;
+  __syncthreads();
+  {
+    const uint64_t ref = src[0];
+    uint64_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < kItems; i++)
+      if (threadIdx.x * kItems + i < n) diff |= k[i] ^ ref;
+    diff >>= idx_bits;
+    if (diff) atomicOr(&s_diff, (unsigned long long)diff);
+  }
+  __syncthreads();
+  const unsigned dd = (unsigned)s_diff;
+  const unsigned hi = dd ? 32u - (unsigned)__builtin_clz(dd) : 1u;
+  sorter().sort(k, storage, idx_bits, idx_bits + hi);
   __syncthreads();
   uint64_t* s_k = reinterpret_cast<uint64_t*>(&storage);
 #pragma unroll
