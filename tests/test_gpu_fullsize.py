@@ -16,7 +16,7 @@ import pytest
 import torch
 
 import scenes
-from test_gpu_parity import DEV, L1_TOL, _dgr, hip_planes, hip_raw_forward, scratch_views, settings, tt
+from test_gpu_parity import DEV, L1_TOL, _dgr, check_forward, hip_planes, hip_raw_forward, scratch_views, settings, tt
 
 pytestmark = pytest.mark.gpu
 
@@ -234,3 +234,17 @@ def test_c4_three_million_gaussians_sh3_native_resolution():
         assert torch.isfinite(g[k].grad).all(), k
         assert float(g[k].grad[~vis].abs().sum()) == 0.0, k  # culled Gaussians receive exact zeros
     assert float(g["shs"].grad.abs().sum()) > 0 and float(g["albedo"].grad.abs().sum()) > 0
+
+
+def test_c4_forward_matches_oracle_at_native_size(orc):
+    """configs[3] at its own size against the oracle: 3 M Gaussians, SH 3, 1237x822, ~29 M instances with tile lists up to
+    ~38 000 keys -- the dense-scene binning (long lists partitioned by sampled splitters, bucket sorts in LDS) gives the
+    oracle's keys / point_list / ranges bit for bit, per-Gaussian state bit for bit, planes within the tolerance."""
+    orc.set_threads(orc.max_threads())
+    try:
+        sc = scenes.surface_scene(P=3_000_000, sh_degree=3, seed=0)
+        cam = scenes.orbit_camera(5, 64, 1237, 822, radius=3.5)
+        _, ref, res, nflip = check_forward(orc, sc, cam, bg=(0, 0, 0), tag="C4 ")
+    finally:
+        orc.set_threads(min(8, orc.max_threads()))
+    assert res[0] > 20_000_000 and nflip <= 1e-4 * 1237 * 822
