@@ -499,7 +499,7 @@ bin_sort_kernel(int T, unsigned idx_bits, const uint32_t* __restrict__ tile_orde
 // back -- costs 2.4 ms of a 9 ms step there and keeps the host in the loop.  Here the scatter by tile already IS the
 // most significant radix pass; a tile whose list is long (> kLongList keys) gets ONE more most-significant pass, with
 // splitters drawn from its own keys (a sample sort): after the scatter a tile's stretch of `keys_unsorted` is in
-// arbitrary order, so every (n / 1024)-th key is a uniform sample; its sorted sample yields B - 1 = ceil(n / 1536) - 1
+// arbitrary order, so every (n / 512)-th key is a uniform sample; its sorted sample yields B - 1 = ceil(n / 1536) - 1
 // splitters, the tile's keys are partitioned into B buckets (histogram per 4096-key chunk, prefix, scatter into the
 // tile's stretch of the output array -- runs of hundreds of keys: coalesced), and every bucket is sorted in place by the
 // same LDS kernels as a short list.  Buckets are key ranges, keys are unique and totally ordered by (depth, index), so
@@ -510,7 +510,13 @@ constexpr unsigned kLongList = 8192;     // lists above this are partitioned (be
 constexpr unsigned kBucketTarget = 1536;  // keys per bucket aimed at (the 256-lane LDS sort takes up to 2048)
 constexpr unsigned kMaxBuckets = 32;
 constexpr unsigned kPartChunk = 4096;    // keys per workgroup pass of the histogram / partition kernels
-constexpr unsigned kSampleMax = 1024;
+// splitter sample = 256 lanes x this many keys: 1024 / 512 / 256 samples measured at C4 -- plan 0.083 / 0.063 / 0.054 ms, but with
+// 256 the buckets balance worse (the 1024-lane bucket sort grows from 0.02 to 0.07 ms)
+#ifndef GIGS_SAMPLE_PER_LANE
+#define GIGS_SAMPLE_PER_LANE 2
+#endif
+constexpr int kSamplePerLane = GIGS_SAMPLE_PER_LANE;
+constexpr unsigned kSampleMax = 256 * kSamplePerLane;
 
 struct LongTile { uint32_t tile, B, first_chunk, nchunks; };
 struct LongState {
@@ -545,7 +551,7 @@ size_t long_space_bytes(size_t T, size_t R) {
 __device__ __forceinline__ unsigned buckets_for(unsigned n, unsigned target) { return min(kMaxBuckets, (n + target - 1) / target); }
 
 // one workgroup per tile (most return at once): sample, sort the sample, publish splitters and the chunk descriptors
-using SampleSort = rocprim::block_radix_sort<uint64_t, 256, 4, rocprim::empty_type, 1, 1, 8>;
+using SampleSort = rocprim::block_radix_sort<uint64_t, 256, kSamplePerLane, rocprim::empty_type, 1, 1, 8>;
 __global__ void __launch_bounds__(256)
 long_plan_kernel(int T, unsigned idx_bits, unsigned target, const uint2* __restrict__ ranges,
                  const uint64_t* __restrict__ keys_unsorted, LongState st) {
@@ -563,15 +569,15 @@ long_plan_kernel(int T, unsigned idx_bits, unsigned target, const uint2* __restr
     }
     // a uniform sample of the tile's keys (their order after the scatter is arbitrary): every (n / S)-th one
     const unsigned S = kSampleMax;  // n > kLongList > S
-    uint64_t k[4];
+    uint64_t k[kSamplePerLane];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const unsigned j = threadIdx.x * 4 + i;
+    for (int i = 0; i < kSamplePerLane; i++) {
+      const unsigned j = threadIdx.x * kSamplePerLane + i;
       k[i] = keys_unsorted[rg.x + (unsigned)(((unsigned long long)j * n) / S)];
     }
     SampleSort().sort(k, storage, 0, 32 + idx_bits);
 #pragma unroll
-    for (int i = 0; i < 4; i++) s_sorted[threadIdx.x * 4 + i] = k[i];
+    for (int i = 0; i < kSamplePerLane; i++) s_sorted[threadIdx.x * kSamplePerLane + i] = k[i];
     __syncthreads();
     const unsigned slot = s_slot, first = s_first;
     if (threadIdx.x < kMaxBuckets) {
