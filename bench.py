@@ -143,6 +143,37 @@ def pmc_valu_busy(stage: str):
         return None
 
 
+def pmc_light_roofline():
+    """The GGX pre-filter launch (all five levels in one kernel, forward and backward) against the HBM roofline, from the committed
+    PMC pass of this configuration: HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md), duration =
+    GRBM_GUI_ACTIVE / 8 XCDs at 2.4 GHz.  The kernel streams its cached pair-weight tables (0.74 GB per direction at base 256),
+    which is what makes it HBM-bound; the bytes it could not avoid even by recomputing the weights (textures + window bounds)
+    are `alg_bytes_without_tables`."""
+    f = _pmc_path()
+    if f is None:
+        return None
+    try:
+        d = json.load(open(f))
+    except Exception:  # noqa: BLE001
+        return None
+    out = {"pmc_summary": os.path.relpath(f, ROOT), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "alg_bytes_without_tables": int(2 * 6.3e6 + 96 * 6 * (256 ** 2 + 128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2))}
+    for tag, key in (("fwd", "specular_apply_multi_kernel<false>"), ("bwd", "specular_apply_multi_kernel<true>")):
+        cands = [v for k, v in d.items() if k.startswith(key)]
+        if not cands:
+            continue
+        v = cands[0]
+        try:
+            byts = (2 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024
+            ms = v["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0 / 2.4e6
+            out[tag] = {"hbm_bytes": int(byts), "ms_alone": round(ms, 4), "achieved": round(byts / (ms * 1e-3) / 1e9, 1),
+                        "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "valu_busy": round(4.0 * v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / (1024.0 * v["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0), 3)}
+        except Exception:  # noqa: BLE001
+            pass
+    return out if ("fwd" in out or "bwd" in out) else None
+
+
 def make_light(device, shade: str = "hip"):
     import pbr
     light = pbr.CubemapLight(base_res=256).to(device)
@@ -622,7 +653,8 @@ def run(args):
                        "parallelism": "view-parallel dp%d, 1 view/GPU/step, flat grad all-reduce%s"
                                       % (world, " of the stage-2 non-zero gradient set" if reduce_only else " of every gradient")},
             "ranks_seen": ranks_seen, "comm": comm, "repeats": repeats,
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "roofline_light": None if inference else pmc_light_roofline(), "cpu_baseline": cpu,
+            "kernels": kernels,
         }
         line.update(extras)
         if parity_rep is not None:
