@@ -475,7 +475,7 @@ int gigs_backward(int P, int D, int M, int R, const float* background, int width
   if (P == 0) return 0;
   if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(GIGS_ERR_INVALID, "bad sizes");
   if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GIGS_ERR_INVALID, "null scratch buffer");
-  if (!dL_dmean2D || !dL_dconic || !dL_ddepth || !dL_dopacity || !dL_dnormal || !dL_dalbedo ||
+  if (!dL_dmean2D || !dL_dopacity || !dL_dnormal || !dL_dalbedo ||
       !dL_droughness || !dL_dmetallic || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
       (shs && !dL_dsh))
     return fail(GIGS_ERR_INVALID, "null gradient output");

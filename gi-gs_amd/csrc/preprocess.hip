@@ -279,31 +279,50 @@ __device__ __forceinline__ v3 dnormvdv3(v3 v, v3 dv) {  // auxiliary.h:118-128
 }
 
 __global__ void __launch_bounds__(kPreBlock)
-preprocess_bwd_kernel(BwdArgs a, GeomState g) {
+preprocess_bwd_kernel(BwdArgs a, GeomState g, int sh_always) {
   extern __shared__ __align__(16) float sh_lds[];
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   const int P = a.P, M = a.M, D = a.D;
+  const bool live = idx < P;
+
+  // ---- unpack the blend-backward record into the reference's separate gradient tensors
+  const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 g0 = z4, g1 = z4, g2 = z4, g3 = z4, g4 = z4;
+  if (live) {
+    float4* gr = reinterpret_cast<float4*>(g.grec + (size_t)idx * GIGS_GREC);
+    g0 = gr[0]; g1 = gr[1]; g2 = gr[2]; g3 = gr[3]; g4 = gr[4];
+    // consumed: zero again, so that another backward on the same forward state starts from zero (see preprocess_fwd)
+    gr[0] = z4; gr[1] = z4; gr[2] = z4; gr[3] = z4; gr[4] = z4;
+  }
+
+  // The SH coefficients (12*M bytes per Gaussian) matter only where a colour gradient arrived: with
+  // dL_dcolor == 0 the reference's computeColorFromSH backward (backward.cu:21-140) yields dL_dsh = 0
+  // and adds 0 to dL_dmean for finite coefficients. A block whose Gaussians all have a zero colour
+  // gradient (every block of a stage-2 step, whose loss never reads the SH colour plane) therefore
+  // skips the read and writes its dL_dsh zeros as one contiguous run.
+  int block_sh = 0;
   if (a.shs) {
     const size_t first = (size_t)blockIdx.x * kPreBlock;
     const int nG = min(kPreBlock, P - (int)first);
-    stage_sh(a.shs, sh_lds, first, nG, M);
-    __syncthreads();
+    block_sh = sh_always || __syncthreads_or(live && !(g1.w == 0.0f && g2.x == 0.0f && g2.y == 0.0f));
+    if (block_sh) {
+      stage_sh(a.shs, sh_lds, first, nG, M);
+      __syncthreads();
+    } else {
+      float* z = a.dL_dsh + first * M * 3;
+      const int n = nG * M * 3;
+      const int n4 = (reinterpret_cast<uintptr_t>(z) & 15) == 0 ? n / 4 : 0;  // a slab view may start off a 16-byte boundary
+      for (int i = threadIdx.x; i < n4; i += kPreBlock) reinterpret_cast<float4*>(z)[i] = z4;
+      for (int i = 4 * n4 + threadIdx.x; i < n; i += kPreBlock) z[i] = 0.0f;
+    }
   }
-  if (idx >= P) return;
-
-  // ---- unpack the blend-backward record into the reference's separate gradient tensors
-  float4* gr = reinterpret_cast<float4*>(g.grec + (size_t)idx * GIGS_GREC);
-  const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4];
-  {  // consumed: zero again, so that another backward on the same forward state starts from zero (see preprocess_fwd)
-    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    gr[0] = z4; gr[1] = z4; gr[2] = z4; gr[3] = z4; gr[4] = z4;
-  }
+  if (!live) return;
   // g0 = (m2d.x, m2d.y, m2d.abs, con.xx) g1 = (con.xy, con.yy, dopac, dcol.r)
   // g2 = (dcol.g, dcol.b, dn.x, dn.y) g3 = (dn.z, dalb.r, dalb.g, dalb.b) g4 = (drough, dmetal, ddepth, -)
   a.dL_dmean2D[3 * (size_t)idx + 0] = g0.x;
   a.dL_dmean2D[3 * (size_t)idx + 1] = g0.y;
   a.dL_dmean2D[3 * (size_t)idx + 2] = g0.z;
-  reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(g0.w, g1.x, 0.0f, g1.y);
+  if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(g0.w, g1.x, 0.0f, g1.y);
   a.dL_dopacity[idx] = g1.z;
   a.dL_dcolor[3 * (size_t)idx + 0] = g1.w;
   a.dL_dcolor[3 * (size_t)idx + 1] = g2.x;
@@ -316,15 +335,20 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g) {
   a.dL_dalbedo[3 * (size_t)idx + 2] = g3.w;
   a.dL_droughness[idx] = g4.x;
   a.dL_dmetallic[idx] = g4.y;
-  a.dL_ddepth[idx] = g4.z;
+  if (a.dL_ddepth) a.dL_ddepth[idx] = g4.z;
 
-  if (!(a.radii[idx] > 0)) {
+  // Every term of the geometry gradients below carries one of these as a factor: with all of them zero (the detached
+  // blend weights of a stage-2 step leave only the material planes' gradients) the chain yields zeros for finite
+  // parameters, so the Gaussian's geometry (64 bytes) is not read and nothing is evaluated.
+  const bool geo_zero = !sh_always && g0.x == 0.0f && g0.y == 0.0f && g0.w == 0.0f && g1.x == 0.0f && g1.y == 0.0f &&
+                        g4.z == 0.0f && g1.w == 0.0f && g2.x == 0.0f && g2.y == 0.0f;
+  if (geo_zero || !(a.radii[idx] > 0)) {
     // culled Gaussian: the reference leaves the caller's zero-initialised outputs untouched; writing
     // the zeros here lets the caller hand in uninitialised memory (no memset launches per tensor)
     a.dL_dmean3D[3 * (size_t)idx + 0] = 0.0f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.0f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.0f;
-    if (a.shs)
+    if (block_sh)
       for (int i = 0; i < 3 * M; i++) a.dL_dsh[(size_t)idx * M * 3 + i] = 0.0f;
     a.dL_dscale[3 * (size_t)idx + 0] = 0.0f; a.dL_dscale[3 * (size_t)idx + 1] = 0.0f; a.dL_dscale[3 * (size_t)idx + 2] = 0.0f;
     reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0, 0, 0, 0);
@@ -412,7 +436,7 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g) {
   dmeans = dmeans + dm2;
 
   // ---- computeColorFromSH backward (backward.cu:21-140)
-  if (a.shs) {
+  if (block_sh) {
     const float* sh = sh_lds + threadIdx.x * sh_stride(M);
 #define SH(k) (v3{sh[3 * (k)], sh[3 * (k) + 1], sh[3 * (k) + 2]})
     const float* cp = a.cam_pos;
@@ -523,7 +547,11 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g) {
 void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, hipStream_t s) {
   const int blocks = (a.P + kPreBlock - 1) / kPreBlock;
   const size_t lds = a.shs ? (size_t)kPreBlock * sh_stride(a.M) * sizeof(float) : 0;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(kPreBlock), lds, s, a, g);
+  // GIGS_PRE_BWD_SH_SKIP=0 (diagnostic): evaluate every visible Gaussian and read the SH block of every group, whatever
+  // the incoming gradients (as before round 3)
+  const char* e = getenv("GIGS_PRE_BWD_SH_SKIP");
+  const int sh_always = (e && e[0] == '0') ? 1 : 0;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(kPreBlock), lds, s, a, g, sh_always);
 }
 
 }  // namespace gigs

@@ -338,7 +338,9 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
         return _mk(shape, dtype=torch.float32, device=dev)
 
     dL_dmeans3D, dL_dmeans2D, dL_dcolors = z("means3D", P, 3), z("means2D", P, 3), z("colors", P, NUM_CHANNELS)
-    dL_dconic, dL_ddepth, dL_dopacity = z("", P, 2, 2), z("", P, 1), z("opacity", P, 1)
+    # dL_dconic [P,2,2] / dL_ddepth [P]: scratch the reference binding allocates and never returns
+    # (rasterize_points.cu:302-303) -- not requested from the library (NULL)
+    dL_dopacity = z("opacity", P, 1)
     dL_dnormal, dL_dalbedo = z("normal", P, 3), z("albedo", P, 3)
     dL_droughness, dL_dmetallic = z("roughness", P, 1), z("metallic", P, 1)
     dL_dcov3D, dL_dsh = z("cov3D", P, 6), z("sh", P, M, 3)
@@ -362,7 +364,7 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
                 imgBuffer.data_ptr(), p(grad_depth, "grad_depth"), p(grad_color, "grad_color"),
                 p(grad_opacity, "grad_opacity"), p(grad_normal, "grad_normal"), p(grad_albedo, "grad_albedo"),
                 p(grad_roughness, "grad_roughness"), p(grad_metallic, "grad_metallic"),
-                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_ddepth.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dmeans2D.data_ptr(), None, None, dL_dopacity.data_ptr(),
                 dL_dnormal.data_ptr(), dL_dalbedo.data_ptr(), dL_droughness.data_ptr(),
                 dL_dmetallic.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
                 dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),

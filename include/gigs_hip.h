@@ -72,8 +72,9 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
 /* Rasterizer::backward (rasterizer.h:103-150, rasterizer_impl.cu:676-803).  Every element of every
  * dL_d* output is written (culled Gaussians get zeros), so the caller need not zero-initialise them
  * as the reference binding does (R/rasterize_points.cu:299-312); dL_dconic [P,2,2] and dL_ddepth [P]
- * are the two scratch gradients the reference allocates but does not return.  Any of the seven incoming
- * dL_dpix_* planes may be NULL = an all-zero gradient (an output the loss does not use). */
+ * are the two scratch gradients the reference allocates but does not return: either may be NULL (not
+ * written).  Any of the seven incoming dL_dpix_* planes may be NULL = an all-zero gradient (an output
+ * the loss does not use). */
 int gigs_backward(int P, int D, int M, int R, const float* background, int width, int height,
                   const float* means3D, const float* shs, const float* colors_precomp,
                   const float* normal, const float* albedo, const float* roughness,

@@ -321,7 +321,7 @@ def test_backward_matches_oracle(orc, deg, W, H, P):
     assert np.abs(want["means3D"]).max() > 0 and np.abs(want["sh"]).max() > 0
 
 
-def test_backward_stage2_pattern_and_linearity(orc):
+def test_backward_stage2_pattern_and_linearity(orc, monkeypatch):
     """Stage-2 training feeds only albedo/roughness/metallic image gradients."""
     sc = scenes.surface_scene(P=8000, sh_degree=2, seed=5, scale_mu=0.03)
     cam = scenes.orbit_camera(0, 4, 160, 128, radius=3.5)
@@ -333,6 +333,55 @@ def test_backward_stage2_pattern_and_linearity(orc):
     # detached blend weights: no gradient reaches geometry or colour from these planes
     for k in ("means3D", "scales", "rotations", "opacity", "sh", "means2D"):
         assert np.abs(got[k]).max() == 0.0, k
+    # ... which the preprocess backward uses to skip the geometry chain and the SH read of such Gaussians: same
+    # result as evaluating everything (GIGS_PRE_BWD_SH_SKIP=0)
+    monkeypatch.setenv("GIGS_PRE_BWD_SH_SKIP", "0")
+    full, _, _ = _backward_pair(orc, sc, cam, (0, 0, 0), seed=1, zero=zero)
+    for k in got:
+        if k in ("albedo", "roughness", "metallic"):  # float atomics: equal to rounding
+            np.testing.assert_allclose(got[k], full[k], rtol=1e-4, atol=1e-6 * max(np.abs(full[k]).max(), 1e-20))
+        else:
+            assert np.array_equal(got[k], full[k]), k
+
+
+def test_backward_colour_gradient_on_part_of_the_image(orc):
+    """The preprocess backward reads the SH block of a 256-Gaussian group only if one of its Gaussians
+    received a colour gradient: order the cloud along screen x and feed a colour gradient on the left half of
+    the image, so that some groups take the reading branch, some the skipping one, and some straddle."""
+    sc = scenes.random_scene(P=6000, sh_degree=3, seed=21, scale_mu=0.03)
+    cam = scenes.orbit_camera(0, 5, 192, 128)
+    pv = np.c_[sc["means3D"], np.ones(len(sc["means3D"]))] @ np.asarray(cam["viewmatrix"], np.float64).reshape(4, 4)
+    order = np.argsort(pv[:, 0] / np.maximum(pv[:, 2], 1e-3), kind="stable")  # screen x
+    for k in GAUSS_KEYS:
+        sc[k] = np.ascontiguousarray(sc[k][order])
+    dgr = _dgr()
+    H, W = cam["image_height"], cam["image_width"]
+    r, _ = oracle_forward(orc, sc, cam, bg=(0.1, 0.2, 0.3))
+    pg = random_pix_grads(np.random.default_rng(3), H, W)
+    pg["color"][..., W // 3:] = 0
+    for k in ("opacity", "depth", "normal"):
+        pg[k][:] = 0
+    want = r.backward(grad_color=pg["color"], grad_opacity=pg["opacity"], grad_depth=pg["depth"],
+                      grad_normal=pg["normal"], grad_albedo=pg["albedo"], grad_roughness=pg["roughness"],
+                      grad_metallic=pg["metallic"])
+    st = settings(dgr, cam, sc["sh_degree"], bg=(0.1, 0.2, 0.3))
+    t = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+    m2d = torch.zeros_like(t["means3D"], requires_grad=True)
+    outs = dgr._RasterizeGaussians.apply(t["means3D"], m2d, t["opacities"], t["normal"], t["albedo"], t["roughness"],
+                                         t["metallic"], t["shs"], torch.Tensor([]), t["scales"], t["rotations"],
+                                         torch.Tensor([]), st)
+    loss = ((outs[0] * tt(pg["color"])).sum() + (outs[5] * tt(pg["albedo"])).sum()
+            + (outs[6] * tt(pg["roughness"])).sum() + (outs[7] * tt(pg["metallic"])).sum())
+    loss.backward()
+    torch.cuda.synchronize()
+    got = dict(means3D=t["means3D"].grad, sh=t["shs"].grad, scales=t["scales"].grad, rotations=t["rotations"].grad,
+               opacity=t["opacities"].grad, albedo=t["albedo"].grad)
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    _check_grads(got, {k: want[k] for k in got}, tag="partial ")
+    per_group = np.abs(got["sh"]).reshape(len(order), -1).max(1)
+    groups = [per_group[i:i + 256] for i in range(0, len(order), 256)]
+    assert any(g.max() == 0 for g in groups) and any(g.max() > 0 for g in groups)
+    assert any(g.max() > 0 and (g == 0).any() for g in groups)
 
 
 def test_backward_scratch_gradients_c_abi(orc):
