@@ -314,6 +314,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and parity)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (drop_in_step, full_grad_step, iteration) that follow the timed region")
+    ap.add_argument("--iteration", action="store_true",
+                    help="print the complete training iteration (it/s, `iteration` / `iteration_stage1`) beside the metric even "
+                         "under --no-extras (it is part of the default line)")
     ap.add_argument("--cpu-single-res", type=int, default=200,
                     help="resolution of the bounded single-thread CPU sample (0 = skip)")
     args = ap.parse_args(argv)
@@ -626,7 +629,7 @@ def run(args):
                 cpu, parity_rep = cpu_baseline_and_parity(sc, cams[vi0], gi, args.sh_degree, light, brdf_lut, stepper,
                                                           args.config.upper(), single_thread_res=args.cpu_single_res)
         extras = {}
-        if not args.no_extras and world == 1 and not inference:
+        if (not args.no_extras or args.iteration) and world == 1 and not inference:
             extras = secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n_views, sc)
         what = ("relight renders/sec (inference, PBR+indirect, mips built once)" if inference
                 else "train-step renders/sec (fwd+bwd, G-buffer+indirect)")
@@ -702,6 +705,24 @@ def secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n
         for p in leaves:
             p.grad = None
 
+    if not args.no_extras:
+        _drop_in_and_full_grad(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n_views, out, clear)
+    clear()
+    try:
+        import train_iteration
+        out["iteration"] = train_iteration.bench_iteration(sc, light, brdf_lut, gi, args.sh_degree, cams_t, view_dirs, gt_image,
+                                                           steps=max(20, args.steps), warmup=5)
+        out["iteration_stage1"] = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image,
+                                                                         steps=max(20, args.steps), warmup=5)
+        lean = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image, steps=max(20, args.steps),
+                                                      warmup=5, compute_occlusion=False)
+        out["iteration_stage1"]["without_the_unused_ssao_march"] = {k: lean[k] for k in ("iterations_per_s", "ms_per_iteration")}
+    except ImportError:
+        pass
+    return out
+
+
+def _drop_in_and_full_grad(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n_views, out, clear):
     drop = pipeline.Stage2Step(light, brdf_lut, gi, args.sh_degree, graphs=False, fused=False)
 
     def drop_step(i):
@@ -725,19 +746,6 @@ def secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n
     st = {k: round(ms / n, 4) for k, (ms, n) in prof.stages.items() if n and k in ("blend_fwd", "blend_bwd", "preprocess_bwd")}
     out["full_grad_step"] = dict(rec, kernels_avg_ms=st, what="rasterizer + in-op filters + SSAO forward, backward with all seven "
                                  "incoming gradient planes live, eager")
-    clear()
-    try:
-        import train_iteration
-        out["iteration"] = train_iteration.bench_iteration(sc, light, brdf_lut, gi, args.sh_degree, cams_t, view_dirs, gt_image,
-                                                           steps=max(20, args.steps), warmup=5)
-        out["iteration_stage1"] = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image,
-                                                                         steps=max(20, args.steps), warmup=5)
-        lean = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image, steps=max(20, args.steps),
-                                                      warmup=5, compute_occlusion=False)
-        out["iteration_stage1"]["without_the_unused_ssao_march"] = {k: lean[k] for k in ("iterations_per_s", "ms_per_iteration")}
-    except ImportError:
-        pass
-    return out
 
 
 if __name__ == "__main__":

@@ -697,28 +697,6 @@ cube_texture_fwd_kernel(int res, const float* __restrict__ tex, int n, const flo
   }
 }
 
-// scatters g_out through the same taps; accumulates into d_tex (caller zeroes)
-__global__ void __launch_bounds__(256)
-cube_texture_bwd_kernel(int res, int n, const float* __restrict__ dirs, const float* __restrict__ g_out,
-                        float* __restrict__ d_tex, int planar) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  Taps t;
-  if (!cube_taps(res, dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2], t)) return;
-  const float g0 = planar ? g_out[i] : g_out[3 * (size_t)i];
-  const float g1 = planar ? g_out[(size_t)n + i] : g_out[3 * (size_t)i + 1];
-  const float g2 = planar ? g_out[2 * (size_t)n + i] : g_out[3 * (size_t)i + 2];
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (t.idx[k] >= 0 && t.w[k] != 0.0f) {
-      float* p = d_tex + 3 * (size_t)t.idx[k];
-      atomicAdd(p, g0 * t.w[k]);
-      atomicAdd(p + 1, g1 * t.w[k]);
-      atomicAdd(p + 2, g2 * t.w[k]);
-    }
-}
-
-
 // latlong_to_cubemap (relight.py:92-111): every cube texel looks its direction up in an equirectangular map.
 //   gy, gx = linspace(-1 + 1/res, 1 - 1/res, res)   (torch: start + i*step below the middle, end - (n-1-i)*step above)
 //   v = normalize(cube_to_dir(face, gx, gy));  tu = atan2(v.x, -v.z) / (2 pi) + 0.5;  tv = acos(clamp(v.y, -1, 1)) / pi
@@ -962,6 +940,28 @@ __device__ __forceinline__ void run_add3(float* target, int key, float v0, float
     if (v0 != 0.0f) atomicAdd(target, v0);
     if (v1 != 0.0f) atomicAdd(target + 1, v1);
     if (v2 != 0.0f) atomicAdd(target + 2, v2);
+  }
+}
+
+// scatters g_out through the same taps; accumulates into d_tex (caller zeroes).  Neighbouring samples that hit the same
+// texel are pre-summed per 16-lane row (run_add3): the envmap TV's latlong grid (losses.get_envmap_dirs) sends whole rows
+// of 512 samples to the four texels around a pole, which serialised 0.32 ms of memory-side atomics.
+__global__ void __launch_bounds__(256)
+cube_texture_bwd_kernel(int res, int n, const float* __restrict__ dirs, const float* __restrict__ g_out,
+                        float* __restrict__ d_tex, int planar) {
+  const int gi = blockIdx.x * 256 + threadIdx.x;
+  const bool live = gi < n;
+  const int i = live ? gi : 0;  // dead lanes add nothing: the DPP scans need every lane
+  Taps t;
+  const bool ok = cube_taps(res, dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2], t) && live;
+  const float g0 = planar ? g_out[i] : g_out[3 * (size_t)i];
+  const float g1 = planar ? g_out[(size_t)n + i] : g_out[3 * (size_t)i + 1];
+  const float g2 = planar ? g_out[2 * (size_t)n + i] : g_out[3 * (size_t)i + 2];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int idx = (ok && t.idx[k] >= 0 && t.w[k] != 0.0f) ? t.idx[k] : -1;
+    const float w = idx >= 0 ? t.w[k] : 0.0f;
+    run_add3<false>(d_tex + 3 * (size_t)max(idx, 0), idx, g0 * w, g1 * w, g2 * w);
   }
 }
 

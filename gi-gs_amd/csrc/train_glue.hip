@@ -441,8 +441,8 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
 // ---- parameter activations (scene/gaussian_model.py:48-58, 178-263) ------------------------------------------
 // get_features = cat(f_dc, f_rest), get_opacity / albedo / roughness / metallic = sigmoid, get_scaling = exp,
 // get_rotation / get_normal = F.normalize(dim=-1, eps=1e-12): eight getters, ~10 torch kernels forward and ~20 backward
-// per iteration; here one pass each way.  Lane i handles SH float i of the concatenation and, for i < P, the sixteen
-// small attributes of Gaussian i.
+// per iteration; here one launch each way (the SH concatenation in 64-Gaussian tiles, then the sixteen small attributes
+// one Gaussian per lane).
 struct ActPtrs {
   const float *f_dc, *f_rest, *opacity, *normal, *albedo, *roughness, *metallic, *scaling, *rotation;  // raw
   float *shs, *o_opacity, *o_normal, *o_albedo, *o_roughness, *o_metallic, *o_scales, *o_rotations;    // fwd outputs
@@ -478,15 +478,81 @@ __device__ __forceinline__ void normalize_bwd(const float* __restrict__ v, const
   }
 }
 
-__global__ void __launch_bounds__(256)
-activate_fwd_kernel(int P, int K, ActPtrs A) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int row_f = 3 * K;
-  if (i < (long long)P * row_f) {
-    const long long r = i / row_f;
-    const int c = (int)(i - r * row_f);
-    A.shs[i] = c < 3 ? A.f_dc[3 * r + c] : A.f_rest[r * (row_f - 3) + (c - 3)];
+// The SH concatenation cat(f_dc [P,1,3], f_rest [P,K-1,3]) -> shs [P,K,3] (and its backward, the split) moves 24*K bytes
+// per Gaussian: a tile of 64 Gaussians is contiguous in all three arrays, so it is read with 16-byte loads, re-laid out in
+// LDS (which holds the tile in the concatenated layout) and written with 16-byte stores.  One float per lane with a
+// division for its (row, column) ran at 3 TB/s; pointers that are not 16-byte aligned (views into a gradient slab) take
+// the scalar form of the same loops.
+constexpr int kActRows = 64;
+constexpr int kActMaxRowF = 48;  // K <= 16 (SH degree 3)
+
+__device__ __forceinline__ int act_div_small(int x, float inv) {  // x / d for 0 <= x < 2^12, inv = 1 / d
+  return (int)(((float)x + 0.5f) * inv);
+}
+__device__ __forceinline__ bool act_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// global [n] (contiguous) -> LDS rows of `stride` floats starting at column `col0`, `width` floats per row
+__device__ __forceinline__ void act_tile_in(const float* __restrict__ src, int n, int width, float* tile, int stride, int col0) {
+  const float inv = 1.0f / (float)width;
+  const int n4 = act_aligned16(src) ? n / 4 : 0;
+  for (int j = threadIdx.x; j < n4; j += 256) {
+    const float4 v = reinterpret_cast<const float4*>(src)[j];
+    const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int e = 4 * j + k, r = act_div_small(e, inv);
+      tile[r * stride + col0 + (e - r * width)] = e4[k];
+    }
   }
+  for (int e = 4 * n4 + threadIdx.x; e < n; e += 256) {
+    const int r = act_div_small(e, inv);
+    tile[r * stride + col0 + (e - r * width)] = src[e];
+  }
+}
+// LDS rows -> global [n] (contiguous)
+__device__ __forceinline__ void act_tile_out(float* __restrict__ dst, int n, int width, const float* tile, int stride, int col0) {
+  const float inv = 1.0f / (float)width;
+  const int n4 = act_aligned16(dst) ? n / 4 : 0;
+  for (int j = threadIdx.x; j < n4; j += 256) {
+    float e4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int e = 4 * j + k, r = act_div_small(e, inv);
+      e4[k] = tile[r * stride + col0 + (e - r * width)];
+    }
+    reinterpret_cast<float4*>(dst)[j] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+  }
+  for (int e = 4 * n4 + threadIdx.x; e < n; e += 256) {
+    const int r = act_div_small(e, inv);
+    dst[e] = tile[r * stride + col0 + (e - r * width)];
+  }
+}
+
+__device__ __forceinline__ void act_sh_tile_fwd(int P, int row_f, const ActPtrs& A, int tile_id, float* tile) {
+  const int r0 = tile_id * kActRows, rows = min(kActRows, P - r0);
+  act_tile_in(A.f_dc + 3 * (size_t)r0, rows * 3, 3, tile, row_f, 0);
+  if (row_f > 3) act_tile_in(A.f_rest + (size_t)r0 * (row_f - 3), rows * (row_f - 3), row_f - 3, tile, row_f, 3);
+  __syncthreads();
+  act_tile_out(A.shs + (size_t)r0 * row_f, rows * row_f, row_f, tile, row_f, 0);
+}
+__device__ __forceinline__ void act_sh_tile_bwd(int P, int row_f, const ActPtrs& A, int tile_id, float* tile) {
+  const int r0 = tile_id * kActRows, rows = min(kActRows, P - r0);
+  if (A.g_shs) act_tile_in(A.g_shs + (size_t)r0 * row_f, rows * row_f, row_f, tile, row_f, 0);
+  else for (int e = threadIdx.x; e < rows * row_f; e += 256) tile[e] = 0.0f;
+  __syncthreads();
+  act_tile_out(A.d_f_dc + 3 * (size_t)r0, rows * 3, 3, tile, row_f, 0);
+  if (row_f > 3) act_tile_out(A.d_f_rest + (size_t)r0 * (row_f - 3), rows * (row_f - 3), row_f - 3, tile, row_f, 3);
+}
+
+// grid: the SH tiles first, then one block per 256 Gaussians for the sixteen small attributes
+__global__ void __launch_bounds__(256)
+activate_fwd_kernel(int P, int K, ActPtrs A, int sh_tiles) {
+  __shared__ __align__(16) float tile[kActRows * kActMaxRowF];
+  if ((int)blockIdx.x < sh_tiles) {
+    act_sh_tile_fwd(P, 3 * K, A, blockIdx.x, tile);
+    return;
+  }
+  const int i = ((int)blockIdx.x - sh_tiles) * 256 + threadIdx.x;
   if (i >= P) return;
   A.o_opacity[i] = sigmoidf(A.opacity[i]);
   A.o_roughness[i] = sigmoidf(A.roughness[i]);
@@ -501,16 +567,13 @@ activate_fwd_kernel(int P, int K, ActPtrs A) {
 }
 
 __global__ void __launch_bounds__(256)
-activate_bwd_kernel(int P, int K, ActPtrs A) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int row_f = 3 * K;
-  if (i < (long long)P * row_f) {
-    const long long r = i / row_f;
-    const int c = (int)(i - r * row_f);
-    const float g = A.g_shs ? A.g_shs[i] : 0.0f;
-    if (c < 3) A.d_f_dc[3 * r + c] = g;
-    else A.d_f_rest[r * (row_f - 3) + (c - 3)] = g;
+activate_bwd_kernel(int P, int K, ActPtrs A, int sh_tiles) {
+  __shared__ __align__(16) float tile[kActRows * kActMaxRowF];
+  if ((int)blockIdx.x < sh_tiles) {
+    act_sh_tile_bwd(P, 3 * K, A, blockIdx.x, tile);
+    return;
   }
+  const int i = ((int)blockIdx.x - sh_tiles) * 256 + threadIdx.x;
   if (i >= P) return;
   {
     const float s = sigmoidf(A.opacity[i]);
@@ -857,7 +920,7 @@ static void act_fill_raw(gigs::ActPtrs& A, const gigs_activation_raw* r) {
 }
 
 int gigs_activate_fwd(int P, int K, const gigs_activation_raw* raw, const gigs_activation_out* out, void* stream) {
-  if (P < 0 || K < 1 || (P > 0 && (!act_raw_ok(raw, K) || !out || !out->shs || !out->opacities || !out->normal ||
+  if (P < 0 || K < 1 || 3 * K > gigs::kActMaxRowF || (P > 0 && (!act_raw_ok(raw, K) || !out || !out->shs || !out->opacities || !out->normal ||
                                    !out->albedo || !out->roughness || !out->metallic || !out->scales || !out->rotations)))
     return gigs_internal_fail(GIGS_ERR_INVALID, "activate_fwd: bad argument");
   if (P == 0) return 0;
@@ -867,8 +930,9 @@ int gigs_activate_fwd(int P, int K, const gigs_activation_raw* raw, const gigs_a
   A.shs = out->shs; A.o_opacity = out->opacities; A.o_normal = out->normal; A.o_albedo = out->albedo;
   A.o_roughness = out->roughness; A.o_metallic = out->metallic; A.o_scales = out->scales; A.o_rotations = out->rotations;
   void* tok; gigs_internal_stage_begin(30, stream, &tok);
-  const long long n = (long long)P * 3 * K;
-  hipLaunchKernelGGL(gigs::activate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K, A);
+  const int sh_tiles = (P + gigs::kActRows - 1) / gigs::kActRows;
+  hipLaunchKernelGGL(gigs::activate_fwd_kernel, dim3((unsigned)(sh_tiles + (P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K,
+                     A, sh_tiles);
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "activate_fwd: launch failed");
   return 0;
@@ -876,7 +940,7 @@ int gigs_activate_fwd(int P, int K, const gigs_activation_raw* raw, const gigs_a
 
 int gigs_activate_bwd(int P, int K, const gigs_activation_raw* raw, const gigs_activation_out* grad_out,
                       const gigs_activation_raw_grad* grad_raw, void* stream) {
-  if (P < 0 || K < 1 || (P > 0 && (!act_raw_ok(raw, K) || !grad_out || !grad_raw || !grad_raw->f_dc ||
+  if (P < 0 || K < 1 || 3 * K > gigs::kActMaxRowF || (P > 0 && (!act_raw_ok(raw, K) || !grad_out || !grad_raw || !grad_raw->f_dc ||
                                    (K > 1 && !grad_raw->f_rest) || !grad_raw->opacity || !grad_raw->normal ||
                                    !grad_raw->albedo || !grad_raw->roughness || !grad_raw->metallic ||
                                    !grad_raw->scaling || !grad_raw->rotation)))
@@ -892,8 +956,9 @@ int gigs_activate_bwd(int P, int K, const gigs_activation_raw* raw, const gigs_a
   A.d_albedo = grad_raw->albedo; A.d_roughness = grad_raw->roughness; A.d_metallic = grad_raw->metallic;
   A.d_scaling = grad_raw->scaling; A.d_rotation = grad_raw->rotation;
   void* tok; gigs_internal_stage_begin(31, stream, &tok);
-  const long long n = (long long)P * 3 * K;
-  hipLaunchKernelGGL(gigs::activate_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K, A);
+  const int sh_tiles = (P + gigs::kActRows - 1) / gigs::kActRows;
+  hipLaunchKernelGGL(gigs::activate_bwd_kernel, dim3((unsigned)(sh_tiles + (P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K,
+                     A, sh_tiles);
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "activate_bwd: launch failed");
   return 0;

@@ -251,13 +251,14 @@ def test_env_tv_loss_matches_restatement():
     assert (b.grad.cpu().double() - br.grad).abs().max().item() <= 1e-4 * br.grad.abs().max().item()
 
 
-def test_fused_activations_match_the_getters():
-    """scene/gaussian_model.py:178-263 written with torch ops vs gigs_activate_fwd / _bwd."""
+@pytest.mark.parametrize("P,K,misalign", [(1003, 9, False), (1003, 9, True), (130, 16, False), (64, 4, False), (77, 1, False)])
+def test_fused_activations_match_the_getters(P, K, misalign):
+    """scene/gaussian_model.py:178-263 written with torch ops vs gigs_activate_fwd / _bwd (SH concatenation through 64-row
+    LDS tiles: full and ragged tiles, every SH degree, and pointers off the 16-byte grid = views into a slab)."""
     import activations
     import torch.nn.functional as F
     dev = _dev()
     g = torch.Generator().manual_seed(31)
-    P, K = 1003, 9
     shapes = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (K - 1, 3), "opacity": (1,), "normal": (3,), "albedo": (3,),
               "roughness": (1,), "metallic": (1,), "scaling": (3,), "rotation": (4,)}
     base = {n: torch.randn((P,) + s, generator=g) * 2.0 for n, s in shapes.items()}
@@ -267,7 +268,13 @@ def test_fused_activations_match_the_getters():
                 normal=F.normalize(want_in["normal"], p=2, dim=-1), albedo=torch.sigmoid(want_in["albedo"]),
                 roughness=torch.sigmoid(want_in["roughness"]), metallic=torch.sigmoid(want_in["metallic"]),
                 scales=torch.exp(want_in["scaling"]), rotations=F.normalize(want_in["rotation"]))
-    got_in = {n: t.clone().to(dev).requires_grad_(True) for n, t in base.items()}
+    def place(t):
+        if not misalign:
+            return t.clone().to(dev).requires_grad_(True)
+        buf = torch.zeros(t.numel() + 3, device=dev)  # the parameter starts 4 bytes into an allocation
+        buf[1:1 + t.numel()] = t.reshape(-1).to(dev)
+        return buf[1:1 + t.numel()].view(t.shape).detach().requires_grad_(True)
+    got_in = {n: place(t) for n, t in base.items()}
     got = activations.activate(got_in)
     assert got["means3D"] is got_in["xyz"]
     ws = {n: torch.randn(want[n].shape, generator=g) for n in want}
@@ -276,7 +283,7 @@ def test_fused_activations_match_the_getters():
     for n in want:
         assert torch.allclose(got[n].detach().cpu(), want[n].detach(), rtol=2e-6, atol=1e-7), n
     for n in shapes:
-        if n == "xyz":
+        if n == "xyz" or base[n].numel() == 0:  # K = 1: f_rest is empty
             continue
         w = want_in[n].grad if want_in[n].grad is not None else torch.zeros_like(base[n])
         gg = got_in[n].grad.cpu()
