@@ -151,7 +151,11 @@ class CapturedAdam:
         # table rows follow the launch order: bucket by bucket
         self.order = [i for idx in self.buckets.values() for i in idx]
         self.table = torch.zeros(n, 2, dtype=torch.float32, device=dev)
-        self.host = torch.zeros(n, 2, dtype=torch.float32).pin_memory()
+        # two pinned staging buffers, used in turn: the host may run ahead of the device, and a buffer is rewritten only once
+        # the copy that read it has completed (its event)
+        self.hosts = [torch.zeros(n, 2, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._copied = [None, None]
+        self._turn = 0
         self._sc = (C.c_float * 2)()
 
     def warmup(self) -> None:
@@ -198,14 +202,21 @@ class CapturedAdam:
 
     def advance(self) -> None:
         """Host side of one update: step counts += 1, table := this step's scalars (async copy on the current stream)."""
+        host, ev = self.hosts[self._turn], self._copied[self._turn]
+        if ev is not None:
+            ev.synchronize()
         for row, i in enumerate(self.order):
             o, group, p, _ = self.entries[i]
             st = o.state[p]
             st["step"] += 1
             _lib.gigs_adam_scalars(float(group["lr"]), int(st["step"]), float(group["betas"][0]), float(group["betas"][1]),
                                    self._sc)
-            self.host[row, 0], self.host[row, 1] = self._sc[0], self._sc[1]
-        self.table.copy_(self.host, non_blocking=True)
+            host[row, 0], host[row, 1] = self._sc[0], self._sc[1]
+        self.table.copy_(host, non_blocking=True)
+        if ev is None:
+            ev = self._copied[self._turn] = torch.cuda.Event()
+        ev.record()
+        self._turn ^= 1
 
     def retreat(self) -> None:
         """Undo advance() for a step that is being repeated (binning overflow: its update was never replayed)."""
