@@ -127,14 +127,23 @@ class CubemapLight(nn.Module):
         else:
             while self.specular[-1].shape[1] > self.LIGHT_MIN_RES:
                 self.specular += [cubemap_mip.apply(self.specular[-1])]
-        self.diffuse = diffuse_cubemap(self.specular[-1])
         n = len(self.specular)
         rough = [(idx / (n - 2)) * (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) + self.MIN_ROUGHNESS for idx in range(n - 1)] + [1.0]
+        coarsest = self.specular[-1]
+        diffuse_first = os.environ.get("GIGS_LIGHT_DIFFUSE_LAST", "1") != "1"
+        if diffuse_first:
+            self.diffuse = diffuse_cubemap(coarsest)
         # the levels are independent: one launch filters them all (and one launch back-propagates them all)
         merged = specular_cubemap_levels(self.specular, rough, cutoff)
         if merged is not None:
             self.specular = merged
+            if not diffuse_first:
+                # created after the GGX node, the diffuse filter's backward runs BEFORE the GGX backward (autograd walks
+                # the later node first): 0.02 ms of short workgroups in front of the launch that floods every CU
+                self.diffuse = diffuse_cubemap(coarsest)
             return
+        if not diffuse_first:
+            self.diffuse = diffuse_cubemap(coarsest)
         for idx in range(n - 1):
             self.specular[idx] = specular_cubemap(self.specular[idx], rough[idx], cutoff)
         self.specular[-1] = specular_cubemap(self.specular[-1], 1.0, cutoff)
