@@ -650,7 +650,8 @@ cubemap_mip_fwd_kernel(int r, int C, const float* __restrict__ in, float* __rest
 }
 
 __global__ void __launch_bounds__(256)
-cubemap_mip_bwd_kernel(int r, const float* __restrict__ dout, float* __restrict__ din, const float* __restrict__ add) {
+cubemap_mip_bwd_kernel(int r, const float* __restrict__ dout, float* __restrict__ din, const float* __restrict__ add,
+                       const float* __restrict__ dout2) {
   const int res = 2 * r;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 6 * res * res) return;
@@ -669,9 +670,14 @@ cubemap_mip_bwd_kernel(int r, const float* __restrict__ dout, float* __restrict_
     for (int k = 0; k < 4; k++)
       if (t.idx[k] >= 0) {
         const float* p = dout + 3 * (size_t)t.idx[k];
-        v.x += (p[0] * 0.25f) * t.w[k];
-        v.y += (p[1] * 0.25f) * t.w[k];
-        v.z += (p[2] * 0.25f) * t.w[k];
+        float p0 = p[0], p1 = p[1], p2 = p[2];
+        if (dout2) {  // a second gradient of the coarse level (it fed two filters): the sum autograd would have formed first
+          const float* q = dout2 + 3 * (size_t)t.idx[k];
+          p0 += q[0]; p1 += q[1]; p2 += q[2];
+        }
+        v.x += (p0 * 0.25f) * t.w[k];
+        v.y += (p1 * 0.25f) * t.w[k];
+        v.z += (p2 * 0.25f) * t.w[k];
       }
   }
   if (add) {  // the level's own gradient (it also feeds a filter): summed here instead of by a separate pass
@@ -1271,7 +1277,8 @@ int gigs_cubemap_mip_bwd(int res_out, const float* dout, float* din, void* strea
   if (res_out <= 0 || !dout || !din) return gigs_internal_fail(GIGS_ERR_INVALID, "cubemap_mip_bwd: bad argument");
   const int res = 2 * res_out;
   void* tok; gigs_internal_stage_begin(17, stream, &tok);
-  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din, (const float*)nullptr);
+  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din, (const float*)nullptr,
+                     (const float*)nullptr);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;
@@ -1281,7 +1288,19 @@ int gigs_cubemap_mip_bwd_add(int res_out, const float* dout, const float* add, f
   if (res_out <= 0 || !dout || !add || !din) return gigs_internal_fail(GIGS_ERR_INVALID, "cubemap_mip_bwd_add: bad argument");
   const int res = 2 * res_out;
   void* tok; gigs_internal_stage_begin(17, stream, &tok);
-  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din, add);
+  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din, add,
+                     (const float*)nullptr);
+  gigs_internal_stage_end(tok);
+  PBR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gigs_cubemap_mip_bwd_add2(int res_out, const float* dout, const float* dout2, const float* add, float* din, void* stream) {
+  if (res_out <= 0 || !dout || !din) return gigs_internal_fail(GIGS_ERR_INVALID, "cubemap_mip_bwd_add2: bad argument");
+  const int res = 2 * res_out;
+  void* tok; gigs_internal_stage_begin(17, stream, &tok);
+  hipLaunchKernelGGL(gigs::cubemap_mip_bwd_kernel, dim3((6 * res * res + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_out, dout, din, add,
+                     dout2);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;

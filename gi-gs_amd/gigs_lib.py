@@ -74,6 +74,7 @@ SIGNATURES = {
     "gigs_specular_cubemap_multi_w": (_i, [_i, C.c_void_p, _i, C.c_void_p]),
     "gigs_cubemap_mip_fwd": (_i, [_i, _i, _f, _f, C.c_void_p]),
     "gigs_cubemap_mip_bwd_add": (_i, [_i, _f, _f, _f, C.c_void_p]),
+    "gigs_cubemap_mip_bwd_add2": (_i, [_i, _f, _f, _f, _f, C.c_void_p]),
     "gigs_cubemap_mip_bwd": (_i, [_i, _f, _f, C.c_void_p]),
     "gigs_shade_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
                             C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, C.c_void_p]),

@@ -44,15 +44,17 @@ class cubemap_mip(torch.autograd.Function):
 
 
 class _mip_chain(torch.autograd.Function):
-    """base -> (mip1, ..., mipN) by repeated cubemap_mip, as ONE autograd node: each level also feeds a GGX filter (and the
-    last one the diffuse filter), so op-by-op autograd runs a separate accumulation pass per level before every
-    cubemap_mip backward; here the level's own gradient is added inside the mip backward kernel
-    (gigs_cubemap_mip_bwd_add).  Same arithmetic as the chain of cubemap_mip calls."""
+    """base -> (base, mip1, ..., mipN, mipN') by repeated cubemap_mip, as ONE autograd node.  Every level also feeds a GGX
+    filter, the coarsest one the diffuse filter as well (through its copy mipN') and the base the chain itself, so op-by-op
+    autograd runs a separate accumulation pass per level before every cubemap_mip backward; here every sum is formed inside
+    the mip backward kernel (gigs_cubemap_mip_bwd_add2: the same additions, in the same order of operations per element).
+    Same arithmetic as the chain of cubemap_mip calls."""
 
     @staticmethod
     def forward(ctx, base, n_levels):
         if not base.is_cuda:
             raise RuntimeError("cubemap must be a CUDA/HIP tensor: pbr (gigs-hip) has no CPU path")
+        ctx.set_materialize_grads(False)  # an unused output arrives as None, not as a zero tensor
         cur = base.contiguous().float()
         outs = []
         with torch.cuda.device(cur.device):
@@ -63,28 +65,31 @@ class _mip_chain(torch.autograd.Function):
                 gigs_lib.check(_lib.gigs_cubemap_mip_fwd(r, 3, cur.data_ptr(), nxt.data_ptr(), s), "cubemap_mip_fwd")
                 outs.append(nxt)
                 cur = nxt
-        return tuple(outs)
+        return (base.view_as(base), *outs, outs[-1].clone())
 
     @staticmethod
-    def backward(ctx, *gs):
-        # walk back from the coarsest level; gs[k] is the gradient level k+1 receives from its filters (None = zero)
+    def backward(ctx, g_base, *gs):
+        # walk back from the coarsest level; gs[k] is the gradient level k+1 receives from its filter (None = zero), the
+        # last entry the one the coarsest level's copy receives (the diffuse filter's)
         gs = [None if g is None else g.contiguous().float() for g in gs]
-        dev = next(g for g in gs if g is not None).device
+        g_base = None if g_base is None else g_base.contiguous().float()
+        gs, g_dup = gs[:-1], gs[-1]
         G = gs[-1]
         if G is None:
+            G, g_dup = g_dup, None
+        if G is None:
             raise RuntimeError("_mip_chain.backward: the coarsest level received no gradient")
+        dev = G.device
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         with torch.cuda.device(dev):
             s = torch.cuda.current_stream().cuda_stream
             for k in range(len(gs) - 1, -1, -1):
                 r = G.shape[1]
                 fine = torch.empty((6, 2 * r, 2 * r, 3), dtype=torch.float32, device=dev)
-                add = gs[k - 1] if k > 0 else None
-                if add is not None:
-                    gigs_lib.check(_lib.gigs_cubemap_mip_bwd_add(r, G.data_ptr(), add.data_ptr(), fine.data_ptr(), s),
-                                   "cubemap_mip_bwd_add")
-                else:
-                    gigs_lib.check(_lib.gigs_cubemap_mip_bwd(r, G.data_ptr(), fine.data_ptr(), s), "cubemap_mip_bwd")
-                G = fine
+                add = gs[k - 1] if k > 0 else g_base
+                gigs_lib.check(_lib.gigs_cubemap_mip_bwd_add2(r, G.data_ptr(), p(g_dup), p(add), fine.data_ptr(), s),
+                               "cubemap_mip_bwd_add2")
+                G, g_dup = fine, None
         return G, None
 
 
@@ -118,18 +123,21 @@ class CubemapLight(nn.Module):
 
     def build_mips(self, cutoff: float = 0.99) -> None:
         self.specular = [self.base]
+        diffuse_in = None
         if os.environ.get("GIGS_MIP_CHAIN", "1") == "1" and self.base.shape[3] == 3:
             n_levels, r = 0, self.base.shape[1]
             while r > self.LIGHT_MIN_RES:
                 n_levels, r = n_levels + 1, r // 2
             if n_levels:
-                self.specular += list(_mip_chain.apply(self.base, n_levels))
+                chain = _mip_chain.apply(self.base, n_levels)
+                self.specular = list(chain[:-1])  # the base as the node's output: its GGX gradient enters the chain's last step
+                diffuse_in = chain[-1]
         else:
             while self.specular[-1].shape[1] > self.LIGHT_MIN_RES:
                 self.specular += [cubemap_mip.apply(self.specular[-1])]
         n = len(self.specular)
         rough = [(idx / (n - 2)) * (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) + self.MIN_ROUGHNESS for idx in range(n - 1)] + [1.0]
-        coarsest = self.specular[-1]
+        coarsest = diffuse_in if diffuse_in is not None else self.specular[-1]
         diffuse_first = os.environ.get("GIGS_LIGHT_DIFFUSE_LAST", "1") != "1"
         if diffuse_first:
             self.diffuse = diffuse_cubemap(coarsest)

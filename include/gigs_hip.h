@@ -213,6 +213,9 @@ int gigs_cubemap_mip_bwd(int res_out, const float* dout, float* din, void* strea
 /* din = add + the above (add [6,2r,2r,3]: the gradient the fine level receives from its other consumer, so that the
  * chain base <- mip1 <- ... <- mipN is walked back without separate accumulation passes). */
 int gigs_cubemap_mip_bwd_add(int res_out, const float* dout, const float* add, float* din, void* stream);
+/* the same with a second gradient of the coarse level: din = add + lookup(0.25 * (dout + dout2)); dout2 and add may be
+ * NULL.  (The coarsest level feeds the GGX filter and the diffuse filter, the base the GGX filter and the chain.) */
+int gigs_cubemap_mip_bwd_add2(int res_out, const float* dout, const float* dout2, const float* add, float* din, void* stream);
 
 /* pbr_shading (pbr/shade.py:108-241) fused into one kernel.  normals/view_dirs/albedo [H,W,3],
  * roughness/occlusion/metallic [H,W,1] (occlusion, metallic, background may be NULL), mask = bool
