@@ -358,6 +358,18 @@ static void launch_zero(float* p, size_t n, hipStream_t s) {
   const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, p, n);
 }
+// two buffers, one node (the small one rides along: a node of its own costs ~5 us on the step's critical path)
+__global__ void __launch_bounds__(256) zero2_kernel(float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * 256) {
+    if (i < na) a[i] = 0.0f;
+    else b[i - na] = 0.0f;
+  }
+}
+static void launch_zero2(float* a, size_t na, float* b, size_t nb, hipStream_t s) {
+  const size_t n = na + nb;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(zero2_kernel, dim3(blocks), dim3(256), 0, s, a, na, b, nb);
+}
 
 }  // namespace gigs
 
@@ -438,8 +450,7 @@ int gigs_stage2_loss_fwd_grad(int height, int width, const float* render_direct,
   hipStream_t s = (hipStream_t)stream;
   void* tok; gigs_internal_stage_begin(19, stream, &tok);
   float* rows = acc4 + 4;
-  gigs::launch_zero(rows, 4 * gigs::kAccSlots, s);
-  gigs::launch_zero(d_irr_linear_unit, 3 * (size_t)height * width, s);
+  gigs::launch_zero2(rows, 4 * gigs::kAccSlots, d_irr_linear_unit, 3 * (size_t)height * width, s);
   hipLaunchKernelGGL(gigs::stage2_loss_fwd_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, s, height,
                      width, render_direct, irr_linear, gt_image, normal_mask_f, roughness, metallic, render_rgb, rows,
                      d_render_direct_unit, d_irr_linear_unit);
