@@ -156,6 +156,15 @@ normalize_mask_kernel(size_t HW, const float* __restrict__ in, float* __restrict
   out[p] = o.x; out[HW + p] = o.y; out[2 * HW + p] = o.z;
 }
 
+// mask = (v != 0).all(0) of a [3,H,W] plane set as floats (gaussian_renderer/__init__.py:158; the masked TV's weight):
+// torch's `!=` + `.all(0)` + `.float()` are a compare, a fill, a reduction and a cast
+__global__ void __launch_bounds__(256)
+nonzero_mask_kernel(size_t HW, const float* __restrict__ in, float* __restrict__ mask) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  mask[p] = (in[p] != 0.0f && in[HW + p] != 0.0f && in[2 * HW + p] != 0.0f) ? 1.0f : 0.0f;
+}
+
 // ---- loss -------------------------------------------------------------------------------------
 // acc[0] = sum |render_rgb - gt|, acc[1] = sum (1 - roughness) * mask, acc[2] = sum metallic * mask,
 // acc[3] = sum mask;  loss = acc0 / (3 H W) + 0.001 * (acc1 / acc3 + acc2 / acc3)   (train.py:396-402)
@@ -418,6 +427,14 @@ int gigs_normalize_mask(int height, int width, const float* in, float* out, uint
                      in, out, mask);
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "normalize_mask: launch failed");
+  return 0;
+}
+
+int gigs_nonzero_mask(int height, int width, const float* in, float* mask, void* stream) {
+  if (height <= 0 || width <= 0 || !in || !mask) return gigs_internal_fail(GIGS_ERR_INVALID, "nonzero_mask: bad argument");
+  const size_t HW = (size_t)height * width;
+  hipLaunchKernelGGL(gigs::nonzero_mask_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream, HW, in, mask);
+  if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "nonzero_mask: launch failed");
   return 0;
 }
 

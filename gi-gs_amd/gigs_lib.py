@@ -89,6 +89,7 @@ SIGNATURES = {
     "gigs_gbuffer_post": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_gbuffer_post_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_normalize_mask": (_i, [_i, _i, _f, _f, _f, C.c_void_p]),
+    "gigs_nonzero_mask": (_i, [_i, _i, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_stage2_loss_fwd_grad": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),

@@ -138,6 +138,18 @@ def get_tv_loss(gt_image: torch.Tensor, prediction: torch.Tensor, pad: int = 1, 
     return _Tv.apply(gt_image, prediction, None, step)
 
 
+def nonzero_mask(planes: torch.Tensor) -> torch.Tensor:
+    """(planes != 0).all(0, keepdim=True).float() of a [3,H,W] tensor in one launch (gaussian_renderer/__init__.py:158)."""
+    x = planes.detach()
+    if not x.is_cuda or x.dim() != 3 or x.shape[0] != 3:
+        return (x != 0).all(0, keepdim=True).float()
+    x = x.contiguous().float()
+    out = torch.empty((1,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        gigs_lib.check(_lib.gigs_nonzero_mask(int(x.shape[1]), int(x.shape[2]), _p(x), _p(out), _stream()), "nonzero_mask")
+    return out
+
+
 def get_masked_tv_loss(mask: torch.Tensor, gt_image: torch.Tensor, prediction: torch.Tensor,
                        erosion: bool = False) -> torch.Tensor:
     """train.py:116-142; `erosion` (a 7x7 kornia morphology pass the reference never enables) is not provided."""

@@ -59,7 +59,7 @@ class Stage2Regularizer:
         self.envmap_dirs = envmap_dirs if envmap_dirs is not None else losses.get_envmap_dirs(device=light.base.device)
 
     def __call__(self, maps: Dict[str, torch.Tensor]) -> torch.Tensor:
-        mask = (maps["normal_map"].detach() != 0).all(0, keepdim=True)  # gaussian_renderer/__init__.py:158
+        mask = losses.nonzero_mask(maps["normal_map"])                  # gaussian_renderer/__init__.py:158
         rough = maps["roughness_map"] * (1.0 - 0.04) + 0.04             # train.py:297-298
         brdf = torch.cat([maps["albedo_map"], rough, maps["metallic_map"]], dim=0)
         loss = self.brdf_tv_weight * losses.get_masked_tv_loss(mask, maps["gt_image"], brdf)

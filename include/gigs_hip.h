@@ -307,6 +307,9 @@ int gigs_gbuffer_post(int height, int width, const float* normal_map, const floa
 int gigs_gbuffer_post_bwd(int height, int width, const float* normal_map, const float* viewmatrix,
                           const float* g_normals_view, float* scratch3, float* g_normal_map, void* stream);
 int gigs_normalize_mask(int height, int width, const float* in, float* out, uint8_t* mask, void* stream);
+/* mask [H,W] (floats 0 / 1) = (in != 0).all(0) of in [3,H,W]: normal_mask of gaussian_renderer/__init__.py:158 as the
+ * masked TV loss (train.py:116-142) weighs with it. */
+int gigs_nonzero_mask(int height, int width, const float* in, float* mask, void* stream);
 int gigs_stage2_loss_fwd(int height, int width, const float* render_direct, const float* irr_linear,
                          const float* gt_image, const float* normal_mask_f, const float* roughness,
                          const float* metallic, float* render_rgb, float* acc4, float* loss, void* stream);

@@ -344,3 +344,19 @@ def test_captured_adam_in_a_hipgraph_equals_the_eager_launch():
                     assert torch.equal(sr["exp_avg"], sg["exp_avg"]) and torch.equal(sr["exp_avg_sq"], sg["exp_avg_sq"])
     cap.retreat()
     assert int(got_a.state[got_p[0]]["step"]) == 5
+
+
+def test_nonzero_mask_equals_the_torch_expression():
+    """losses.nonzero_mask == (x != 0).all(0, keepdim=True).float() (gaussian_renderer/__init__.py:158), incl. -0.0, NaN, Inf
+    and a ragged size."""
+    import losses
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 37, 53, generator=g)
+    x[torch.rand(3, 37, 53, generator=g) < 0.2] = 0.0
+    x[0, 0, 0], x[1, 0, 1], x[2, 0, 2], x[0, 0, 3] = -0.0, float("nan"), float("inf"), float("nan")
+    x[1, 0, 3] = 0.0
+    want = (x != 0).all(0, keepdim=True).float()
+    got = losses.nonzero_mask(x.to(dev)).cpu()
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert 0.0 < want.mean().item() < 1.0
