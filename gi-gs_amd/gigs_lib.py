@@ -95,6 +95,8 @@ SIGNATURES = {
     "gigs_stage2_loss_fwd_grad": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_cube_texture_fwd": (_i, [_i, _f, _i, _f, _f, _i, C.c_void_p]),
     "gigs_cube_texture_bwd": (_i, [_i, _i, _f, _f, _f, _i, C.c_void_p]),
+    "gigs_cube_taps": (_i, [_i, _i, _f, _f, _f, C.c_void_p]),
+    "gigs_cube_texture_bwd_gather": (_i, [_i, _i, _i, _f, _f, _f, _i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_latlong_to_cubemap": (_i, [_i, _i, _i, _i, _i, _f, _f, C.c_void_p]),
     "gigs_loss_scratch_floats": (C.c_size_t, [_i, _i, _i]),
     "gigs_l1_ssim_fwd": (_i, [_i, _i, _i, _f, _f, C.c_float, _f, _f, _f, _f, _f, C.c_void_p]),

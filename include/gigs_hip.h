@@ -342,6 +342,15 @@ int gigs_latlong_to_cubemap(int res_y, int res_x, int lat_h, int lat_w, int chan
                             float* cubemap, void* stream);
 int gigs_cube_texture_bwd(int res, int n, const float* dirs, const float* g_out, float* d_cubemap, int planar,
                           void* stream);
+/* The lookup's backward as a gather, for a direction set that does not change between calls (the envmap TV's panorama grid).
+ * gigs_cube_taps exports the four taps of every direction (idx [n,4] texel index or -1, w [n,4]); the caller sorts the valid
+ * ones by texel into a CSR list -- offsets [6 res^2 + 1], ent_sample / ent_w in sample order within a texel -- and
+ * gigs_cube_texture_bwd_gather writes EVERY texel of d_cubemap (no zero-fill needed) as the sum of its entries: one lane per
+ * texel, one wave for each of the n_heavy texels (heavy_ids) that hold more than `heavy` entries.  No atomics: reproducible. */
+int gigs_cube_taps(int res, int n, const float* dirs, int* idx, float* w, void* stream);
+int gigs_cube_texture_bwd_gather(int res, int n, int planar, const int* offsets, const int* ent_sample, const float* ent_w,
+                                 int heavy, int n_heavy, const int* heavy_ids, const float* g_out, float* d_cubemap,
+                                 void* stream);
 
 /* Training-loop glue (gigs-hip extension): the image losses of train.py and the Adam step, one
  * pass each.  Planes are [C,H,W] fp32; `scratch` holds at least gigs_loss_scratch_floats(C,H,W) floats (per-workgroup

@@ -232,14 +232,17 @@ def test_cube_texture_matches_restated_lookup():
     assert planes.shape == (3, 40, 100) and torch.equal(planes.permute(1, 2, 0).reshape(4000, 3), got.detach())
 
 
-def test_env_tv_loss_matches_restatement():
+@pytest.mark.parametrize("size", [(64, 128), (128, 256)])
+def test_env_tv_loss_matches_restatement(size, monkeypatch):
+    """(128, 256): 32 768 directions -- the lookup's backward runs as the cached gather (pbr/texture.py), whose pole texels
+    hold hundreds of entries (the one-wave-per-texel part); compared with the restatement and with the atomic scatter."""
     import losses
     from oracle import train_glue_ref as ref
     dev = _dev()
     g = torch.Generator().manual_seed(22)
     base = (0.5 + 0.25 * torch.randn(6, 32, 32, 3, generator=g)).abs()
-    dirs = ref.envmap_dirs_ref((64, 128))
-    got_dirs = losses.get_envmap_dirs((64, 128), device=dev)
+    dirs = ref.envmap_dirs_ref(size)
+    got_dirs = losses.get_envmap_dirs(size, device=dev)
     assert (got_dirs.cpu() - dirs).abs().max().item() < 1e-6
     br = base.double().requires_grad_(True)
     want = ref.env_tv_ref(br, dirs)
@@ -249,6 +252,20 @@ def test_env_tv_loss_matches_restatement():
     got.backward()
     assert abs(got.item() - want.item()) <= 2e-5 * abs(want.item())
     assert (b.grad.cpu().double() - br.grad).abs().max().item() <= 1e-4 * br.grad.abs().max().item()
+    if size[0] * size[1] >= 1 << 14:
+        import pbr.texture as tex
+        d_dev = dirs.to(dev)
+        b1 = base.to(dev).requires_grad_(True)
+        losses.env_tv_loss(b1, d_dev).backward()
+        plan = tex._gather_plan(d_dev.contiguous().float(), 32, size[0] * size[1], build=False)
+        assert plan is not None and plan["n_heavy"] > 0  # the gather ran, poles included
+        b2 = base.to(dev).requires_grad_(True)
+        losses.env_tv_loss(b2, d_dev).backward()
+        assert torch.equal(b1.grad, b2.grad)  # reproducible
+        monkeypatch.setenv("GIGS_CUBE_BWD_GATHER", "0")
+        b3 = base.to(dev).requires_grad_(True)
+        losses.env_tv_loss(b3, d_dev).backward()
+        assert (b3.grad - b1.grad).abs().max().item() <= 1e-5 * b1.grad.abs().max().item()
 
 
 @pytest.mark.parametrize("P,K,misalign", [(1003, 9, False), (1003, 9, True), (130, 16, False), (64, 4, False), (77, 1, False)])
