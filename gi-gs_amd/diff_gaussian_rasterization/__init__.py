@@ -734,17 +734,21 @@ class _SSR(torch.autograd.Function):
         (color, abd) = _C.SSR(image_width, image_height, focal_x, focal_y, radius, bias, thick, delta, step,
                               start, normal, pos, rgb, albedo, roughness, metallic, F0)
         ctx.save_for_backward(roughness, metallic, abd)
+        ctx.set_materialize_grads(False)  # `abd` is never differentiated: no zero tensor for it
         return (color, abd)
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_abd=None):
         roughness, metallic, abd = ctx.saved_tensors
         # closed form, R/…/__init__.py:671-673 (gigs_ssr_backward)
-        g = grad_out_color.contiguous().float()
-        grad_albedo = torch.empty_like(abd)
-        with torch.cuda.device(abd.device):
-            gigs_lib.check(_lib.gigs_ssr_backward(int(abd.shape[2]), int(abd.shape[1]), g.data_ptr(), abd.data_ptr(),
-                                                  grad_albedo.data_ptr(), _stream()), "SSR backward")
+        if grad_out_color is None:
+            grad_albedo = torch.zeros_like(abd)
+        else:
+            g = grad_out_color.contiguous().float()
+            grad_albedo = torch.empty_like(abd)
+            with torch.cuda.device(abd.device):
+                gigs_lib.check(_lib.gigs_ssr_backward(int(abd.shape[2]), int(abd.shape[1]), g.data_ptr(), abd.data_ptr(),
+                                                      grad_albedo.data_ptr(), _stream()), "SSR backward")
         grad_roughness = torch.zeros_like(roughness)
         grad_metallic = torch.zeros_like(metallic)
         return (None, None, None, None, None, None, None, None, None, None, None, None, None,

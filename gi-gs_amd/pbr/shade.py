@@ -66,6 +66,7 @@ class _PbrShade(torch.autograd.Function):
                 diffuse, *specular):
         dev = normals.device
         H, W, _ = normals.shape
+        ctx.set_materialize_grads(False)  # an output the loss does not use: None, not a zero tensor (the kernel takes NULL)
         f = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
         normals, view_dirs, albedo, roughness = f(normals), f(view_dirs), f(albedo), f(roughness)
         occlusion, metallic, background = f(occlusion), f(metallic), f(background)

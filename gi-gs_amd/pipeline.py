@@ -143,6 +143,9 @@ class _GbufferPostFused(torch.autograd.Function):
                                                  normals_view.data_ptr(), mask.data_ptr(), None, onv.data_ptr(), s),
                            "gbuffer_post")
         ctx.save_for_backward(nm, vm)
+        # four of the five outputs carry no gradient: without this autograd hands the backward a zero tensor for each
+        # (two [3,H,W] float fills and two bool fills, 0.05 ms per stage-1 iteration at 800x800)
+        ctx.set_materialize_grads(False)
         nfd_mask_b, mask_b = nfd_mask.bool(), mask.bool()
         ctx.mark_non_differentiable(nfd_out, nfd_mask_b, mask_b, onv)
         return nfd_out, nfd_mask_b, normals_view, mask_b, onv
@@ -153,6 +156,8 @@ class _GbufferPostFused(torch.autograd.Function):
         lib = gigs_lib.lib()
         nm, vm = ctx.saved_tensors
         _, H, W = nm.shape
+        if g_normals_view is None:
+            return None, None, None, None
         g = g_normals_view.contiguous().float()
         scratch, g_nm = torch.empty_like(nm), torch.empty_like(nm)
         with torch.cuda.device(nm.device):
