@@ -914,7 +914,13 @@ def _fused_begin(self, start_event=None):
     else:
         self.side.wait_event(self.blend_begin)
     with torch.cuda.stream(self.side):
-        return self.mips(self.dummy)
+        out = self.mips(self.dummy)
+        # what the shade waits for: an event of its own, so that work queued on this stream later (the regularisers,
+        # _fused_step) is not waited for with it
+        if getattr(self, "lights_ready", None) is None:
+            self.lights_ready = torch.cuda.Event()
+        self.lights_ready.record()
+    return out
 
 
 def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, normal_map, out_normal_view, albedo_map,
@@ -923,7 +929,19 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     from stage2_fused import Stage2FusedBack
     H, W = cam["image_height"], cam["image_width"]
     main = torch.cuda.current_stream()
-    main.wait_stream(self.side)
+    # The regularisers (BRDF TV, envmap TV: ~15 small kernels forward, as many backward) read the rasterizer's planes and
+    # the light only -- not the shade, the marches or the loss -- so they go to the light's stream, idle by now, beside the
+    # shade and the SSR march; autograd runs their backward there too, beside the shade backward (GIGS_REG_SIDE=0: on the
+    # caller's stream behind the loss, where they sit on the critical path on both ways: 0.2 ms per iteration at C2).
+    reg_side = self.regularizer is not None and os.environ.get("GIGS_REG_SIDE", "1") == "1"
+    if reg_side:
+        if getattr(self, "raster_done", None) is None:
+            self.raster_done = torch.cuda.Event()
+        self.raster_done.record()  # the rasterizer's planes exist: all the regularisers wait for
+    if getattr(self, "lights_ready", None) is not None:
+        main.wait_event(self.lights_ready)
+    else:
+        main.wait_stream(self.side)
     for t in lights:
         t.record_stream(main)
     args = (normal_map.detach(), out_normal_view.detach(), albedo_map, roughness_map, metallic_map,
@@ -946,7 +964,20 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     loss, render_rgb, render_direct, IRR = self.back(*args)
     if extra_loss is not None:
         loss = loss + extra_loss(normal_map, albedo_map, roughness_map, metallic_map)
-    if self.regularizer is not None:
+    if reg_side:
+        # queued (host order) behind the fused node so that autograd, which walks later nodes first, starts their backward
+        # before the shade backward; the stream waits only for the rasterizer's planes
+        maps = dict(normal_map=normal_map, albedo_map=albedo_map, roughness_map=roughness_map, metallic_map=metallic_map,
+                    gt_image=gt_image)
+        self.side.wait_event(self.raster_done)
+        with torch.cuda.stream(self.side):
+            reg = self.regularizer(maps)
+        for t in maps.values():
+            t.record_stream(self.side)
+        main.wait_stream(self.side)
+        reg.record_stream(main)
+        loss = loss + reg
+    elif self.regularizer is not None:
         loss = loss + self.regularizer(dict(normal_map=normal_map, albedo_map=albedo_map, roughness_map=roughness_map,
                                             metallic_map=metallic_map, gt_image=gt_image))
     res = dict(loss=loss.detach(), render_rgb=render_rgb, render_direct=render_direct, IRR=IRR,

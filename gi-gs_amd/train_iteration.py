@@ -59,12 +59,15 @@ class Stage2Regularizer:
         self.envmap_dirs = envmap_dirs if envmap_dirs is not None else losses.get_envmap_dirs(device=light.base.device)
 
     def __call__(self, maps: Dict[str, torch.Tensor]) -> torch.Tensor:
+        # the envmap term's nodes are created first: autograd walks later nodes first, so the BRDF term's backward -- whose
+        # gradients the rasterizer's backward waits for -- runs ahead of the panorama lookup's (the values do not change)
+        env = losses.env_tv_loss(self.light.base, self.envmap_dirs) if self.env_tv_weight != 0.0 else None
         mask = losses.nonzero_mask(maps["normal_map"])                  # gaussian_renderer/__init__.py:158
         rough = maps["roughness_map"] * (1.0 - 0.04) + 0.04             # train.py:297-298
         brdf = torch.cat([maps["albedo_map"], rough, maps["metallic_map"]], dim=0)
         loss = self.brdf_tv_weight * losses.get_masked_tv_loss(mask, maps["gt_image"], brdf)
-        if self.env_tv_weight != 0.0:
-            loss = loss + self.env_tv_weight * losses.env_tv_loss(self.light.base, self.envmap_dirs)
+        if env is not None:
+            loss = loss + self.env_tv_weight * env
         return loss
 
 
