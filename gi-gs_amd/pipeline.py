@@ -457,6 +457,7 @@ class WholeStepGraph:
                 with torch.no_grad():
                     o.post_update()  # idempotent (a clamp): run once outside the capture as its warm-up
             torch.cuda.synchronize()
+        self._seed = torch.ones((), dtype=torch.float32, device=self.dev)
         _collect_idle()
         was = gc.isenabled()
         gc.disable()  # see graphed(): a cyclic-GC pass during capture may destroy HIP objects, which HIP refuses
@@ -482,7 +483,10 @@ class WholeStepGraph:
             light_ops.bwd_head_start_ns = int(1e3 * float(os.environ.get("GIGS_LIGHT_BWD_HEAD_START_US", "10")))
             try:
                 with torch.cuda.graph(gb, pool=gf.pool(), stream=cap, capture_error_mode="thread_local"):
-                    grads = torch.autograd.grad(loss, params + [res["viewspace_points"]], allow_unused=True)
+                    # the seed gradient as a persistent tensor: autograd's own ones_like(loss) is a fill node at the head of
+                    # the backward graph
+                    grads = torch.autograd.grad(loss, params + [res["viewspace_points"]], grad_outputs=self._seed.reshape(loss.shape),
+                                                allow_unused=True)
             finally:
                 light_ops.bwd_head_start_ns = 0
             del loss
