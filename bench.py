@@ -643,7 +643,7 @@ def run(args):
                                    % (args.config.upper(), cname, P // 1000, W, H, args.sh_degree, gi["step"], gi["start"],
                                       gi["delta"]),
                        "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade, "hip_graphs": args.graphs, "fused_glue": args.fused,
-                       "gi_march": os.environ.get("GIGS_GI_MARCH", "proj (default)"),
+                       "gi_march": gigs_lib.GI_MARCHES[gigs_lib.current().option("gi_march")],
                        "rasterizer": ("one hipGraph per view" if inference and args.graphs == "on" else
                                       "hipGraph (GIGS_RASTER_GRAPH=1)" if os.environ.get("GIGS_RASTER_GRAPH", "0") == "1"
                                       else "whole step = 2 hand-captured hipGraphs (fwd, bwd), asynchronous binning"

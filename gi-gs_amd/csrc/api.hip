@@ -9,7 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
-#include <atomic>
+#include <algorithm>
+#include <new>
 #include <mutex>
 #include <vector>
 
@@ -100,17 +101,39 @@ const char* kStageNames[kNumStages] = {
   "stage2_loss_fwd", "stage2_loss_bwd", "l1_ssim_fwd", "l1_ssim_bwd", "tv_loss_fwd", "tv_loss_bwd", "masked_l1",
   "adam_step", "densify_stats", "gather_rows", "dist2", "activate_fwd", "activate_bwd"};
 
-// optional event recorded on the forward's stream right before the blend kernel is launched (gigs_set_blend_begin_event)
-std::atomic<void*> g_blend_begin_event{nullptr};
-// gigs_set_async_binning: capacity > 0 -> the next forwards bin into a chunk of that many instances, read nothing back
-std::atomic<unsigned> g_async_capacity{0};
-std::atomic<void*> g_async_counters{nullptr};
-
-// GIGS_BINNING=legacy: the reference-shaped scan / duplicate / global radix sort / tile-ranges path
-bool binning_bucketed() {
-  const char* e = getenv("GIGS_BINNING");
-  return !(e && strcmp(e, "legacy") == 0);
+// ---- contexts (include/gigs_hip.h) -------------------------------------------------------------------------------
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
 }
+gigs::Options options_from_env() {
+  gigs::Options o;
+  const char* b = getenv("GIGS_BINNING");
+  o.binning_legacy = (b && strcmp(b, "legacy") == 0) ? 1 : 0;
+  o.bucket_max_mean = env_int("GIGS_BUCKET_MAX_MEAN", gigs::kBucketMaxMeanList);
+  const char* ll = getenv("GIGS_LONG_LISTS");
+  o.long_lists = (ll && ll[0]) ? (ll[0] == '1' ? 1 : 0) : -1;
+  o.bucket_target = std::max(256, env_int("GIGS_BUCKET_TARGET", 1536));
+  o.blend_cull = env_int("GIGS_BLEND_CULL", 1) != 0;
+  o.pre_bwd_sh_skip = env_int("GIGS_PRE_BWD_SH_SKIP", 1) != 0;
+  o.gi_march = 4;
+  if (const char* e = getenv("GIGS_GI_MARCH")) {
+    static const char* names[] = {"exact", "hoist", "hoist_fma", "proj_nr", "proj"};
+    for (int i = 0; i < 5; i++)
+      if (strcmp(e, names[i]) == 0) o.gi_march = i;
+  }
+  o.gi_cert = env_int("GIGS_GI_CERT", 1) != 0;
+  o.gi_interleave = env_int("GIGS_GI_INTERLEAVE", 1) != 0;
+  o.gi_tile_log2w = env_int("GIGS_GI_TILE_LOG2W", 3);
+  if (o.gi_tile_log2w < 0 || o.gi_tile_log2w > 6) o.gi_tile_log2w = 3;
+  o.gi_zero_rays = env_int("GIGS_GI_ZERO_RAYS", 0) != 0;
+  o.spec_max8 = env_int("GIGS_SPEC_MAX8", 128);
+  o.spec_max16 = env_int("GIGS_SPEC_MAX16", 1500);
+  o.shade_lds_floats = env_int("GIGS_SHADE_LDS_FLOATS", 30 * 1024);
+  o.shade_bwd_blocks = std::max(0, env_int("GIGS_SHADE_BWD_BLOCKS", 0));
+  return o;
+}
+const gigs::Ctx& ctx_of(const gigs_ctx* c) { return c ? *reinterpret_cast<const gigs::Ctx*>(c) : gigs::default_ctx(); }
 
 struct ProfRec { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -153,8 +176,20 @@ struct StageScope {
 
 }  // namespace
 
+namespace gigs {
+const Options& default_options() {
+  static const Options o = options_from_env();  // the environment is read here, once
+  return o;
+}
+const Ctx& default_ctx() {
+  static const Ctx c = {default_options(), 0u, nullptr, nullptr};
+  return c;
+}
+}  // namespace gigs
+
 // helpers for the other translation units of the library (not part of the ABI)
 extern "C" {
+__attribute__((visibility("hidden"))) const gigs::Options* gigs_internal_options(const gigs_ctx* ctx) { return &ctx_of(ctx).opt; }
 __attribute__((visibility("hidden"))) int gigs_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 __attribute__((visibility("hidden"))) void gigs_internal_stage_begin(int stage, void* stream, void** token) {
   *token = new StageScope(stage, (hipStream_t)stream);
@@ -209,7 +244,46 @@ long long gigs_image_offset(int width, int height, int which) {
   return (long long)((const char*)ptrs[which] - base);
 }
 
-void gigs_set_blend_begin_event(void* hip_event) { g_blend_begin_event.store(hip_event); }
+gigs_ctx* gigs_ctx_create(void) {
+  gigs::Ctx* c = new (std::nothrow) gigs::Ctx(gigs::default_ctx());
+  if (!c) fail(GIGS_ERR_ALLOC, "gigs_ctx_create: out of host memory");
+  return reinterpret_cast<gigs_ctx*>(c);
+}
+void gigs_ctx_destroy(gigs_ctx* ctx) { delete reinterpret_cast<gigs::Ctx*>(ctx); }
+
+int gigs_ctx_get_options(const gigs_ctx* ctx, gigs_options* out) {
+  if (!out || out->struct_bytes < (int)sizeof(gigs_options)) return fail(GIGS_ERR_INVALID, "gigs_ctx_get_options: set struct_bytes = sizeof(gigs_options)");
+  const gigs::Options& o = ctx_of(ctx).opt;
+  out->struct_bytes = (int)sizeof(gigs_options);
+  out->binning_legacy = o.binning_legacy; out->bucket_max_mean = o.bucket_max_mean; out->long_lists = o.long_lists;
+  out->bucket_target = o.bucket_target; out->blend_cull = o.blend_cull; out->pre_bwd_sh_skip = o.pre_bwd_sh_skip;
+  out->gi_march = o.gi_march; out->gi_cert = o.gi_cert; out->gi_interleave = o.gi_interleave;
+  out->gi_tile_log2w = o.gi_tile_log2w; out->gi_zero_rays = o.gi_zero_rays; out->spec_max8 = o.spec_max8;
+  out->spec_max16 = o.spec_max16; out->shade_lds_floats = o.shade_lds_floats; out->shade_bwd_blocks = o.shade_bwd_blocks;
+  return 0;
+}
+int gigs_ctx_set_options(gigs_ctx* ctx, const gigs_options* in) {
+  if (!ctx) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_options: the default context is immutable, create one");
+  if (!in || in->struct_bytes < (int)sizeof(gigs_options)) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_options: set struct_bytes = sizeof(gigs_options)");
+  if (in->gi_march < 0 || in->gi_march > 4) return fail(GIGS_ERR_INVALID, "gi_march must be 0..4");
+  if (in->gi_tile_log2w < 0 || in->gi_tile_log2w > 6) return fail(GIGS_ERR_INVALID, "gi_tile_log2w must be 0..6");
+  if (in->long_lists < -1 || in->long_lists > 1) return fail(GIGS_ERR_INVALID, "long_lists must be -1, 0 or 1");
+  if (in->bucket_target < 256 || in->bucket_max_mean < 0) return fail(GIGS_ERR_INVALID, "bucket_target >= 256, bucket_max_mean >= 0");
+  if (in->spec_max8 < 0 || in->spec_max16 < in->spec_max8) return fail(GIGS_ERR_INVALID, "0 <= spec_max8 <= spec_max16");
+  if (in->shade_lds_floats < 0 || in->shade_bwd_blocks < 0) return fail(GIGS_ERR_INVALID, "shade_lds_floats, shade_bwd_blocks >= 0");
+  gigs::Options& o = reinterpret_cast<gigs::Ctx*>(ctx)->opt;
+  o.binning_legacy = in->binning_legacy != 0; o.bucket_max_mean = in->bucket_max_mean; o.long_lists = in->long_lists;
+  o.bucket_target = in->bucket_target; o.blend_cull = in->blend_cull != 0; o.pre_bwd_sh_skip = in->pre_bwd_sh_skip != 0;
+  o.gi_march = in->gi_march; o.gi_cert = in->gi_cert != 0; o.gi_interleave = in->gi_interleave != 0;
+  o.gi_tile_log2w = in->gi_tile_log2w; o.gi_zero_rays = in->gi_zero_rays != 0; o.spec_max8 = in->spec_max8;
+  o.spec_max16 = in->spec_max16; o.shade_lds_floats = in->shade_lds_floats; o.shade_bwd_blocks = in->shade_bwd_blocks;
+  return 0;
+}
+int gigs_ctx_set_blend_begin_event(gigs_ctx* ctx, void* hip_event) {
+  if (!ctx) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_blend_begin_event: the default context is immutable, create one");
+  reinterpret_cast<gigs::Ctx*>(ctx)->blend_begin_event = hip_event;
+  return 0;
+}
 
 __global__ void __launch_bounds__(64) stream_delay_kernel(unsigned ticks) {
   // wall_clock64: constant 100 MHz counter; every wave reaches the exit after at most `ticks` (<= 100 000) ticks
@@ -224,9 +298,12 @@ int gigs_stream_delay(unsigned nanoseconds, void* stream) {
   return hipGetLastError() == hipSuccess ? 0 : gigs_internal_fail(GIGS_ERR_HIP, "stream_delay: launch failed");
 }
 
-void gigs_set_async_binning(int r_capacity, unsigned* device_counters) {
-  g_async_capacity.store(r_capacity > 0 ? (unsigned)r_capacity : 0u);
-  g_async_counters.store(r_capacity > 0 ? (void*)device_counters : nullptr);
+int gigs_ctx_set_async_binning(gigs_ctx* ctx, int r_capacity, unsigned* device_counters) {
+  if (!ctx) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_async_binning: the default context is immutable, create one");
+  gigs::Ctx* c = reinterpret_cast<gigs::Ctx*>(ctx);
+  c->async_capacity = r_capacity > 0 ? (unsigned)r_capacity : 0u;
+  c->async_counters = r_capacity > 0 ? device_counters : nullptr;
+  return 0;
 }
 
 void gigs_profile_begin(void) {
@@ -261,7 +338,7 @@ const char* gigs_profile_stage_name(int stage) {
   return (stage >= 0 && stage < kNumStages) ? kStageNames[stage] : "";
 }
 
-int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer,
+int gigs_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer,
                  void* binning_user, gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M,
                  const float* background, int width, int height, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* opacities,
@@ -275,6 +352,8 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
                  int* radii, int debug, void* stream) {
   (void)prefiltered;  // the reference only uses it to trap on an impossible state (auxiliary.h:167-171)
   hipStream_t s = (hipStream_t)stream;
+  const gigs::Ctx& cx = ctx_of(ctx);
+  const gigs::Options& opt = cx.opt;
   if (P < 0 || width <= 0 || height <= 0) return fail(GIGS_ERR_INVALID, "bad P / image size");
   if (P == 0) return 0;  // rasterize_points.cu:190-191: outputs stay as the caller initialised them
   if (!geometryBuffer || !binningBuffer || !imageBuffer) return fail(GIGS_ERR_INVALID, "null allocation callback");
@@ -318,15 +397,14 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
   STAGE_CHECK("preprocess");
   int num_rendered = 0;
   gigs::BinningState bin;
-  const unsigned async_cap = g_async_capacity.load();
-  const bool bucket = binning_bucketed() && T <= (size_t)gigs::kBinMaxTiles;
-  if (async_cap > 0 && !bucket) return fail(GIGS_ERR_INVALID, "asynchronous binning needs the tile-bucketed path (GIGS_BINNING, <= %d tiles)", gigs::kBinMaxTiles);
-  static const int max_mean = [] { const char* e = getenv("GIGS_BUCKET_MAX_MEAN"); return e ? atoi(e) : gigs::kBucketMaxMeanList; }();
-  // dense scene (mean list above kBucketMaxMeanList): lists beyond 8192 keys are partitioned by sampled splitters before the
-  // LDS sorts (binning.hip).  GIGS_LONG_LISTS=1 / 0 forces / forbids it.
+  const unsigned async_cap = cx.async_capacity;
+  const bool bucket = !opt.binning_legacy && T <= (size_t)gigs::kBinMaxTiles;
+  if (async_cap > 0 && !bucket) return fail(GIGS_ERR_INVALID, "asynchronous binning needs the tile-bucketed path (options.binning_legacy = 0, <= %d tiles)", gigs::kBinMaxTiles);
+  // dense scene (mean list above options.bucket_max_mean): lists beyond 8192 keys are partitioned by sampled splitters before
+  // the LDS sorts (binning.hip).  options.long_lists = 1 / 0 forces / forbids it.
   auto long_lists = [&](size_t est_mean) {
-    if (const char* e = getenv("GIGS_LONG_LISTS")) return e[0] == '1';
-    return est_mean > (size_t)max_mean;
+    if (opt.long_lists >= 0) return opt.long_lists == 1;
+    return est_mean > (size_t)opt.bucket_max_mean;
   };
   bool dense = false;
   if (bucket) {
@@ -337,7 +415,7 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
     {
       StageScope sc(kDuplicate, s);
       gigs::launch_bin_count(P, radii, a.gx, a.gy, geom, img, s);
-      gigs::launch_bin_prefix(P, (int)T, async_cap > 0 ? async_cap : 0x7fffffffu, img, (unsigned*)g_async_counters.load(), s);
+      gigs::launch_bin_prefix(P, (int)T, async_cap > 0 ? async_cap : 0x7fffffffu, img, cx.async_counters, s);
     }
     STAGE_CHECK("bin count / prefix");
     if (async_cap > 0) {
@@ -363,7 +441,7 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
     {
       StageScope sc(kSort, s);
       gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, geom, bin, img, s);
-      if (gigs::launch_bin_sort((int)T, P, dense && num_rendered > 0, (unsigned)num_rendered, bin, img, s) != 0)
+      if (gigs::launch_bin_sort((int)T, P, dense && num_rendered > 0, (unsigned)opt.bucket_target, (unsigned)num_rendered, bin, img, s) != 0)
         return fail(GIGS_ERR_HIP, "bin_sort: cannot fork the sort streams");
     }
     STAGE_CHECK("bin scatter / sort");
@@ -405,11 +483,11 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
   }
   STAGE_CHECK("identifyTileRanges");
   }
-  if (void* ev = g_blend_begin_event.load()) HIP_TRY(hipEventRecord((hipEvent_t)ev, s));
+  if (void* ev = cx.blend_begin_event) HIP_TRY(hipEventRecord((hipEvent_t)ev, s));
   {
     StageScope sc(kBlendFwd, s);
     gigs::launch_blend_fwd(a, geom, bin, img, out_color, out_opacity, out_depth, out_normal,
-                           out_normal_view, out_pos, out_albedo, out_roughness, out_metallic, s);
+                           out_normal_view, out_pos, out_albedo, out_roughness, out_metallic, opt.blend_cull, s);
   }
   STAGE_CHECK("render");
   return num_rendered;
@@ -427,7 +505,7 @@ char* lite_chunk_alloc(size_t n, void* user) {
 }
 }  // namespace
 
-int gigs_lite_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer, void* binning_user,
+int gigs_lite_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer, void* binning_user,
                       gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M, const float* background, int width,
                       int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -449,14 +527,14 @@ int gigs_lite_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_
   float* spare = reinterpret_cast<float*>(up(ib + img_bytes));    // normal 3N | normal_view 3N | pos 3N | albedo 3N | roughness N | metallic N
   gigs::launch_zero_words(reinterpret_cast<uint32_t*>(zeros), 8 * (size_t)P, (hipStream_t)stream);
   LiteChunk gc{gb, geom_bytes}, ic{ib, img_bytes};
-  return gigs_forward(lite_chunk_alloc, &gc, binningBuffer, binning_user, lite_chunk_alloc, &ic, P, D, M, background, width, height,
+  return gigs_forward(ctx, lite_chunk_alloc, &gc, binningBuffer, binning_user, lite_chunk_alloc, &ic, P, D, M, background, width, height,
                       means3D, shs, colors_precomp, opacities, zeros, zeros + 3 * (size_t)P, zeros + 6 * (size_t)P,
                       zeros + 7 * (size_t)P, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
                       tan_fovx, tan_fovy, prefiltered, argmax_depth, 0, out_color, out_opacity, out_depth, spare, spare + 3 * N,
                       spare + 6 * N, spare + 9 * N, spare + 12 * N, spare + 13 * N, radii, debug, stream);
 }
 
-int gigs_backward(int P, int D, int M, int R, const float* background, int width, int height,
+int gigs_backward(gigs_ctx* ctx, int P, int D, int M, int R, const float* background, int width, int height,
                   const float* means3D, const float* shs, const float* colors_precomp,
                   const float* normal, const float* albedo, const float* roughness,
                   const float* metallic, const float* scales, const float* rotations,
@@ -517,7 +595,7 @@ int gigs_backward(int P, int D, int M, int R, const float* background, int width
   STAGE_CHECK("render backward");
   {
     StageScope sc(kPreprocessBwd, s);
-    gigs::launch_preprocess_bwd(a, geom, s);
+    gigs::launch_preprocess_bwd(a, geom, ctx_of(ctx).opt.pre_bwd_sh_skip, s);
   }
   STAGE_CHECK("preprocess backward");
   return 0;
@@ -561,13 +639,13 @@ size_t gigs_gi_scratch_bytes(int width, int height) {
   return gigs::gi_scratch_bytes(width, height);
 }
 
-int gigs_ssao_ex(int width, int height, float focal_x, float focal_y, float radius, float bias,
+int gigs_ssao_ex(gigs_ctx* ctx, int width, int height, float focal_x, float focal_y, float radius, float bias,
                  float thick, float delta, int step, int start, const float* normal_view,
                  const float* pos, float* occlusion, void* scratch, void* stream) {
   if (width <= 0 || height <= 0 || !normal_view || !pos || !occlusion) return fail(GIGS_ERR_INVALID, "bad argument");
   if (width >= (1 << 15) || height >= (1 << 15)) return fail(GIGS_ERR_INVALID, "image side above 32767 pixels");
   StageScope sc(kSsao, (hipStream_t)stream);
-  const int rc = gigs::launch_ssao(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
+  const int rc = gigs::launch_ssao(ctx_of(ctx).opt, width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
                                    normal_view, pos, occlusion, scratch, (hipStream_t)stream);
   if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
   if (rc) return fail(GIGS_ERR_HIP, "ray table upload failed");
@@ -577,11 +655,11 @@ int gigs_ssao_ex(int width, int height, float focal_x, float focal_y, float radi
 int gigs_ssao(int width, int height, float focal_x, float focal_y, float radius, float bias,
               float thick, float delta, int step, int start, const float* normal_view,
               const float* pos, float* occlusion, void* stream) {
-  return gigs_ssao_ex(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, normal_view, pos,
+  return gigs_ssao_ex(nullptr, width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, normal_view, pos,
                       occlusion, nullptr, stream);
 }
 
-int gigs_ssr_ex(int width, int height, float focal_x, float focal_y, float radius, float bias,
+int gigs_ssr_ex(gigs_ctx* ctx, int width, int height, float focal_x, float focal_y, float radius, float bias,
                 float thick, float delta, int step, int start, const float* normal_view,
                 const float* pos, const float* rgb, const float* albedo, const float* roughness,
                 const float* metallic, const float* F0, float* color, float* abd, void* scratch, void* stream) {
@@ -589,7 +667,7 @@ int gigs_ssr_ex(int width, int height, float focal_x, float focal_y, float radiu
     return fail(GIGS_ERR_INVALID, "bad argument");
   if (width >= (1 << 15) || height >= (1 << 15)) return fail(GIGS_ERR_INVALID, "image side above 32767 pixels");
   StageScope sc(kSsr, (hipStream_t)stream);
-  const int rc = gigs::launch_ssr(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
+  const int rc = gigs::launch_ssr(ctx_of(ctx).opt, width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
                                   normal_view, pos, rgb, albedo, roughness, metallic, F0, color, abd, scratch,
                                   (hipStream_t)stream);
   if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
@@ -601,7 +679,7 @@ int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, 
              float thick, float delta, int step, int start, const float* normal_view,
              const float* pos, const float* rgb, const float* albedo, const float* roughness,
              const float* metallic, const float* F0, float* color, float* abd, void* stream) {
-  return gigs_ssr_ex(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, normal_view, pos, rgb,
+  return gigs_ssr_ex(nullptr, width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, normal_view, pos, rgb,
                      albedo, roughness, metallic, F0, color, abd, nullptr, stream);
 }
 

@@ -778,12 +778,12 @@ void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsig
 
 // ---- dense scenes: the long lists' partition + bucket sorts (tables in the binning chunk's sort_space, which the
 // bucketed path does not otherwise use; sort_size_cached() covers both uses)
-void launch_long_lists(int T, int P, unsigned capacity, const BinningState& b, const ImageState& img, hipStream_t s) {
+void launch_long_lists(int T, int P, unsigned target, unsigned capacity, const BinningState& b, const ImageState& img, hipStream_t s) {
   char* space = b.sort_space;
   LongState st = LongState::fromChunk(space, (size_t)T, (size_t)capacity);
   const unsigned ib = bin_index_bits(P);
   launch_zero_words(st.counts, 8, s);
-  static const unsigned target = [] { const char* e = getenv("GIGS_BUCKET_TARGET"); return e ? (unsigned)std::max(256, atoi(e)) : kBucketTarget; }();
+  if (target < 256u) target = kBucketTarget;  // gigs_options.bucket_target
   hipLaunchKernelGGL(long_plan_kernel, dim3(std::min(T, 1024)), dim3(256), 0, s, T, ib, target, img.ranges, b.keys_unsorted, st);
   hipLaunchKernelGGL(long_chunks_kernel<false>, dim3(2048), dim3(256), 0, s, img.ranges, b.keys_unsorted, b.keys, st);
   hipLaunchKernelGGL(long_prefix_kernel, dim3(std::min(T, 1024)), dim3(64), 0, s, img.ranges, st);
@@ -793,14 +793,15 @@ void launch_long_lists(int T, int P, unsigned capacity, const BinningState& b, c
   hipLaunchKernelGGL(long_sort_small_kernel, dim3(2048), dim3(256), 0, s, ib, st, b.keys, b.point_list);
 }
 
-int launch_bin_sort(int T, int P, bool long_lists, unsigned capacity, const BinningState& b, const ImageState& img, hipStream_t s) {
+int launch_bin_sort(int T, int P, bool long_lists, unsigned bucket_target, unsigned capacity, const BinningState& b, const ImageState& img,
+                    hipStream_t s) {
   // (Running size classes concurrently on forked streams was tried: with the light's side stream and two sort streams
   // the runtime ran out of hardware queues and folded the light filter onto the main queue -- 25 % slower.  Hence one
   // kernel that holds lists of every length up to 8192 keys, and a second for the longer ones: in a sparse scene it
   // sorts them whole (usually there are none), in a dense one they are partitioned first (launch_long_lists).)
   const unsigned ib = bin_index_bits(P);
   if (long_lists)
-    launch_long_lists(T, P, capacity, b, img, s);
+    launch_long_lists(T, P, bucket_target, capacity, b, img, s);
   else
     hipLaunchKernelGGL(bin_sort_kernel<true>, dim3(std::min(T, 256)), dim3(1024), 0, s, T, ib, img.tile_order, img.ranges,
                        b.keys_unsorted, b.keys, b.point_list);

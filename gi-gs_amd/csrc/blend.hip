@@ -413,12 +413,10 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
 void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& b,
                       const ImageState& im, float* out_color, float* out_opacity,
                       float* out_depth, float* out_normal, float* out_normal_view, float* out_pos,
-                      float* out_albedo, float* out_roughness, float* out_metallic, hipStream_t s) {
+                      float* out_albedo, float* out_roughness, float* out_metallic, int cull, hipStream_t s) {
   BlendOut o{out_color, out_opacity, out_depth, out_normal, out_normal_view,
              out_pos, out_albedo, out_roughness, out_metallic};
-  // GIGS_BLEND_CULL=0 disables the quadrant cull (diagnostic: the outputs must not change by a bit)
-  const char* e = getenv("GIGS_BLEND_CULL");
-  const int cull = !(e && e[0] == '0');
+  // cull = 0 (gigs_options.blend_cull) disables the quadrant cull (diagnostic: the outputs must not change by a bit)
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(a.gx * a.gy), dim3(GIGS_TILE), 0, s, a.W, a.H, a.gx,
                      im.ranges, b.point_list, g.brec, a.viewmatrix, a.background, im.n_contrib,
                      im.final_T, o, a.argmax_depth, a.inference, b.hit_mask, cull, im.tile_order);

@@ -113,55 +113,93 @@ void launch_depth_to_normal(int W, int H, float fx, float fy, const float* viewm
 // ------------------------------------------------------------------------------------------
 // Ray table: per ray two float4 -- {ts.x, ts.y, ts.z, cos(theta)}, {sin(theta), w, 0, 0}
 // with ts = normalize(sin t cos p, sin t sin p, cos t) and w = cos t * sin t.
+//
+// Zero-weight rays.  The reference's theta loop starts at 0 (forward.cu:681, 797): sin(0) = 0, so for every azimuth
+// the first ray is the SAME direction (0, 0, 1) -- the pixel's normal -- with weight w = cos * sin = 0.  SSAO adds
+// `w` for a hit (forward.cu:711: occ += 0, a no-op) and `w` to the sample sum (:690, again + 0); SSR adds
+// rgb * cos * sin = +-0, or NaN when the hit pixel's rgb is not finite (forward.cu:824-826), identically for all of
+// them.  So the table holds the rays with w != 0 first, in the reference's loop order (`n_live`), and the zero-weight
+// ones behind them (`n_dead`; 32 of 512 at delta = 0.0625): SSAO marches the live ones only, SSR the live ones plus ONE
+// of the dead ones (its +-0 / NaN applied once is the same as applied 32 times: x + 0 = x, NaN is sticky); the
+// sample counts (SSAO's sum of weights, SSR's nrSamples = all rays) are unchanged.  gigs_options.gi_zero_rays = 1
+// marches every dead ray as well, after the live ones -- same partial sums, same bits (tested): the proof that the
+// cut is exact.  The dead rays are recognised by value (sin = 0 and ts.xy = 0, all with the same ts.z / cos), not by
+// index; if a delta ever produced zero-weight rays of different directions they would simply count as live.
+// The cache is keyed by (device, delta) and an entry is never modified once built, so concurrent streams and
+// contexts share it safely.
 // ------------------------------------------------------------------------------------------
 struct RayTable {
+  int device = -1;
   float delta = -1.0f;
-  int nrays = 0;
+  int nrays = 0;   // all rays of the reference's loops (SSR's nrSamples)
+  int n_live = 0;  // rays with a non-zero weight: table entries [0, n_live)
+  int n_dead = 0;  // identical zero-weight rays: entries [n_live, n_live + n_dead)
   float sum_w = 0.0f;  // SSAO's nrSamples, accumulated in fp32 in ray order
   float4* dev = nullptr;
-  size_t cap = 0;
 };
 static std::mutex g_ray_mu;
-static RayTable g_ray[16];
+static std::vector<RayTable> g_ray;  // immutable entries
 
 static int get_ray_table(float delta, hipStream_t s, RayTable& out) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -2;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -2;
   std::lock_guard<std::mutex> lk(g_ray_mu);
-  RayTable& t = g_ray[dev];
-  if (t.delta != delta || t.dev == nullptr) {
-    if (!(delta > 1e-4f)) return -1;  // would not terminate / absurd table
-    std::vector<float4> h;
-    const float sampleDelta = delta * kPiF;
-    float sum_w = 0.0f;
-    for (float phi = 0.0f; (double)phi < 2.0 * (double)kPiF; phi += sampleDelta) {
-      for (float theta = 0.0f; (double)theta <= 0.5 * (double)kPiF;
-           theta = (float)((double)theta + (double)sampleDelta * 0.5)) {
-        const float ct = cosf(theta), st = sinf(theta);
-        float tx = st * cosf(phi), ty = st * sinf(phi), tz = ct;
-        const float inv = 1.0f / sqrtf(tx * tx + ty * ty + tz * tz);
-        tx *= inv; ty *= inv; tz *= inv;
-        const float w = ct * st;
-        sum_w += w;
-        h.push_back(make_float4(tx, ty, tz, ct));
-        h.push_back(make_float4(st, w, 0.0f, 0.0f));
-        if (h.size() > (1u << 21)) return -1;
-      }
+  for (const RayTable& t : g_ray)
+    if (t.device == dev && t.delta == delta) { out = t; return 0; }
+  if (!(delta > 1e-4f)) return -1;  // would not terminate / absurd table
+  std::vector<float4> h;
+  const float sampleDelta = delta * kPiF;
+  float sum_w = 0.0f;
+  for (float phi = 0.0f; (double)phi < 2.0 * (double)kPiF; phi += sampleDelta) {
+    for (float theta = 0.0f; (double)theta <= 0.5 * (double)kPiF;
+         theta = (float)((double)theta + (double)sampleDelta * 0.5)) {
+      const float ct = cosf(theta), st = sinf(theta);
+      float tx = st * cosf(phi), ty = st * sinf(phi), tz = ct;
+      const float inv = 1.0f / sqrtf(tx * tx + ty * ty + tz * tz);
+      tx *= inv; ty *= inv; tz *= inv;
+      const float w = ct * st;
+      sum_w += w;
+      h.push_back(make_float4(tx, ty, tz, ct));
+      h.push_back(make_float4(st, w, 0.0f, 0.0f));
+      if (h.size() > (1u << 21)) return -1;
     }
-    const size_t bytes = h.size() * sizeof(float4);
-    if (bytes > t.cap) {
-      // one-time (per device, per larger delta) internal allocation; never freed
-      float4* p = nullptr;
-      if (hipMalloc(&p, bytes) != hipSuccess) return -2;
-      t.dev = p;  // an older, smaller table is intentionally leaked: a kernel may still read it
-      t.cap = bytes;
-    }
-    if (hipMemcpyAsync(t.dev, h.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
-    if (hipStreamSynchronize(s) != hipSuccess) return -2;  // h is pageable and goes out of scope
-    t.delta = delta;
-    t.nrays = (int)(h.size() / 2);
-    t.sum_w = sum_w;
   }
+  // live rays first, the (identical) zero-weight rays behind them
+  const size_t n = h.size() / 2;
+  std::vector<size_t> dead;
+  for (size_t r = 0; r < n; r++) {
+    const float4 a = h[2 * r], b = h[2 * r + 1];
+    if (b.x == 0.0f && b.y == 0.0f && a.x == 0.0f && a.y == 0.0f) dead.push_back(r);
+  }
+  for (size_t k = 1; k < dead.size(); k++)
+    if (h[2 * dead[k]].z != h[2 * dead[0]].z || h[2 * dead[k]].w != h[2 * dead[0]].w) { dead.clear(); break; }
+  std::vector<float4> ordered;
+  ordered.reserve(h.size());
+  {
+    size_t k = 0;
+    for (size_t r = 0; r < n; r++) {
+      if (k < dead.size() && dead[k] == r) { k++; continue; }
+      ordered.push_back(h[2 * r]); ordered.push_back(h[2 * r + 1]);
+    }
+    for (size_t r : dead) { ordered.push_back(h[2 * r]); ordered.push_back(h[2 * r + 1]); }
+  }
+  RayTable t;
+  const size_t bytes = ordered.size() * sizeof(float4);
+  // one-time (per device and delta) internal allocation; never freed, never rewritten
+  if (hipMalloc(&t.dev, bytes ? bytes : 16) != hipSuccess) return -2;
+  if (bytes) {
+    // a blocking copy: the entry is complete before any stream can read it.  (First use of a delta on a device must
+    // therefore happen outside a hipGraph capture -- every capture in this package is preceded by an eager warm-up.)
+    if (hipMemcpy(t.dev, ordered.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return -2;
+  }
+  (void)s;
+  t.device = dev;
+  t.delta = delta;
+  t.nrays = (int)n;
+  t.n_dead = (int)dead.size();
+  t.n_live = (int)(n - dead.size());
+  t.sum_w = sum_w;
+  g_ray.push_back(t);
   out = t;
   return 0;
 }
@@ -171,7 +209,9 @@ struct GiParams {
   float fx, fy, radius, bias, thick;
   int step, start;
   float inv_step;  // exact 1/step when step is a power of two
-  int nrays;
+  int n_live;       // rays [0, n_live) are split across the four waves of a workgroup
+  int nrays;        // rays [n_live, nrays) behind them go round-robin to the waves (zero-weight rays: none for SSAO, one for SSR)
+  int nrays_total;  // all rays of the reference's loops (SSR's nrSamples)
   int tile_log2w;  // the 64 pixels of a workgroup form a (1 << tile_log2w) x (64 >> tile_log2w) rectangle
   int ray_interleave;  // fast marches: wave w takes ray pairs w, w + 4, ... instead of the w-th quarter of the ray set
   int cert_shift;      // certification blocks are (1 << cert_shift)^2 pixels; 0 = no certification table
@@ -923,8 +963,11 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
       const __amdgpu_buffer_rsrc_t pos_z = z_plane_rsrc(pos_map + 2 * HW, HW);
       const float a = 1 + pos.z / 100;
       const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
-      const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
-      const int r0 = wave * chunk, r1 = min(p.nrays, r0 + chunk);
+      // the live rays [0, n_live) are split across the waves; rays behind them (zero-weight ones a caller asked to be
+      // marched all the same: none by default) go round-robin to the waves afterwards, so the live rays' partial sums do
+      // not depend on them
+      const int chunk = (p.n_live + kGiWaves - 1) / kGiWaves;
+      const int r0 = wave * chunk, r1 = min(p.n_live, r0 + chunk);
       const bool mag_ok = gi_mag_ok(pos, a, p.radius);
       if constexpr (kMode > 0) {
         // absurd magnitudes (|pos| >= 2^59) are outside the fast marches' contract: such a pixel takes no hits
@@ -936,10 +979,9 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
           // the four waves of a workgroup share its 64 pixels and split the ray set: contiguous quarters (a quarter of the
           // azimuths each), or interleaved pairs (every wave sees every direction: equal work per wave -- the workgroup
           // holds its slots until its slowest wave is done)
-          const int rs = p.ray_interleave ? 2 * wave : r0, re = p.ray_interleave ? p.nrays : r1;
+          const int rs = p.ray_interleave ? 2 * wave : r0, re = p.ray_interleave ? p.n_live : r1;
           const int rstep = p.ray_interleave ? 2 * kGiWaves : 2;
-          for (int r = rs; r < re; r += rstep) {
-            const int rb = min(r + 1, re - 1);  // an odd chunk marches its last ray twice and counts it once
+          auto pair = [&](int r, int rb) {
             f32x2 Bxy[2], Bz2;
             float bz0, bz1;
             fast_ray<kMode>(p, tbn, ft, a, rays[2 * r], Bxy[0], bz0);
@@ -950,7 +992,9 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
             else march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
             occ += hit[0] >= 0 ? rays[2 * r + 1].y : 0.0f;
             occ += (hit[1] >= 0 && rb != r) ? rays[2 * rb + 1].y : 0.0f;
-          }
+          };
+          for (int r = rs; r < re; r += rstep) pair(r, min(r + 1, re - 1));  // an odd chunk marches its last ray twice and counts it once
+          for (int r = p.n_live + wave; r < p.nrays; r += kGiWaves) pair(r, r);
         }
       } else {
       const unsigned sv_min_bits = gi_sv_min_bits(a, p.radius, p.inv_step);
@@ -969,13 +1013,15 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
 #pragma unroll
         for (int k = 0; k < kGiRays; k++) occ += hit[k] >= 0 ? w[k] : 0.0f;  // x + 0 is exact: ray order kept
       }
-      for (; r < r1; r++) {
-        const float4 ra = rays[2 * r];
+      auto single = [&](int q) {
+        const float4 ra = rays[2 * q];
         const v3 sv = tbn_apply(tbn, ra.x, ra.y, ra.z);
         int hit;
         march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, sv_min_bits, &hit);
-        occ += hit >= 0 ? rays[2 * r + 1].y : 0.0f;
-      }
+        occ += hit >= 0 ? rays[2 * q + 1].y : 0.0f;
+      };
+      for (; r < r1; r++) single(r);
+      for (r = p.n_live + wave; r < p.nrays; r += kGiWaves) single(r);
       }
     }
   }
@@ -1018,8 +1064,8 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
     const __amdgpu_buffer_rsrc_t pos_z = z_plane_rsrc(pos_map + 2 * HW, HW);
     const float a = 1 + pos.z / 100;
     const float cx = float(p.W) / 2.0f, cy = float(p.H) / 2.0f;
-    const int chunk = (p.nrays + kGiWaves - 1) / kGiWaves;
-    const int r0 = wave * chunk, r1 = min(p.nrays, r0 + chunk);
+    const int chunk = (p.n_live + kGiWaves - 1) / kGiWaves;  // see ssao_kernel
+    const int r0 = wave * chunk, r1 = min(p.n_live, r0 + chunk);
     const bool mag_ok = gi_mag_ok(pos, a, p.radius);
     auto add_hit = [&](int q, float cos_t, float sin_t) {
       if (q >= 0) {
@@ -1035,10 +1081,9 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
         const float inv_scale = kCert ? __uint_as_float((127u - (unsigned)p.cert_shift) << 23) : 1.0f;  // 2^-shift
         const FastTbn ft = make_fast_tbn<kMode>(p, tbn, a, inv_scale);
         const CertPix cp = make_cert(p, c, inv_scale);
-        const int rs = p.ray_interleave ? 2 * wave : r0, re = p.ray_interleave ? p.nrays : r1;
+        const int rs = p.ray_interleave ? 2 * wave : r0, re = p.ray_interleave ? p.n_live : r1;
         const int rstep = p.ray_interleave ? 2 * kGiWaves : 2;
-        for (int r = rs; r < re; r += rstep) {
-          const int rb = min(r + 1, re - 1);
+        auto pair = [&](int r, int rb) {
           const float4 ra0 = rays[2 * r], ra1 = rays[2 * rb];
           f32x2 Bxy[2], Bz2;
           float bz0, bz1;
@@ -1053,7 +1098,10 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
             add_hit(hit[0], ra0.w, rays[2 * r + 1].x);
             add_hit(hit[1], ra1.w, rays[2 * rb + 1].x);
           }
-        }
+        };
+        for (int r = rs; r < re; r += rstep) pair(r, min(r + 1, re - 1));
+        // the zero-weight ray (ONE representative by default): rgb * cos * 0 = +-0, or NaN for a non-finite hit pixel
+        for (int r = p.n_live + wave; r < p.nrays; r += kGiWaves) pair(r, r);
       }
     } else {
     const unsigned sv_min_bits = gi_sv_min_bits(a, p.radius, p.inv_step);
@@ -1078,13 +1126,15 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
         for (int k = 0; k < kGiRays; k++) add_hit(hit[k], ct[k], st[k]);
       }
     }
-    for (; r < r1; r++) {
-      const float4 ra = rays[2 * r];
+    auto single = [&](int q) {
+      const float4 ra = rays[2 * q];
       const v3 sv = tbn_apply(tbn, ra.x, ra.y, ra.z);
       int hit;
       march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, sv_min_bits, &hit);
-      add_hit(hit, ra.w, rays[2 * r + 1].x);
-    }
+      add_hit(hit, ra.w, rays[2 * q + 1].x);
+    };
+    for (; r < r1; r++) single(r);
+    for (r = p.n_live + wave; r < p.nrays; r += kGiWaves) single(r);
     }
   }
   s_part[wave][0][lane] = diffuse.x;
@@ -1109,7 +1159,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
   kD.x = (float)((double)kD.x * (1.0 - (double)metallic));
   kD.y = (float)((double)kD.y * (1.0 - (double)metallic));
   kD.z = (float)((double)kD.z * (1.0 - (double)metallic));
-  const float nrSamples = (float)p.nrays;  // += 1 per ray in fp32 is exact below 2^24
+  const float nrSamples = (float)p.nrays_total;  // += 1 per ray in fp32 is exact below 2^24
   v3 gd;
   if (nrSamples > 0.0f) {
     gd.x = (float)((double)(kPiF * diffuse.x) * (1.0 / (double)nrSamples) * (double)kD.x);
@@ -1128,22 +1178,24 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
   abd[2 * HW + pix_id] = gd.z;
 }
 
-static GiParams make_params(int W, int H, float fx, float fy, float radius, float bias, float thick,
-                            int step, int start, int nrays, bool& pow2) {
+static GiParams make_params(const Options& o, int W, int H, float fx, float fy, float radius, float bias, float thick,
+                            int step, int start, const RayTable& t, bool ssr, bool& pow2) {
   GiParams p;
   p.W = W; p.H = H; p.fx = fx; p.fy = fy; p.radius = radius; p.bias = bias; p.thick = thick;
-  p.step = step; p.start = start; p.nrays = nrays;
+  p.step = step; p.start = start;
+  p.n_live = t.n_live;
+  // zero-weight rays (see the ray table): all of them on request, else one for SSR (NaN propagation) and none for SSAO
+  p.nrays = t.n_live + (o.gi_zero_rays ? t.n_dead : (ssr && t.n_dead > 0 ? 1 : 0));
+  p.nrays_total = t.nrays;
   pow2 = step > 0 && (step & (step - 1)) == 0 && step <= (1 << 20);
   p.inv_step = pow2 ? 1.0f / (float)step : 0.0f;
   if (step - start > 64 - kGiGroup) pow2 = false;  // a partial last group may index kGiGroup - 1 entries past step - 1
   // j / step: exact for a power-of-two step; otherwise the correctly rounded quotient (read by the fast marches only)
   for (int k = 0; k < 64; k++) p.fjt[k] = pow2 ? (float)(start + k) * p.inv_step : (float)(start + k) / (float)step;
   for (int k = 0; k < 64; k++) p.fjc[k] = p.fjt[k < step - 1 - start ? k : (step - 1 - start > 0 ? step - 1 - start : 0)];
-  // GIGS_GI_TILE_LOG2W: tuning knob for the pixel rectangle of a workgroup (3 = 8x8 ... 6 = 64x1)
-  const char* e = getenv("GIGS_GI_TILE_LOG2W");
-  p.tile_log2w = (e && e[0] >= '0' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGiTileLog2W;
-  const char* il = getenv("GIGS_GI_INTERLEAVE");
-  p.ray_interleave = (il && il[0] == '0') ? 0 : 1;  // measured at C2: SSAO 0.94 -> 0.89, SSR 0.93 -> 0.90 ms (GIGS_GI_INTERLEAVE=0: quarters)
+  // gi_tile_log2w: tuning knob for the pixel rectangle of a workgroup (3 = 8x8 ... 6 = 64x1)
+  p.tile_log2w = (o.gi_tile_log2w >= 0 && o.gi_tile_log2w <= 6) ? o.gi_tile_log2w : kGiTileLog2W;
+  p.ray_interleave = o.gi_interleave ? 1 : 0;  // measured at C2: SSAO 0.94 -> 0.89, SSR 0.93 -> 0.90 ms (0: quarters)
   return p;
 }
 // Certification table, (bw + 1) x (bh + 1) entries.  Per (1 << shift)^2 block of the z plane: the minimum over its non-zero
@@ -1198,11 +1250,10 @@ size_t gi_scratch_bytes(int W, int H) {
   return sh ? cert_table_bytes(W, H, sh) : 0;
 }
 // fills p.cert_*; returns the table's byte size (0 = run without certification)
-static size_t prepare_cert(GiParams& p, int mode, const float* pos, void* scratch, hipStream_t s) {
+static size_t prepare_cert(const Options& o, GiParams& p, int mode, const float* pos, void* scratch, hipStream_t s) {
   p.cert_shift = p.cert_w = p.cert_h = 0;
   p.cert_d0 = cert_consts(p.bias, p.thick).d0;
-  const char* e = getenv("GIGS_GI_CERT");
-  if (!scratch || mode < 3 || (e && e[0] == '0')) return 0;
+  if (!scratch || mode < 3 || !o.gi_cert) return 0;
   const int sh = cert_shift_for(p.W, p.H);
   if (!sh) return 0;
   p.cert_shift = sh;
@@ -1213,17 +1264,14 @@ static size_t prepare_cert(GiParams& p, int mode, const float* pos, void* scratc
   return cert_table_bytes(p.W, p.H, sh);
 }
 
-// GIGS_GI_MARCH: exact | hoist | hoist_fma | proj_nr | proj (see the block comment above march2_fast).  The fast
-// marches read the j/step table, so marches of more than 64 - kGiGroup steps take the exact path.
+// gigs_options.gi_march: 0 exact | 1 hoist | 2 hoist_fma | 3 proj_nr | 4 proj (see the block comment above march2_fast;
+// GIGS_GI_MARCH names them in the environment).  The fast marches read the j/step table, so marches of more than
+// 64 - kGiGroup steps take the exact path.
 #ifndef GIGS_GI_DEFAULT_MODE
 #define GIGS_GI_DEFAULT_MODE 4  // "proj": measured 1.3e-7 mean L1 / 1e-4 changed pixels vs the exact march at C2
 #endif
-static int gi_march_mode(int step, int start) {
-  static const char* names[] = {"exact", "hoist", "hoist_fma", "proj_nr", "proj"};
-  int mode = GIGS_GI_DEFAULT_MODE;
-  if (const char* e = getenv("GIGS_GI_MARCH"))
-    for (int i = 0; i < 5; i++)
-      if (strcmp(e, names[i]) == 0) mode = i;
+static int gi_march_mode(const Options& o, int step, int start) {
+  int mode = (o.gi_march >= 0 && o.gi_march <= 4) ? o.gi_march : GIGS_GI_DEFAULT_MODE;
   if (step - start > 64 - kGiGroup || step <= 0) mode = 0;
   return mode;
 }
@@ -1232,18 +1280,18 @@ static dim3 gi_grid(const GiParams& p) {
   return dim3((p.W + tw - 1) / tw, (p.H + th - 1) / th);
 }
 
-int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, float thick,
+int launch_ssao(const Options& o, int W, int H, float fx, float fy, float radius, float bias, float thick,
                 float delta, int step, int start, const float* normal, const float* pos,
                 float* occlusion, void* scratch, hipStream_t s) {
   RayTable t;
   const int rc = get_ray_table(delta, s, t);
   if (rc) return rc;
   bool pow2;
-  GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
+  GiParams p = make_params(o, W, H, fx, fy, radius, bias, thick, step, start, t, /*ssr*/ false, pow2);
   if (W >= (1 << 15) || H >= (1 << 15)) return -2;  // rejected with a message by the C-ABI wrapper
   const dim3 grid = gi_grid(p);
-  const int mode = gi_march_mode(step, start);
-  const size_t cert = (start < step) ? prepare_cert(p, mode, pos, scratch, s) : 0;
+  const int mode = gi_march_mode(o, step, start);
+  const size_t cert = (start < step) ? prepare_cert(o, p, mode, pos, scratch, s) : 0;
   const float2* tab = (const float2*)scratch;
 #define GIGS_SSAO_LAUNCH(POW2, MODE, CERT, LDS) \
   hipLaunchKernelGGL((ssao_kernel<POW2, MODE, CERT>), grid, dim3(256), LDS, s, p, t.dev, t.sum_w, normal, pos, occlusion, tab)
@@ -1260,7 +1308,7 @@ int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, floa
   return 0;
 }
 
-int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float thick,
+int launch_ssr(const Options& o, int W, int H, float fx, float fy, float radius, float bias, float thick,
                float delta, int step, int start, const float* normal, const float* pos,
                const float* rgb, const float* albedo, const float* /*roughness*/,
                const float* metallic, const float* F0, float* color, float* abd, void* scratch, hipStream_t s) {
@@ -1268,11 +1316,11 @@ int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float
   const int rc = get_ray_table(delta, s, t);
   if (rc) return rc;
   bool pow2;
-  GiParams p = make_params(W, H, fx, fy, radius, bias, thick, step, start, t.nrays, pow2);
+  GiParams p = make_params(o, W, H, fx, fy, radius, bias, thick, step, start, t, /*ssr*/ true, pow2);
   if (W >= (1 << 15) || H >= (1 << 15)) return -2;  // rejected with a message by the C-ABI wrapper
   const dim3 grid = gi_grid(p);
-  const int mode = gi_march_mode(step, start);
-  const size_t cert = (start < step) ? prepare_cert(p, mode, pos, scratch, s) : 0;
+  const int mode = gi_march_mode(o, step, start);
+  const size_t cert = (start < step) ? prepare_cert(o, p, mode, pos, scratch, s) : 0;
   const float2* tab = (const float2*)scratch;
 #define GIGS_SSR_LAUNCH(POW2, MODE, CERT, LDS)                                                                          \
   hipLaunchKernelGGL((ssr_kernel<POW2, MODE, CERT>), grid, dim3(256), LDS, s, p, t.dev, normal, pos, rgb, albedo, metallic, \

@@ -229,6 +229,35 @@ inline size_t required_bytes(A... a) {
   return reinterpret_cast<size_t>(p) + kAlign;
 }
 
+// ---- per-context state (include/gigs_hip.h: gigs_ctx / gigs_options) ------------------------
+// Every switch a launch path reads lives here: the library itself keeps no mutable process-wide state besides
+// immutable caches (ray tables, texel tables, rocPRIM temp sizes) and the diagnostic profile session.  The
+// default options are the environment, parsed ONCE (first use); a context starts as a copy of them.
+struct Options {
+  int binning_legacy;    // GIGS_BINNING=legacy
+  int bucket_max_mean;   // GIGS_BUCKET_MAX_MEAN
+  int long_lists;        // GIGS_LONG_LISTS: -1 auto, 0 never, 1 always
+  int bucket_target;     // GIGS_BUCKET_TARGET
+  int blend_cull;        // GIGS_BLEND_CULL
+  int pre_bwd_sh_skip;   // GIGS_PRE_BWD_SH_SKIP
+  int gi_march;          // GIGS_GI_MARCH: 0 exact, 1 hoist, 2 hoist_fma, 3 proj_nr, 4 proj
+  int gi_cert;           // GIGS_GI_CERT
+  int gi_interleave;     // GIGS_GI_INTERLEAVE
+  int gi_tile_log2w;     // GIGS_GI_TILE_LOG2W
+  int gi_zero_rays;      // GIGS_GI_ZERO_RAYS: 1 = march the zero-weight rays too (diagnostic; same bits)
+  int spec_max8, spec_max16;  // GIGS_SPEC_MAX8 / _MAX16
+  int shade_lds_floats;  // GIGS_SHADE_LDS_FLOATS
+  int shade_bwd_blocks;  // GIGS_SHADE_BWD_BLOCKS (0 = one workgroup per CU)
+};
+struct Ctx {
+  Options opt;
+  unsigned async_capacity;  // gigs_ctx_set_async_binning
+  unsigned* async_counters;
+  void* blend_begin_event;  // gigs_ctx_set_blend_begin_event
+};
+const Options& default_options();  // api.hip
+const Ctx& default_ctx();          // options = default_options(), no async binning, no event
+
 // ---- kernel launchers implemented in the .hip files --------------------------------------
 struct FwdArgs {
   int P, D, M, W, H;
@@ -248,7 +277,8 @@ void launch_bin_prefix(int P, int T, unsigned capacity, const ImageState& img, u
 void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, const GeomState& g,
                         const BinningState& b, const ImageState& img, hipStream_t s);
 // long_lists: tiles above 8192 keys are partitioned by sampled splitters and sorted bucket by bucket (dense scenes)
-int launch_bin_sort(int T, int P, bool long_lists, unsigned capacity, const BinningState& b, const ImageState& img, hipStream_t s);
+int launch_bin_sort(int T, int P, bool long_lists, unsigned bucket_target, unsigned capacity, const BinningState& b, const ImageState& img,
+                    hipStream_t s);
 size_t long_space_bytes(size_t T, size_t R);
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                          hipStream_t s);
@@ -263,7 +293,7 @@ void launch_tile_order(int T, const uint2* ranges, uint32_t* tile_order, hipStre
 void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& b,
                       const ImageState& im, float* out_color, float* out_opacity,
                       float* out_depth, float* out_normal, float* out_normal_view, float* out_pos,
-                      float* out_albedo, float* out_roughness, float* out_metallic, hipStream_t s);
+                      float* out_albedo, float* out_roughness, float* out_metallic, int cull, hipStream_t s);
 
 struct BwdArgs {
   int P, D, M, R, W, H;
@@ -280,15 +310,15 @@ struct BwdArgs {
 };
 void launch_blend_bwd(const BwdArgs& a, const GeomState& g, const BinningState& b,
                       const ImageState& im, hipStream_t s);
-void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, hipStream_t s);
+void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, int sh_skip, hipStream_t s);
 
 void launch_depth_to_normal(int W, int H, float fx, float fy, const float* viewmatrix,
                             const float* depth, float* normal, float* depth_pos, hipStream_t s);
-int launch_ssao(int W, int H, float fx, float fy, float radius, float bias, float thick,
+int launch_ssao(const Options& o, int W, int H, float fx, float fy, float radius, float bias, float thick,
                 float delta, int step, int start, const float* normal, const float* pos,
                 float* occlusion, void* scratch, hipStream_t s);
 size_t gi_scratch_bytes(int W, int H);
-int launch_ssr(int W, int H, float fx, float fy, float radius, float bias, float thick,
+int launch_ssr(const Options& o, int W, int H, float fx, float fy, float radius, float bias, float thick,
                float delta, int step, int start, const float* normal, const float* pos,
                const float* rgb, const float* albedo, const float* roughness,
                const float* metallic, const float* F0, float* color, float* abd, void* scratch, hipStream_t s);

@@ -531,19 +531,16 @@ __global__ void __launch_bounds__(256) specular_apply_multi_kernel(SpecLevels L)
   else specular_apply_body<kBackward, true, 64>(block, v.N, v.src, v.bounds, v.offsets, v.W, v.dst, v.wsum_out);
 }
 
-static int spec_lanes_for(int avg_window) {
-  static const int max8 = [] { const char* e = getenv("GIGS_SPEC_MAX8"); return e ? atoi(e) : 128; }();
-  static const int max16 = [] { const char* e = getenv("GIGS_SPEC_MAX16"); return e ? atoi(e) : 1500; }();
-  return (avg_window > 0 && avg_window <= max8) ? 8 : (avg_window > 0 && avg_window <= max16) ? 16 : 64;
+// tuning knobs (gigs_options.spec_max8 / spec_max16): largest mean window served by 8- and by 16-lane groups
+static int spec_lanes_for(const Options& o, int avg_window) {
+  return (avg_window > 0 && avg_window <= o.spec_max8) ? 8 : (avg_window > 0 && avg_window <= o.spec_max16) ? 16 : 64;
 }
 
 template <bool kBackward, bool kNorm>
-static void launch_specular_apply(int res, int avg_window, const float* src, const float* bounds, const uint32_t* offsets,
-                                  const float* W, float* dst, float* wsum_out, hipStream_t s) {
+static void launch_specular_apply(const Options& o, int res, int avg_window, const float* src, const float* bounds,
+                                  const uint32_t* offsets, const float* W, float* dst, float* wsum_out, hipStream_t s) {
   const int total = 6 * res * res;
-  // tuning knobs: largest mean window served by 8- and by 16-lane groups
-  static const int max8 = [] { const char* e = getenv("GIGS_SPEC_MAX8"); return e ? atoi(e) : 128; }();
-  static const int max16 = [] { const char* e = getenv("GIGS_SPEC_MAX16"); return e ? atoi(e) : 1500; }();
+  const int max8 = o.spec_max8, max16 = o.spec_max16;
   if (avg_window > 0 && avg_window <= max8) {
     const int waves = (total + 7) / 8;
     hipLaunchKernelGGL((specular_apply_kernel<kBackward, kNorm, 8>), dim3((waves + 3) / 4), dim3(256), 0, s, res, src,
@@ -762,7 +759,9 @@ struct ShadeArgs {
   int L; const float* spec[8]; int spec_res[8];
   const float* lut; int lut_w, lut_h;
   int tone, gamma;
-  int ablate;  // diagnostic only (env GIGS_ABLATE): bit 0 skips the diffuse-map atomics, bit 1 the specular ones
+#ifdef GIGS_DIAG
+  int ablate;  // -DGIGS_DIAG builds only (tools/gpu_ablate_shade.sh, env GIGS_ABLATE): bit 0 skips the diffuse-map atomics, bit 1 the specular ones
+#endif
   int part;    // backward: 0 = everything; 1 = the material gradients only; 2 = the light-texture gradients only (gigs_shade_ext)
   // backward: gradient textures small enough to be accumulated per workgroup in LDS
   int lds_total;        // floats of dynamic LDS
@@ -1118,7 +1117,12 @@ shade_bwd_kernel(ShadeArgs A) {
   }
   if (A.part == 1) continue;  // the material gradients only (uniform over the grid)
   // ---- light textures (wave-uniform control flow from here on) ----
-  if (A.d_diffuse && !(A.ablate & 1)) {
+#ifdef GIGS_DIAG
+#define GIGS_ABLATED(bit) (A.ablate & (bit))
+#else
+#define GIGS_ABLATED(bit) 0  // the shipped kernel has no result-changing switch
+#endif
+  if (A.d_diffuse && !GIGS_ABLATED(1)) {
     float* base = A.lds_diffuse_off >= 0 ? s_lds + A.lds_diffuse_off : A.d_diffuse;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1127,15 +1131,17 @@ shade_bwd_kernel(ShadeArgs A) {
       run_add3<false>(base + 3 * (size_t)max(idx, 0), idx, g_dl[0] * w, g_dl[1] * w, g_dl[2] * w);
     }
   }
-  if (!(A.ablate & 2)) {
+  if (!GIGS_ABLATED(2)) {
     const float wl = (q.l1 != q.l0) ? (1 - q.lf) : 1.0f;
     float* t0 = A.lds_spec_off[q.l0] >= 0 ? s_lds + A.lds_spec_off[q.l0] : A.d_spec[q.l0];
     float* t1 = A.lds_spec_off[q.l1] >= 0 ? s_lds + A.lds_spec_off[q.l1] : A.d_spec[q.l1];
     if (!A.d_spec[q.l0]) t0 = nullptr;
     if (!A.d_spec[q.l1]) t1 = nullptr;
     // diagnostic (GIGS_ABLATE bit 2 / 3): drop the adds that go to LDS-resident / to global levels
+#ifdef GIGS_DIAG
     if (((A.ablate & 4) && A.lds_spec_off[q.l0] >= 0) || ((A.ablate & 8) && A.lds_spec_off[q.l0] < 0)) t0 = nullptr;
     if (((A.ablate & 4) && A.lds_spec_off[q.l1] >= 0) || ((A.ablate & 8) && A.lds_spec_off[q.l1] < 0)) t1 = nullptr;
+#endif
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int idx = (live && q.has0 && t0) ? q.t0.idx[k] : -1;
@@ -1182,6 +1188,7 @@ extern "C" {
 int gigs_internal_fail(int code, const char* msg);  // api.hip
 void gigs_internal_stage_begin(int stage, void* stream, void** token);
 void gigs_internal_stage_end(void* token);
+const gigs::Options* gigs_internal_options(const gigs_ctx* ctx);  // the context's options (NULL = the defaults)
 
 #define PBR_CHECK_LAUNCH()                                        \
   do {                                                            \
@@ -1270,35 +1277,38 @@ int gigs_specular_weights_divide(int res, const float* bounds, const uint32_t* o
   return 0;
 }
 
-int gigs_specular_cubemap_fwd_w(int res, const float* cubemap, const float* bounds, const uint32_t* offsets,
+int gigs_specular_cubemap_fwd_w(gigs_ctx* ctx, int res, const float* cubemap, const float* bounds, const uint32_t* offsets,
                                 const float* weights, int avg_window, float* out, float* wsum_out, void* stream) {
+  const gigs::Options& o = *gigs_internal_options(ctx);
   if (res <= 0 || !cubemap || !bounds || !offsets || !weights || !out) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_fwd_w: bad argument");
   hipStream_t s = (hipStream_t)stream;
   void* tok; gigs_internal_stage_begin(16, stream, &tok);
   if (wsum_out)
-    gigs::launch_specular_apply<false, true>(res, avg_window, cubemap, bounds, offsets, weights, out, wsum_out, s);
+    gigs::launch_specular_apply<false, true>(o, res, avg_window, cubemap, bounds, offsets, weights, out, wsum_out, s);
   else
-    gigs::launch_specular_apply<false, false>(res, avg_window, cubemap, bounds, offsets, weights, out, nullptr, s);
+    gigs::launch_specular_apply<false, false>(o, res, avg_window, cubemap, bounds, offsets, weights, out, nullptr, s);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;
 }
 
-int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* offsets, const float* weights_swapped,
+int gigs_specular_cubemap_bwd_w(gigs_ctx* ctx, int res, const float* bounds, const uint32_t* offsets, const float* weights_swapped,
                                 int avg_window, const float* grad_out, int grad_is_rgb, float* grad_cubemap, void* stream) {
+  const gigs::Options& o = *gigs_internal_options(ctx);
   if (res <= 0 || !bounds || !offsets || !weights_swapped || !grad_out || !grad_cubemap) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_bwd_w: bad argument");
   hipStream_t s = (hipStream_t)stream;
   void* tok; gigs_internal_stage_begin(17, stream, &tok);
   if (grad_is_rgb)
-    gigs::launch_specular_apply<true, true>(res, avg_window, grad_out, bounds, offsets, weights_swapped, grad_cubemap, nullptr, s);
+    gigs::launch_specular_apply<true, true>(o, res, avg_window, grad_out, bounds, offsets, weights_swapped, grad_cubemap, nullptr, s);
   else
-    gigs::launch_specular_apply<true, false>(res, avg_window, grad_out, bounds, offsets, weights_swapped, grad_cubemap, nullptr, s);
+    gigs::launch_specular_apply<true, false>(o, res, avg_window, grad_out, bounds, offsets, weights_swapped, grad_cubemap, nullptr, s);
   gigs_internal_stage_end(tok);
   PBR_CHECK_LAUNCH();
   return 0;
 }
 
-int gigs_specular_cubemap_multi_w(int n_levels, const gigs_spec_level* levels, int backward, void* stream) {
+int gigs_specular_cubemap_multi_w(gigs_ctx* ctx, int n_levels, const gigs_spec_level* levels, int backward, void* stream) {
+  const gigs::Options& o = *gigs_internal_options(ctx);
   if (n_levels <= 0 || n_levels > 8 || !levels) return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_multi_w: bad level count");
   gigs::SpecLevels L;
   L.n = n_levels;
@@ -1308,7 +1318,7 @@ int gigs_specular_cubemap_multi_w(int n_levels, const gigs_spec_level* levels, i
     if (a.res <= 0 || !a.src || !a.bounds || !a.offsets || !a.weights || !a.dst || (!backward && !a.wsum))
       return gigs_internal_fail(GIGS_ERR_INVALID, "specular_cubemap_multi_w: bad level");
     gigs::SpecLevel& v = L.lv[i];
-    v.N = a.res; v.lanes = gigs::spec_lanes_for(a.avg_window); v.block_begin = blocks;
+    v.N = a.res; v.lanes = gigs::spec_lanes_for(o, a.avg_window); v.block_begin = blocks;
     v.src = a.src; v.bounds = a.bounds; v.offsets = a.offsets; v.W = a.weights; v.dst = a.dst; v.wsum_out = a.wsum;
     const int total = 6 * a.res * a.res;
     const int waves = v.lanes == 64 ? total : (total + (64 / v.lanes) - 1) / (64 / v.lanes);
@@ -1446,8 +1456,10 @@ static int fill_shade(gigs::ShadeArgs& A, int H, int W, const float* normals, co
     A.spec_res[i] = spec_res[i];
   }
   A.lut = lut; A.lut_w = lut_w; A.lut_h = lut_h; A.tone = tone; A.gamma = gamma;
+#ifdef GIGS_DIAG
   const char* ab = getenv("GIGS_ABLATE");
   A.ablate = ab ? atoi(ab) : 0;
+#endif
   A.ps = 3; A.cs = 1; A.rough_scale = 1.0f; A.rough_bias = 0.0f;
   return 0;
 }
@@ -1476,17 +1488,18 @@ int gigs_shade_fwd(int H, int W, const float* normals, const float* view_dirs, c
                    int n_levels, const float* const* spec, const int* spec_res, const float* lut,
                    int lut_w, int lut_h, int tone, int gamma, float* render_rgb, float* diffuse_rgb,
                    float* specular_rgb, float* diffuse_light, void* stream) {
-  return gigs_shade_fwd_ex(H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, background, diffuse,
+  return gigs_shade_fwd_ex(nullptr, H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, background, diffuse,
                            diffuse_res, n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma, render_rgb,
                            diffuse_rgb, specular_rgb, diffuse_light, nullptr, stream);
 }
 
-int gigs_shade_fwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+int gigs_shade_fwd_ex(gigs_ctx* ctx, int H, int W, const float* normals, const float* view_dirs, const float* albedo,
                       const float* roughness, const uint8_t* mask, const float* occlusion,
                       const float* metallic, const float* background, const float* diffuse, int diffuse_res,
                       int n_levels, const float* const* spec, const int* spec_res, const float* lut,
                       int lut_w, int lut_h, int tone, int gamma, float* render_rgb, float* diffuse_rgb,
                       float* specular_rgb, float* diffuse_light, const gigs_shade_ext* ext, void* stream) {
+  (void)ctx;  // the forward reads no option; the parameter keeps the two _ex entries alike
   gigs::ShadeArgs A;
   const int rc = fill_shade(A, H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, background,
                             diffuse, diffuse_res, n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma);
@@ -1510,13 +1523,13 @@ int gigs_shade_bwd(int H, int W, const float* normals, const float* view_dirs, c
                    const float* g_specular_rgb, const float* g_diffuse_light, float* d_albedo,
                    float* d_roughness, float* d_metallic, float* d_diffuse, float* const* d_spec,
                    void* stream) {
-  return gigs_shade_bwd_ex(H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, diffuse, diffuse_res,
+  return gigs_shade_bwd_ex(nullptr, H, W, normals, view_dirs, albedo, roughness, mask, occlusion, metallic, diffuse, diffuse_res,
                            n_levels, spec, spec_res, lut, lut_w, lut_h, tone, gamma, g_render, g_diffuse_rgb,
                            g_specular_rgb, g_diffuse_light, d_albedo, d_roughness, d_metallic, d_diffuse, d_spec, nullptr,
                            stream);
 }
 
-int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+int gigs_shade_bwd_ex(gigs_ctx* ctx, int H, int W, const float* normals, const float* view_dirs, const float* albedo,
                       const float* roughness, const uint8_t* mask, const float* occlusion,
                       const float* metallic, const float* diffuse, int diffuse_res, int n_levels,
                       const float* const* spec, const int* spec_res, const float* lut, int lut_w, int lut_h,
@@ -1540,11 +1553,9 @@ int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs
   A.lds_diffuse_off = -1;
   for (int i = 0; i < 8; i++) A.lds_spec_off[i] = -1;
   const int n_dd = 6 * diffuse_res * diffuse_res * 3;
-  static const int lds_budget = [] {  // GIGS_SHADE_LDS_FLOATS: tuning knob (smaller budget -> more workgroups per CU)
-    const char* e = getenv("GIGS_SHADE_LDS_FLOATS");
-    const int v = e ? atoi(e) : gigs::kShadeLdsBudget;
-    return v < 0 ? 0 : (v > gigs::kShadeLdsBudget ? gigs::kShadeLdsBudget : v);
-  }();
+  const gigs::Options& o = *gigs_internal_options(ctx);
+  // gigs_options.shade_lds_floats: tuning knob (smaller budget -> more workgroups per CU)
+  const int lds_budget = o.shade_lds_floats < 0 ? 0 : (o.shade_lds_floats > gigs::kShadeLdsBudget ? gigs::kShadeLdsBudget : o.shade_lds_floats);
   if (d_diffuse && n_dd <= lds_budget) { A.lds_diffuse_off = 0; used = n_dd; }
   for (int i = n_levels - 1; i >= 0; i--) {
     const int n = 6 * spec_res[i] * spec_res[i] * 3;
@@ -1560,13 +1571,12 @@ int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs
   }
   void* tok; gigs_internal_stage_begin(15, stream, &tok);
   const int n_chunks = (H * W + gigs::kShadeBwdBlock - 1) / gigs::kShadeBwdBlock;
-  static const int max_blocks = [] {  // one workgroup per CU (120 KB of LDS each); GIGS_SHADE_BWD_BLOCKS overrides
-    const char* e = getenv("GIGS_SHADE_BWD_BLOCKS");
-    if (e) return atoi(e);
+  static const int n_cus = [] {  // one workgroup per CU (120 KB of LDS each); gigs_options.shade_bwd_blocks overrides
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return cus;
   }();
+  const int max_blocks = o.shade_bwd_blocks > 0 ? o.shade_bwd_blocks : n_cus;
   // part 1 (materials only) keeps no LDS accumulators: one workgroup per chunk instead of the persistent grid
   const int blocks = (A.part == 1 || n_chunks < max_blocks) ? n_chunks : max_blocks;
   hipLaunchKernelGGL(gigs::shade_bwd_kernel, dim3(blocks), dim3(gigs::kShadeBwdBlock), (size_t)used * sizeof(float),

@@ -544,13 +544,12 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g, int sh_always) {
   }
 }
 
-void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, hipStream_t s) {
+void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, int sh_skip, hipStream_t s) {
   const int blocks = (a.P + kPreBlock - 1) / kPreBlock;
   const size_t lds = a.shs ? (size_t)kPreBlock * sh_stride(a.M) * sizeof(float) : 0;
-  // GIGS_PRE_BWD_SH_SKIP=0 (diagnostic): evaluate every visible Gaussian and read the SH block of every group, whatever
-  // the incoming gradients (as before round 3)
-  const char* e = getenv("GIGS_PRE_BWD_SH_SKIP");
-  const int sh_always = (e && e[0] == '0') ? 1 : 0;
+  // sh_skip = 0 (gigs_options.pre_bwd_sh_skip, diagnostic): evaluate every visible Gaussian and read the SH block of every
+  // group, whatever the incoming gradients (as before round 3)
+  const int sh_always = sh_skip ? 0 : 1;
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(kPreBlock), lds, s, a, g, sh_always);
 }
 

@@ -141,7 +141,8 @@ class BinningOverflow(RuntimeError):
 
 class AsyncBinning:
     """`with AsyncBinning(capacity, device):` -- rasterizer forwards inside bin into a persistent buffer of `capacity`
-    instances and read NOTHING back (gigs_set_async_binning; gigs-hip extension, off by default).  The reference reads
+    instances and read NOTHING back (gigs_ctx_set_async_binning: the setting lives in the library context that is current
+    inside the block, not in the process; gigs-hip extension, off by default).  The reference reads
     the instance count in the middle of every forward (rasterizer_impl.cu:589-594), which stalls the host and keeps the
     forward out of a hipGraph; here the count stays on the device and `num_rendered` is the capacity (the backward
     carves the same layout from it).  Overflow protocol: `snapshot()` after a forward queues a copy of the device
@@ -161,10 +162,13 @@ class AsyncBinning:
     def __enter__(self):
         global _async
         self._prev, _async = _async, self
+        self._use = gigs_lib.use(gigs_lib.current().derive(async_binning=(self.capacity, self.counters)))
+        self._use.__enter__()
         return self
 
     def __exit__(self, *exc):
         global _async
+        self._use.__exit__(*exc)
         _async = self._prev
         return False
 
@@ -284,24 +288,18 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
             return ptr
 
         with torch.cuda.device(dev):
-            if _async is not None:
-                _lib.gigs_set_async_binning(_async.capacity, _async.counters.data_ptr())
-            try:
-                rendered = _lib.gigs_forward(
-                    geom.cb, None, binning.cb, None, img.cb, None, P, int(sh_degree), M, p(bg, "bg"), W, H,
-                    p(means3D, "means3D"), p(sh, "sh"), p(colors_precomp, "colors_precomp"),
-                    p(opacities, "opacities"), p(normal, "normal"), p(albedo, "albedo"),
-                    p(roughness, "roughness"), p(metallic, "metallic"), p(scales, "scales"),
-                    float(scale_modifier), p(rotations, "rotations"), p(cov3Ds_precomp, "cov3Ds_precomp"),
-                    p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
-                    float(tanfovx), float(tanfovy), int(bool(prefiltered)), int(bool(argmax_depth)),
-                    int(bool(inference)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
-                    out_normal.data_ptr(), out_normal_view.data_ptr(), out_pos.data_ptr(),
-                    out_albedo.data_ptr(), out_roughness.data_ptr(), out_metallic.data_ptr(),
-                    radii.data_ptr(), int(debug), _stream())
-            finally:
-                if _async is not None:
-                    _lib.gigs_set_async_binning(0, None)
+            rendered = _lib.gigs_forward(
+                gigs_lib.ctx_ptr(), geom.cb, None, binning.cb, None, img.cb, None, P, int(sh_degree), M, p(bg, "bg"), W, H,
+                p(means3D, "means3D"), p(sh, "sh"), p(colors_precomp, "colors_precomp"),
+                p(opacities, "opacities"), p(normal, "normal"), p(albedo, "albedo"),
+                p(roughness, "roughness"), p(metallic, "metallic"), p(scales, "scales"),
+                float(scale_modifier), p(rotations, "rotations"), p(cov3Ds_precomp, "cov3Ds_precomp"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+                float(tanfovx), float(tanfovy), int(bool(prefiltered)), int(bool(argmax_depth)),
+                int(bool(inference)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
+                out_normal.data_ptr(), out_normal_view.data_ptr(), out_pos.data_ptr(),
+                out_albedo.data_ptr(), out_roughness.data_ptr(), out_metallic.data_ptr(),
+                radii.data_ptr(), int(debug), _stream())
         gigs_lib.check(rendered, "rasterize_gaussians")
     return (rendered, out_color, radii, geom.t, binning.t, img.t, out_opacity, out_depth, out_normal,
             out_normal_view, out_pos, out_albedo, out_roughness, out_metallic)
@@ -355,7 +353,7 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
 
         with torch.cuda.device(dev):
             rc = _lib.gigs_backward(
-                P, int(sh_degree), M, int(num_rendered), p(bg, "bg"), W, H, p(means3D, "means3D"),
+                gigs_lib.ctx_ptr(), P, int(sh_degree), M, int(num_rendered), p(bg, "bg"), W, H, p(means3D, "means3D"),
                 p(sh, "sh"), p(colors_precomp, "colors_precomp"), p(normal, "normal"), p(albedo, "albedo"),
                 p(roughness, "roughness"), p(metallic, "metallic"), p(scales, "scales"),
                 p(rotations, "rotations"), p(cov3Ds_precomp, "cov3Ds_precomp"), p(viewmatrix, "viewmatrix"),
@@ -409,7 +407,7 @@ def _SSAO(width, height, focal_x, focal_y, radius, bias, thick, delta, step, sta
     ps, k1 = _fptr(out_pos, "out_pos")
     scratch = _gi_scratch(int(width), int(height), dev)
     with torch.cuda.device(dev):
-        gigs_lib.check(_lib.gigs_ssao_ex(int(width), int(height), float(focal_x), float(focal_y), float(radius),
+        gigs_lib.check(_lib.gigs_ssao_ex(gigs_lib.ctx_ptr(), int(width), int(height), float(focal_x), float(focal_y), float(radius),
                                          float(bias), float(thick), float(delta), int(step), int(start), n, ps,
                                          occlusion.data_ptr(), None if scratch is None else scratch.data_ptr(), _stream()),
                        "SSAO")
@@ -437,7 +435,7 @@ def _SSR(width, height, focal_x, focal_y, radius, bias, thick, delta, step, star
         keep.append(k)
     scratch = _gi_scratch(int(width), int(height), dev)
     with torch.cuda.device(dev):
-        gigs_lib.check(_lib.gigs_ssr_ex(int(width), int(height), float(focal_x), float(focal_y), float(radius),
+        gigs_lib.check(_lib.gigs_ssr_ex(gigs_lib.ctx_ptr(), int(width), int(height), float(focal_x), float(focal_y), float(radius),
                                         float(bias), float(thick), float(delta), int(step), int(start), *ptrs,
                                         color.data_ptr(), abd.data_ptr(), None if scratch is None else scratch.data_ptr(),
                                         _stream()), "SSR")
@@ -483,7 +481,7 @@ def _lite_rasterize_gaussians(background, means3D, colors, opacity, scales, rota
 
         with torch.cuda.device(dev):
             rendered = _lib.gigs_lite_forward(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, p(background, "background"), W, H,
+                gigs_lib.ctx_ptr(), geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, p(background, "background"), W, H,
                 p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors"), p(opacity, "opacity"), p(scales, "scales"),
                 float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"), p(viewmatrix, "viewmatrix"),
                 p(projmatrix, "projmatrix"), p(campos, "campos"), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GIGS_LIB", os.path.join(_HERE, "libgigs_hip.so"))  # GIGS_LIB: tuning builds
@@ -25,7 +26,7 @@ SIGNATURES = {
     "gigs_required_geom": (C.c_size_t, [_i]),
     "gigs_required_image": (C.c_size_t, [_i, _i]),
     "gigs_required_binning": (C.c_size_t, [_i]),
-    "gigs_forward": (_i, [ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
+    "gigs_forward": (_i, [C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
                           _i, _i, _i, _f, _i, _i,            # P D M background width height
                           _f, _f, _f, _f, _f, _f, _f, _f,    # means3D shs colors opac normal albedo rough metal
                           _f, _fl, _f, _f,                   # scales scale_modifier rotations cov3D
@@ -33,7 +34,7 @@ SIGNATURES = {
                           _i, _i, _i,                        # prefiltered argmax_depth inference
                           _f, _f, _f, _f, _f, _f, _f, _f, _f,  # 9 output planes
                           _f, _i, C.c_void_p]),              # radii debug stream
-    "gigs_backward": (_i, [_i, _i, _i, _i, _f, _i, _i,       # P D M R background width height
+    "gigs_backward": (_i, [C.c_void_p, _i, _i, _i, _i, _f, _i, _i,       # P D M R background width height
                            _f, _f, _f, _f, _f, _f, _f,       # means3D shs colors normal albedo rough metal
                            _f, _f, _f, _f, _f, _f, _f,       # scales rotations cov3D view proj campos radii
                            _fl, _fl, _fl,                    # scale_modifier tanfovx tanfovy
@@ -41,7 +42,7 @@ SIGNATURES = {
                            _f, _f, _f, _f, _f, _f, _f,       # 7 incoming grads
                            _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,  # 14 outputs
                            _i, C.c_void_p]),
-    "gigs_lite_forward": (_i, [ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
+    "gigs_lite_forward": (_i, [C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
                                _i, _i, _i, _f, _i, _i,            # P D M background width height
                                _f, _f, _f, _f,                    # means3D shs colors opacities
                                _f, _fl, _f, _f,                   # scales scale_modifier rotations cov3D
@@ -56,8 +57,8 @@ SIGNATURES = {
     "gigs_ssr": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f,
                       C.c_void_p]),
     "gigs_gi_scratch_bytes": (C.c_size_t, [_i, _i]),
-    "gigs_ssao_ex": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, C.c_void_p]),
-    "gigs_ssr_ex": (_i, [_i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,
+    "gigs_ssao_ex": (_i, [C.c_void_p, _i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, C.c_void_p]),
+    "gigs_ssr_ex": (_i, [C.c_void_p, _i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,
                          C.c_void_p]),
     "gigs_median3x3": (_i, [_i, _i, _i, _f, _f, C.c_void_p]),
     "gigs_median3x3_backward": (_i, [_i, _i, _i, _f, _f, _f, C.c_void_p]),
@@ -69,9 +70,9 @@ SIGNATURES = {
     "gigs_specular_cubemap_bwd": (_i, [_i, _f, _f, _fl, _fl, _f, C.c_void_p]),
     "gigs_specular_weights": (_i, [_i, _f, _f, _fl, _fl, _i, _f, C.c_void_p]),
     "gigs_specular_weights_divide": (_i, [_i, _f, _f, _f, _f, _f, C.c_void_p]),
-    "gigs_specular_cubemap_fwd_w": (_i, [_i, _f, _f, _f, _f, _i, _f, _f, C.c_void_p]),
-    "gigs_specular_cubemap_bwd_w": (_i, [_i, _f, _f, _f, _i, _f, _i, _f, C.c_void_p]),
-    "gigs_specular_cubemap_multi_w": (_i, [_i, C.c_void_p, _i, C.c_void_p]),
+    "gigs_specular_cubemap_fwd_w": (_i, [C.c_void_p, _i, _f, _f, _f, _f, _i, _f, _f, C.c_void_p]),
+    "gigs_specular_cubemap_bwd_w": (_i, [C.c_void_p, _i, _f, _f, _f, _i, _f, _i, _f, C.c_void_p]),
+    "gigs_specular_cubemap_multi_w": (_i, [C.c_void_p, _i, C.c_void_p, _i, C.c_void_p]),
     "gigs_cubemap_mip_fwd": (_i, [_i, _i, _f, _f, C.c_void_p]),
     "gigs_cubemap_mip_bwd_add": (_i, [_i, _f, _f, _f, C.c_void_p]),
     "gigs_cubemap_mip_bwd_add2": (_i, [_i, _f, _f, _f, _f, C.c_void_p]),
@@ -81,9 +82,9 @@ SIGNATURES = {
     "gigs_shade_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
                             C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
                             C.POINTER(C.c_void_p), C.c_void_p]),
-    "gigs_shade_fwd_ex": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
+    "gigs_shade_fwd_ex": (_i, [C.c_void_p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, C.c_void_p, C.c_void_p]),
-    "gigs_shade_bwd_ex": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
+    "gigs_shade_bwd_ex": (_i, [C.c_void_p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int), _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
                                C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     "gigs_gbuffer_post": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
@@ -119,9 +120,13 @@ SIGNATURES = {
     "gigs_image_offset": (C.c_longlong, [_i, _i, _i]),
     "gigs_selftest_div2": (_i, [_i, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_selftest_round": (_i, [_f, C.c_void_p]),
-    "gigs_set_blend_begin_event": (None, [C.c_void_p]),
+    "gigs_ctx_set_blend_begin_event": (_i, [C.c_void_p, C.c_void_p]),
     "gigs_stream_delay": (_i, [C.c_uint, C.c_void_p]),
-    "gigs_set_async_binning": (None, [_i, C.c_void_p]),
+    "gigs_ctx_set_async_binning": (_i, [C.c_void_p, _i, C.c_void_p]),
+    "gigs_ctx_create": (C.c_void_p, []),
+    "gigs_ctx_destroy": (None, [C.c_void_p]),
+    "gigs_ctx_get_options": (_i, [C.c_void_p, C.c_void_p]),
+    "gigs_ctx_set_options": (_i, [C.c_void_p, C.c_void_p]),
     "gigs_profile_begin": (None, []),
     "gigs_profile_end": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
     "gigs_profile_stage_name": (C.c_char_p, [_i]),
@@ -134,6 +139,18 @@ class ShadeExt(C.Structure):
                 ("g_albedo_mul_a", C.c_void_p), ("g_albedo_mul_b", C.c_void_p),
                 ("g_roughness_add", C.c_void_p), ("g_metallic_add", C.c_void_p),
                 ("g_scale", C.c_void_p), ("lamb_mask", C.c_void_p), ("lamb_acc4", C.c_void_p), ("part", C.c_int)]
+
+
+class Options(C.Structure):
+    """gigs_options of include/gigs_hip.h."""
+    _fields_ = [(n, C.c_int) for n in (
+        "struct_bytes", "binning_legacy", "bucket_max_mean", "long_lists", "bucket_target", "blend_cull",
+        "pre_bwd_sh_skip", "gi_march", "gi_cert", "gi_interleave", "gi_tile_log2w", "gi_zero_rays", "spec_max8",
+        "spec_max16", "shade_lds_floats", "shade_bwd_blocks")]
+
+
+OPTION_NAMES = tuple(n for n, _ in Options._fields_ if n != "struct_bytes")
+GI_MARCHES = ("exact", "hoist", "hoist_fma", "proj_nr", "proj")
 
 
 class SpecLevel(C.Structure):
@@ -213,3 +230,127 @@ class profile:
             if cnt[i]:
                 self.stages[lib().gigs_profile_stage_name(i).decode()] = (float(ms[i]), int(cnt[i]))
         return False
+
+
+# ------------------------------------------------------------------------------------------
+# contexts (gigs_ctx): per-instance state of the library -- options, asynchronous binning, scheduling event
+# ------------------------------------------------------------------------------------------
+class Context:
+    """An immutable gigs_ctx.  Contexts are interned by their complete settings (`Context.get`): asking twice for the same
+    options / asynchronous-binning buffer / event yields the same native object, so deriving one per call costs a
+    dictionary lookup.  `ptr` is what the C entry points take first (None = the library's default context)."""
+
+    _cache: dict = {}
+    _lock = threading.Lock()
+
+    def __init__(self, opts: tuple, async_capacity: int, async_counters, blend_event):
+        l = lib()
+        self.opts, self.async_capacity = tuple(opts), int(async_capacity)
+        self.async_counters, self.blend_event = async_counters, blend_event  # kept alive with the context
+        self.ptr = l.gigs_ctx_create()
+        if not self.ptr:
+            raise GigsError("gigs_ctx_create failed")
+        o = Options()
+        o.struct_bytes = C.sizeof(Options)
+        for n, v in zip(OPTION_NAMES, self.opts):
+            setattr(o, n, int(v))
+        check(l.gigs_ctx_set_options(self.ptr, C.byref(o)), "gigs_ctx_set_options")
+        if self.async_capacity > 0:
+            check(l.gigs_ctx_set_async_binning(self.ptr, self.async_capacity,
+                                               None if async_counters is None else async_counters.data_ptr()),
+                  "gigs_ctx_set_async_binning")
+        if blend_event is not None:
+            check(l.gigs_ctx_set_blend_begin_event(self.ptr, blend_event.cuda_event), "gigs_ctx_set_blend_begin_event")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().gigs_ctx_destroy(self.ptr)  # host memory only; queued work does not reference the context
+                self.ptr = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    @classmethod
+    def get(cls, opts: tuple, async_capacity: int = 0, async_counters=None, blend_event=None) -> "Context":
+        key = (tuple(int(v) for v in opts), int(async_capacity),
+               None if async_counters is None else async_counters.data_ptr(), None if blend_event is None else id(blend_event))
+        with cls._lock:
+            c = cls._cache.get(key)
+            if c is None:
+                if len(cls._cache) > 512:  # contexts of long-gone buffers: start over (live ones are re-created on demand)
+                    cls._cache.clear()
+                c = cls._cache[key] = cls(key[0], async_capacity, async_counters, blend_event)
+        return c
+
+    def derive(self, async_binning=None, blend_event="keep", **options) -> "Context":
+        """The context with some settings changed: option names of gigs_options (gi_march also by name), `async_binning` =
+        (capacity, counters tensor) or False to switch it off, `blend_event` = a torch.cuda.Event or None."""
+        opts = list(self.opts)
+        for k, v in options.items():
+            if k == "gi_march" and isinstance(v, str):
+                v = GI_MARCHES.index(v)
+            opts[OPTION_NAMES.index(k)] = int(v)
+        cap, cnt = self.async_capacity, self.async_counters
+        if async_binning is False:
+            cap, cnt = 0, None
+        elif async_binning is not None:
+            cap, cnt = async_binning
+        ev = self.blend_event if isinstance(blend_event, str) else blend_event
+        return Context.get(tuple(opts), cap, cnt, ev)
+
+    def option(self, name: str) -> int:
+        return self.opts[OPTION_NAMES.index(name)]
+
+
+_default_opts = None
+_tls = threading.local()
+
+
+def default_options() -> tuple:
+    """The library's default options: the GIGS_* environment as it was when the library first read it."""
+    global _default_opts
+    if _default_opts is None:
+        o = Options()
+        o.struct_bytes = C.sizeof(Options)
+        check(lib().gigs_ctx_get_options(None, C.byref(o)), "gigs_ctx_get_options")
+        _default_opts = tuple(getattr(o, n) for n in OPTION_NAMES)
+    return _default_opts
+
+
+def current() -> Context:
+    """The context the Python operators of this thread pass to the library."""
+    c = getattr(_tls, "ctx", None)
+    if c is None:
+        c = _tls.ctx = Context.get(default_options())
+    return c
+
+
+def ctx_ptr():
+    return current().ptr
+
+
+class use:
+    """`with use(ctx):` -- the operators called inside (on this thread) run with `ctx`."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self._prev = current()
+        _tls.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _tls.ctx = self._prev
+        return False
+
+
+def options(**kw) -> use:
+    """`with options(gi_march="exact", blend_cull=0):` -- the current context with these gigs_options changed."""
+    return use(current().derive(**kw))
+
+
+def set_options(**kw) -> Context:
+    """The same, for good (scripts and tools): replaces this thread's current context by the derived one."""
+    _tls.ctx = current().derive(**kw)
+    return _tls.ctx

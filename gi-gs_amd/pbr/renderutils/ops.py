@@ -68,7 +68,7 @@ class _specular_cubemap(torch.autograd.Function):
                                                               float(costheta_cutoff), out.data_ptr(), _stream()),
                                "specular_cubemap_fwd")
             else:
-                gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(res, c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
+                gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(gigs_lib.ctx_ptr(), res, c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
                                                                 tables[1].data_ptr(), _avg_window(tables, res),
                                                                 out.data_ptr(), None, _stream()),
                                "specular_cubemap_fwd_w")
@@ -88,7 +88,7 @@ class _specular_cubemap(torch.autograd.Function):
                                                               float(ctx.theta_cutoff), g.data_ptr(), _stream()),
                                "specular_cubemap_bwd")
             else:
-                gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
+                gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(gigs_lib.ctx_ptr(), ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
                                                                 ctx.tables[2].data_ptr(), _avg_window(ctx.tables, ctx.res),
                                                                 d.data_ptr(), 0, g.data_ptr(), _stream()),
                                "specular_cubemap_bwd_w")
@@ -139,7 +139,7 @@ class _specular_cubemap_normalized(torch.autograd.Function):
         out = torch.empty((6, res, res, 3), dtype=torch.float32, device=c.device)
         wsum = torch.empty((6, res, res, 1), dtype=torch.float32, device=c.device)
         with torch.cuda.device(c.device):
-            gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(res, c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
+            gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(gigs_lib.ctx_ptr(), res, c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
                                                             tables[1].data_ptr(), _avg_window(tables, res), out.data_ptr(),
                                                             wsum.data_ptr(), _stream()),
                            "specular_cubemap_fwd_w")
@@ -157,7 +157,7 @@ class _specular_cubemap_normalized(torch.autograd.Function):
             d, table = (_gpu(dout, "dout") / wsum).contiguous(), ctx.tables[2]  # w does not depend on the cubemap
         g = torch.empty((6, ctx.res, ctx.res, 3), dtype=torch.float32, device=d.device)
         with torch.cuda.device(d.device):
-            gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
+            gigs_lib.check(_lib.gigs_specular_cubemap_bwd_w(gigs_lib.ctx_ptr(), ctx.res, bounds.data_ptr(), ctx.tables[0].data_ptr(),
                                                             table.data_ptr(), _avg_window(ctx.tables, ctx.res),
                                                             d.data_ptr(), 1, g.data_ptr(), _stream()),
                            "specular_cubemap_bwd_w")
@@ -187,7 +187,7 @@ class _specular_levels(torch.autograd.Function):
             arr[i] = gigs_lib.SpecLevel(res, _avg_window(tables, res), c.data_ptr(), bounds.data_ptr(), tables[0].data_ptr(),
                                         tables[1].data_ptr(), out.data_ptr(), wsum.data_ptr())
         with torch.cuda.device(dev):
-            gigs_lib.check(_lib.gigs_specular_cubemap_multi_w(len(cs), C.cast(arr, C.c_void_p), 0, _stream()),
+            gigs_lib.check(_lib.gigs_specular_cubemap_multi_w(gigs_lib.ctx_ptr(), len(cs), C.cast(arr, C.c_void_p), 0, _stream()),
                            "specular_cubemap_multi_w")
         ctx.meta = meta
         ctx.shapes = [c.shape[1] for c in cs]
@@ -208,7 +208,7 @@ class _specular_levels(torch.autograd.Function):
         with torch.cuda.device(dev):
             if bwd_head_start_ns > 0:  # see gigs_stream_delay: set by pipeline.WholeStepGraph while it captures the backward
                 gigs_lib.check(_lib.gigs_stream_delay(int(bwd_head_start_ns), _stream()), "stream_delay")
-            gigs_lib.check(_lib.gigs_specular_cubemap_multi_w(len(douts), C.cast(arr, C.c_void_p), 1, _stream()),
+            gigs_lib.check(_lib.gigs_specular_cubemap_multi_w(gigs_lib.ctx_ptr(), len(douts), C.cast(arr, C.c_void_p), 1, _stream()),
                            "specular_cubemap_multi_w")
         return (None, *gs)
 
@@ -263,7 +263,7 @@ def _weight_tables(res, roughness, cutoff, device):
                     ones = torch.ones((6, res, res, 3), dtype=torch.float32, device=device)
                     tmp = torch.empty_like(ones)
                     wsum = torch.empty((6, res, res), dtype=torch.float32, device=device)
-                    gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(res, ones.data_ptr(), bounds.data_ptr(),
+                    gigs_lib.check(_lib.gigs_specular_cubemap_fwd_w(gigs_lib.ctx_ptr(), res, ones.data_ptr(), bounds.data_ptr(),
                                                                     offsets.data_ptr(), tabs[0].data_ptr(), 0,
                                                                     tmp.data_ptr(), wsum.data_ptr(), _stream()),
                                    "specular_cubemap_fwd_w")

@@ -14,10 +14,13 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F
+
+import gigs_lib  # noqa: E402  (importable once the package's __init__ has put this directory on sys.path)
 
 from diff_gaussian_rasterization import (AsyncBinning, BinningOverflow, GaussianRasterizationSettings, GaussianRasterizer,
                                          Gaussian_SSR, OutputPool, _C as _ops, after_blend, filters)
@@ -238,18 +241,16 @@ class RasterFront(torch.nn.Module):
                                       rotations=rotations, derive_normal=True)
 
 
-BUCKET_MAX_MEAN_LIST = int(os.environ.get("GIGS_BUCKET_MAX_MEAN", "2500"))  # csrc/gigs_common.h kBucketMaxMeanList
-
-
 class DenseScene(RuntimeError):
-    """Raised by the graph-capturing steppers only under GIGS_LONG_LISTS=0 for a scene that averages more instances per
+    """Raised by the graph-capturing steppers only under long_lists = 0 (gigs_options; GIGS_LONG_LISTS=0) for a scene that averages more instances per
     tile than one workgroup sorts in LDS: the caller then keeps the synchronous path.  By default dense scenes (3 M
     Gaussians at the Mip-NeRF360 images_4 sizes: 7 000 instances per tile) are NOT declined: the library partitions
     their long tile lists by sampled splitters (csrc/binning.hip) and they take the asynchronous, captured path."""
 
 
 def _declined_as_dense(probe: int, tiles: int) -> bool:
-    return probe > BUCKET_MAX_MEAN_LIST * tiles and os.environ.get("GIGS_LONG_LISTS", "") == "0"
+    c = gigs_lib.current()
+    return probe > c.option("bucket_max_mean") * tiles and c.option("long_lists") == 0
 
 
 class GraphedRaster:
@@ -320,8 +321,15 @@ class GraphedRaster:
             return self.bin.check()
         except BinningOverflow as ex:
             self.capacity = -(-int(1.5 * ex.needed) // 65536) * 65536
-            self.fn = None  # next call re-captures with the larger buffer
+            self.close()  # next call re-captures with the larger buffer
             raise
+
+    def close(self) -> None:
+        """Release the captured callable with the device idle before and after (see WholeStepGraph._drop_graphs)."""
+        if self.fn is not None:
+            torch.cuda.synchronize(self.dev)
+            self.fn = None
+            torch.cuda.synchronize(self.dev)
 
 
 def _graphed_inference(mod, sample):
@@ -384,16 +392,46 @@ class WholeStepGraph:
     repeated; its gradients are never handed out."""
 
     def __init__(self, owner: "Stage2Step", cam: Dict, g: Dict[str, torch.Tensor]):
-        self.owner = owner
+        # a weak reference: the stepper owns its WholeStepGraphs, not the other way round -- no reference cycle, so the
+        # graph execs die where the code says (close(), or the owner's last reference going away), never "whenever the
+        # cyclic collector happens to run" (the round-3 host segfault in hip::Graph::UpdateStreams: DESIGN.md section 5)
+        self.owner = weakref.proxy(owner)
         self.dev = next(iter(g.values())).device
         self.cfg = (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"]))
         self.capacity = 0
         self.gf = self.gb = self.go = self.key = self.adam = None
+        self.res = self.grads = self.vp_grad = self.inner = self.bin = None
+        self._src = {}
         self.recaptures = 0
         self.fwd_done = torch.cuda.Event()
         self._packs = {}
 
     CAM_TENSORS = ("viewmatrix", "projmatrix", "campos")
+
+    def _drop_graphs(self):
+        """Release the three graph execs and what only they keep alive, with the device idle before AND after: an exec is
+        never destroyed while one of its replays may still be running, and nothing is captured or replayed before the
+        destruction has completed."""
+        if self.gf is None and self.gb is None and self.go is None:
+            return
+        torch.cuda.synchronize(self.dev)
+        self.gf = self.gb = self.go = self.adam = self.key = None
+        self.res = self.grads = self.vp_grad = None
+        torch.cuda.synchronize(self.dev)
+
+    def close(self):
+        """Deterministic teardown: the graphs, the captured eager step, the binning buffer and the per-camera caches.  The
+        object captures again if it is called afterwards."""
+        self._drop_graphs()
+        self.inner = self.bin = None
+        self._packs.clear()
+        self._src = {}
+
+    def __del__(self):
+        try:
+            self._drop_graphs()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     def _params(self, g):
         light = getattr(self.owner, "light", None)
@@ -437,7 +475,7 @@ class WholeStepGraph:
         self.s_vd, self.s_gt = view_dirs.detach().clone(), gt_image.detach().clone()
         self._src = {}  # static buffer -> (data_ptr, version) of the tensor it was last filled from
         params = self._params(g)
-        self.gf = self.gb = self.go = None
+        self._drop_graphs()
         _collect_idle()
         # warm-up on a side stream: builds every cached table / library buffer outside the capture
         side = torch.cuda.Stream()
@@ -454,8 +492,10 @@ class WholeStepGraph:
             from optim import CapturedAdam
             CapturedAdam.warmup_device(self.dev)
             if o.post_update is not None:
-                with torch.no_grad():
-                    o.post_update()  # idempotent (a clamp): run once outside the capture as its warm-up
+                # warm the clamp kernel on a scratch tensor, not on the live parameter: the reference clamps only AFTER an
+                # optimizer step (train.py:523), so a light handed in with negative texels must reach its first forward
+                # unchanged on this path as on the eager one
+                torch.zeros(8, device=self.dev).clamp_(min=0.0)
             torch.cuda.synchronize()
         self._seed = torch.ones((), dtype=torch.float32, device=self.dev)
         _collect_idle()
@@ -554,7 +594,7 @@ class WholeStepGraph:
             r, over = int(self.bin.host[0]), int(self.bin.host[1])
             if over:
                 self.capacity = -(-int(1.5 * over) // 65536) * 65536
-                self.gf = None
+                self._drop_graphs()  # waits for the backward replay that is still running, then releases the execs
                 continue
             params = self._params(g)
             if self.go is not None:
@@ -698,6 +738,8 @@ class Stage2Step:
                 # more than four distinct camera models: the fifth onwards takes the piecewise path below
             except DenseScene:
                 self._dense = True  # synchronous binning with the global radix sort: the rasterizer stays eager
+                for w in self._wholes.values():
+                    w.close()
                 self.whole = None
                 self._wholes.clear()
         regen = (lambda: self.prepare(raw)) if self.prepare is not None else None
@@ -733,12 +775,9 @@ class Stage2Step:
         m2d = getattr(self, "_static_m2d", None)
         if self.fused:
             if self.step_begin is None:
-                import gigs_lib
                 self.step_begin, self.blend_begin = torch.cuda.Event(), torch.cuda.Event()
                 self.blend_begin.record()  # creates the underlying hipEvent; the library re-records it in the forward
-                self._set_blend_event = gigs_lib.lib().gigs_set_blend_begin_event
             self.step_begin.record()
-            self._set_blend_event(self.blend_begin.cuda_event)  # only for this forward: cleared again below
         lights = []
         hook = after_blend((lambda: lights.extend(self._fused_begin())) if self.fused else None)
         # eager rasterizer without the host read-back: asynchronous binning into a fixed-capacity buffer (sized from one
@@ -747,18 +786,18 @@ class Stage2Step:
         if self.fused and self.graphs and os.environ.get("GIGS_RASTER_ASYNC", "1") == "1" and not getattr(self, "_dense", False):
             abin = self._eager_async(cam, g, background)
         pre_grads = _snapshot_grads(self._leaves(g)) if abin is not None else None
-        try:
-            with hook, (abin if abin is not None else _NULLCTX):
+        # the blend-begin event belongs to THIS step's forward: it is part of the library context the forward runs with
+        # (gigs_ctx_set_blend_begin_event), not of the process
+        with hook, (abin if abin is not None else _NULLCTX):
+            ev_ctx = gigs_lib.use(gigs_lib.current().derive(blend_event=self.blend_begin)) if self.fused else _NULLCTX
+            with ev_ctx:
                 if self.pool is not None:
                     with self.pool:
                         out = rasterize(cam, g, self.sh_degree, background, self.gi, means2D=m2d)
                 else:
                     out = rasterize(cam, g, self.sh_degree, background, self.gi, means2D=m2d)
-            if abin is not None:
-                abin.snapshot()
-        finally:
-            if self.fused:
-                self._set_blend_event(None)
+        if abin is not None:
+            abin.snapshot()
         ((_, radii, _, _, normal_map_from_depth, normal_map, occlusion_map, albedo_map, roughness_map, metallic_map,
           out_normal_view, depth_pos), screenspace_points, st) = out
         H, W = cam["image_height"], cam["image_width"]
@@ -993,12 +1032,50 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     return res
 
 
+
+def _close_stepper(self):
+    """Deterministic teardown of everything that owns hipGraphs (WholeStepGraphs, graphed callables, the graphed
+    rasterizer): synchronise, release, synchronise.  The stepper captures again if it is called afterwards.  Steppers and
+    trainers are context managers (`with Stage2Trainer(...) as tr:`) that close on exit."""
+    for w in list(getattr(self, "_wholes", {}).values()):
+        w.close()
+    if getattr(self, "whole", None) is not None:
+        self.whole.close()
+    self.whole = None
+    if hasattr(self, "_wholes"):
+        self._wholes.clear()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if getattr(self, "_captured", False):  # piecewise path: the two graphed callables
+        self.front = Stage2Front(self.light, self.brdf_lut, **self.flags)
+        self.loss_fn = stage2_loss
+        self._captured = False
+    if getattr(self, "graster", None) is not None:
+        self.graster.close()
+    for name in ("graster", "back", "mips"):
+        if getattr(self, name, None) is not None:
+            setattr(self, name, None)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def _enter(self):
+    return self
+
+
+def _exit(self, *exc):
+    self.close()
+    return False
+
 def _make_inner(self):
     return Stage2Step(self.light, self.brdf_lut, self.gi, self.sh_degree, graphs=False, fused=True, regularizer=self.regularizer,
                       **self.flags)
 
 
 Stage2Step._make_inner = _make_inner
+Stage2Step.close = _close_stepper
+Stage2Step.__enter__ = _enter
+Stage2Step.__exit__ = _exit
 
 
 def _leaves(self, g):
@@ -1081,6 +1158,8 @@ class Stage1Step:
                     return self.whole(cam, raw, gt_image, view_dirs if view_dirs is not None else self._no_vd)
             except DenseScene:
                 self._dense = True
+                for w in self._wholes.values():
+                    w.close()
                 self.whole = None
                 self._wholes.clear()
         if self.prepare is not None:
@@ -1094,6 +1173,11 @@ class Stage1Step:
             for leaf in raw.values():
                 leaf.grad = None
         return res
+
+
+Stage1Step.close = _close_stepper
+Stage1Step.__enter__ = _enter
+Stage1Step.__exit__ = _exit
 
 
 def stage2_step(cam: Dict, g: Dict[str, torch.Tensor], sh_degree: int, gi: Dict, light, brdf_lut: torch.Tensor,

@@ -108,7 +108,7 @@ class Relighter:
                     probe = pipeline.GraphedRaster(cam, g, self.gi, self.sh_degree, inference=True)
                     r = probe._probe(cam, g, torch.zeros(3, device=g["means3D"].device))
                     tiles = ((int(cam["image_height"]) + 15) // 16) * ((int(cam["image_width"]) + 15) // 16)
-                    if r > pipeline.BUCKET_MAX_MEAN_LIST * tiles:
+                    if pipeline._declined_as_dense(r, tiles):
                         raise pipeline.DenseScene(f"{r} instances over {tiles} tiles")
                     self._capacity = max(65536, -(-2 * r // 65536) * 65536)
                 self._bin = AsyncBinning(self._capacity, g["means3D"].device)
@@ -131,8 +131,15 @@ class Relighter:
                 return out
             except BinningOverflow as ex:
                 self._capacity = -(-int(1.5 * ex.needed) // 65536) * 65536
-                self._graph = None
+                self.close()
         raise RuntimeError("Relighter: the binning capacity kept overflowing")
+
+    def close(self) -> None:
+        """Release the view graph with the device idle before and after (see pipeline.WholeStepGraph._drop_graphs)."""
+        if self._graph is not None:
+            torch.cuda.synchronize()
+            self._graph = self._graph_key = None
+            torch.cuda.synchronize()
 
     # -- the reference's op sequence, operator by operator ------------------------------------------------------
     def _unfused(self, cam, g, view_dirs, alpha_mask, albedo_ratio):
@@ -201,7 +208,7 @@ class Relighter:
             gigs_lib.check(_lib.gigs_gbuffer_post(H, W, p(normal_map), p(out_normal_view), p(vm), p(normals_view), p(mask_u8),
                                                   p(mask_f), p(onv), s), "gbuffer_post")
             gigs_lib.check(_lib.gigs_shade_fwd_ex(
-                H, W, p(normals_view), p(vd), p(albedo_shade), p(roughness_map), p(mask_u8), p(occlusion),
+                gigs_lib.ctx_ptr(), H, W, p(normals_view), p(vd), p(albedo_shade), p(roughness_map), p(mask_u8), p(occlusion),
                 p(metallic_map) if self.metallic else None, None, p(light.diffuse), int(light.diffuse.shape[1]), len(spec),
                 spec_ptr, spec_res, p(lut), int(lut.shape[-2]), int(lut.shape[-3]), int(self.tone), int(self.gamma),
                 p(render_direct), None, None, None, C.addressof(ext), s), "shade_fwd_ex")

@@ -71,7 +71,7 @@ class _Stage2Fused(torch.autograd.Function):
             gigs_lib.check(_lib.gigs_gbuffer_post(H, W, _p(normal_map), _p(out_normal_view), _p(viewmatrix),
                                                   _p(normals_view), _p(mask_u8), _p(mask_f), _p(onv), s), "gbuffer_post")
             gigs_lib.check(_lib.gigs_shade_fwd_ex(
-                H, W, _p(normals_view), _p(view_dirs), _p(albedo_map), _p(roughness_map), _p(mask_u8), _p(occlusion),
+                gigs_lib.ctx_ptr(), H, W, _p(normals_view), _p(view_dirs), _p(albedo_map), _p(roughness_map), _p(mask_u8), _p(occlusion),
                 _p(metallic_map) if use_metallic else None, None, _p(diffuse), int(diffuse.shape[1]), len(specular),
                 spec_ptr, spec_res, _p(lut), int(lut.shape[-2]), int(lut.shape[-3]), int(bool(cfg["tone"])),
                 int(bool(cfg["gamma"])), _p(render_direct), None, None, None, C.addressof(ext), s), "shade_fwd_ex")
@@ -123,7 +123,7 @@ class _Stage2Fused(torch.autograd.Function):
             ext = gigs_lib.ShadeExt(planar=1, rough_scale=1.0 - 0.04, rough_bias=0.04, g_albedo_mul_a=_p(d_irr_u),
                                     g_albedo_mul_b=_p(abd), g_scale=_p(g_loss), lamb_mask=_p(mask_f), lamb_acc4=_p(acc4), part=part)
             gigs_lib.check(_lib.gigs_shade_bwd_ex(
-                H, W, _p(normals_view), _p(view_dirs), _p(albedo_map), _p(roughness_map), _p(mask_u8), _p(occlusion),
+                gigs_lib.ctx_ptr(), H, W, _p(normals_view), _p(view_dirs), _p(albedo_map), _p(roughness_map), _p(mask_u8), _p(occlusion),
                 _p(metallic_map), _p(diffuse), int(diffuse.shape[1]), len(specular), spec_ptr, spec_res, _p(lut),
                 int(lut.shape[-2]), int(lut.shape[-3]), int(bool(cfg["tone"])), int(bool(cfg["gamma"])), _p(d_direct_u),
                 None, None, None, _p(d_albedo), _p(d_rough), _p(d_metal), _p(d_diffuse), dspec_ptr, C.addressof(ext), stream),

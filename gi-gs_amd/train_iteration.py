@@ -106,6 +106,19 @@ class Stage2Trainer:
     def iteration(self, cam: Dict, gt_image: torch.Tensor, view_dirs: torch.Tensor) -> Dict[str, torch.Tensor]:
         return self.stepper(cam, self.raw, gt_image, view_dirs)
 
+    def close(self) -> None:
+        """Deterministic teardown of the stepper's hipGraphs (synchronise, release, synchronise): call it when the trainer
+        is done -- a trainer references its stepper and the stepper the trainer's bound methods, so without it the graph
+        execs would live until a cyclic-GC pass.  `with Stage2Trainer(...) as tr:` closes on exit."""
+        self.stepper.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def replace_parameters(self, raw: Dict[str, torch.Tensor]) -> None:
         """After densification / pruning / opacity reset (densify.py on `self.optimizer`, as the reference's
         GaussianModel methods do, scene/gaussian_model.py:580-931): the optimizer's groups hold NEW tensor objects and
@@ -116,6 +129,7 @@ class Stage2Trainer:
         held = {id(g["params"][0]) for g in self.optimizer.param_groups}
         if any(id(raw[k]) not in held for k in RAW_KEYS):
             raise ValueError("replace_parameters: the tensors must be the ones the optimizer's groups hold")
+        self.stepper.close()  # the graphs around the old tensors are released here, with the device idle
         self.raw = {k: raw[k] for k in RAW_KEYS}
 
     # the tensors a stage-2 iteration's loss reaches (train.py:330-420): everything else gets exact zeros
@@ -179,10 +193,24 @@ class Stage1Trainer:
     def iteration(self, cam: Dict, gt_image: torch.Tensor) -> Dict[str, torch.Tensor]:
         return self.stepper(cam, self.raw, gt_image)
 
+    def close(self) -> None:
+        """Deterministic teardown of the stepper's hipGraphs (synchronise, release, synchronise): call it when the trainer
+        is done -- a trainer references its stepper and the stepper the trainer's bound methods, so without it the graph
+        execs would live until a cyclic-GC pass.  `with Stage1Trainer(...) as tr:` closes on exit."""
+        self.stepper.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def replace_parameters(self, raw: Dict[str, torch.Tensor]) -> None:
         held = {id(g["params"][0]) for g in self.optimizer.param_groups}
         if any(k not in raw or id(raw[k]) not in held for k in RAW_KEYS):
             raise ValueError("replace_parameters: pass the tensors the optimizer's groups hold, under the reference's names")
+        self.stepper.close()
         self.raw = {k: raw[k] for k in RAW_KEYS}
 
 
@@ -199,10 +227,14 @@ def bench_stage1_iteration(sc, gi, sh_degree, cams_t, gt_image, steps=40, warmup
         out = tr.iteration(cams_t[(warmup + i) % n], gt_image)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"iterations_per_s": round(1.0 / dt, 2), "ms_per_iteration": round(1e3 * dt, 3), "steps": steps, "final_loss": float(out["loss"]),
+    formulation = "3 hipGraphs (fwd, bwd, update)" if tr.stepper.whole is not None else "eager"
+    final_loss = float(out["loss"])
+    del out
+    tr.close()
+    return {"iterations_per_s": round(1.0 / dt, 2), "ms_per_iteration": round(1e3 * dt, 3), "steps": steps, "final_loss": final_loss,
             "what": "activations + rasterizer + in-op filters + SSAO + G-buffer post-processing + L1 + D-SSIM + masked normal L1 + "
                     "normal TV + backward (colour and normal gradients: the blend backward's full chain) + Adam (train.py:266-331, 517-520)",
-            "formulation": "3 hipGraphs (fwd, bwd, update)" if tr.stepper.whole is not None else "eager"}
+            "formulation": formulation}
 
 
 def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_image, steps=40, warmup=5) -> Dict:
@@ -221,10 +253,13 @@ def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_im
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     whole = tr.stepper.whole is not None
+    final_loss = float(out["loss"])
+    del out
+    tr.close()
     with torch.no_grad():
         light.base.copy_(base0)  # bench.py's light is shared with the legs that follow
     return {"iterations_per_s": round(1.0 / dt, 2), "ms_per_iteration": round(1e3 * dt, 3), "steps": steps,
-            "final_loss": float(out["loss"]),
+            "final_loss": final_loss,
             "what": "activations + rasterizer + SSAO + build_mips + shade + SSR + L1 + lamb + masked BRDF TV + envmap TV + "
                     "backward + Adam (10 Gaussian groups + light) + clamp (train.py:247-523 without data loading / densification)",
             "formulation": "3 hipGraphs (fwd, bwd, update)" if whole else "eager rasterizer (dense scene / fallback), fused glue"}

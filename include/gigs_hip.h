@@ -44,6 +44,49 @@ const char* gigs_last_error(void);
 /* "gfx950" -- the only architecture the code objects are built for. */
 const char* gigs_build_arch(void);
 
+/* ---- contexts: per-instance state -----------------------------------------------------------------
+ * The reference's rasterizer is a set of stateless static methods (R/cuda_rasterizer/rasterizer.h:20-199) that
+ * all run on the legacy default stream.  This library adds streams, an asynchronous binning mode, a
+ * scheduling event and a number of tuning / diagnostic switches -- and keeps ALL of that in a context the
+ * caller owns, so that two rasterizer instances (or two streams) of one process do not see each other:
+ * every entry point that reads such state takes a `gigs_ctx*` first.  NULL = the default context: the
+ * options below as the environment gave them when the library was first used (parsed ONCE, immutable
+ * afterwards), no asynchronous binning, no event.  A context may be used by one thread at a time;
+ * different contexts are independent (what the library itself caches process-wide -- ray tables, texel
+ * tables, temp-storage sizes -- is keyed by its inputs and never modified once built).
+ * The in-library profile session (gigs_profile_begin/end, a bench.py diagnostic) is the one process-wide
+ * facility left. */
+typedef struct gigs_ctx gigs_ctx;
+typedef struct gigs_options {
+  int struct_bytes;     /* sizeof(gigs_options): set by the caller (ABI growth) */
+  int binning_legacy;   /* 0 (default) tile-bucketed binning; 1 scan / duplicate / global radix sort / tile ranges, the
+                           reference's structure (identical keys, point_list, ranges).        env GIGS_BINNING=legacy */
+  int bucket_max_mean;  /* mean instances per tile above which a scene counts as dense (2500). env GIGS_BUCKET_MAX_MEAN */
+  int long_lists;       /* -1 (default) by density, 0 / 1 forbid / force the long-list partition.  env GIGS_LONG_LISTS */
+  int bucket_target;    /* keys per bucket of that partition (1536).                            env GIGS_BUCKET_TARGET */
+  int blend_cull;       /* 1 (default); 0 = blend forward without the quadrant cull (same bits). env GIGS_BLEND_CULL */
+  int pre_bwd_sh_skip;  /* 1 (default); 0 = the preprocess backward evaluates every chain.   env GIGS_PRE_BWD_SH_SKIP */
+  int gi_march;         /* SSAO / SSR march: 0 exact (the oracle's pixel choices bit for bit), 1 hoist, 2 hoist_fma,
+                           3 proj_nr, 4 proj (default).              env GIGS_GI_MARCH=exact|hoist|hoist_fma|proj_nr|proj */
+  int gi_cert;          /* 1 (default) coarse-depth certification in front of marches 3 / 4 (same bits). env GIGS_GI_CERT */
+  int gi_interleave;    /* 1 (default) interleaved ray pairs per wave, 0 contiguous quarters.     env GIGS_GI_INTERLEAVE */
+  int gi_tile_log2w;    /* pixel rectangle of a march workgroup, 2^k x 64/2^k, k = 0..6 (3).      env GIGS_GI_TILE_LOG2W */
+  int gi_zero_rays;     /* 0 (default) the zero-weight rays (theta = 0: 32 of 512 at delta 0.0625) are not marched -- their
+                           contributions are exact zeros; 1 = marched all the same (same bits).   env GIGS_GI_ZERO_RAYS */
+  int spec_max8;        /* largest mean GGX window served by 8-lane groups (128).                   env GIGS_SPEC_MAX8 */
+  int spec_max16;       /* ... by 16-lane groups (1500).                                            env GIGS_SPEC_MAX16 */
+  int shade_lds_floats; /* LDS accumulator budget of the shade backward in floats (30720).    env GIGS_SHADE_LDS_FLOATS */
+  int shade_bwd_blocks; /* its persistent workgroups, 0 (default) = one per CU.               env GIGS_SHADE_BWD_BLOCKS */
+} gigs_options;
+/* A new context holds a copy of the default options.  Destroying a context frees host memory only; work queued
+ * with it may still be running. */
+gigs_ctx* gigs_ctx_create(void);
+void gigs_ctx_destroy(gigs_ctx* ctx);
+/* out->struct_bytes must be set by the caller; ctx == NULL reads the defaults.  set: values outside their range are
+ * rejected (GIGS_ERR_INVALID) and nothing changes; ctx must not be NULL (the default context is immutable). */
+int gigs_ctx_get_options(const gigs_ctx* ctx, gigs_options* out);
+int gigs_ctx_set_options(gigs_ctx* ctx, const gigs_options* in);
+
 /* Scratch sizes: required<GeometryState>(P), required<ImageState>(N), required<BinningState>(R)
  * (R/cuda_rasterizer/rasterizer_impl.h:67-73).  Need a visible GPU (rocPRIM temp-storage
  * queries). Return 0 and set the error string on failure. */
@@ -56,7 +99,7 @@ size_t gigs_required_binning(int num_rendered);
  * -> tile ranges -> G-buffer blend.  `background` is 3 floats.  `radii` may be NULL.
  * Every pixel of every output plane and every radii[i] is written when P > 0; when P == 0 nothing
  * is launched and the caller's (zero) initialisation stays. */
-int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer,
+int gigs_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer,
                  void* binning_user, gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M,
                  const float* background, int width, int height, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* opacities,
@@ -75,7 +118,7 @@ int gigs_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn bi
  * are the two scratch gradients the reference allocates but does not return: either may be NULL (not
  * written).  Any of the seven incoming dL_dpix_* planes may be NULL = an all-zero gradient (an output
  * the loss does not use). */
-int gigs_backward(int P, int D, int M, int R, const float* background, int width, int height,
+int gigs_backward(gigs_ctx* ctx, int P, int D, int M, int R, const float* background, int width, int height,
                   const float* means3D, const float* shs, const float* colors_precomp,
                   const float* normal, const float* albedo, const float* roughness,
                   const float* metallic, const float* scales, const float* rotations,
@@ -122,12 +165,13 @@ int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, 
  * extension; may be NULL = identical to the plain entries).  With it the default march first builds a min/max table
  * of the position plane's z over 16..64-pixel blocks there and skips, conservatively, the z-plane lookups of samples
  * that cannot hit: bit-identical outputs, ~92 % fewer gathers on the bench view.  The buffer is
- * only used during the call's kernels (stream-ordered). */
+ * only used during the call's kernels (stream-ordered).  `ctx` selects the march (gigs_options.gi_*; NULL = defaults);
+ * gigs_ssao / gigs_ssr are these with ctx = NULL and scratch = NULL. */
 size_t gigs_gi_scratch_bytes(int width, int height);
-int gigs_ssao_ex(int width, int height, float focal_x, float focal_y, float radius, float bias,
+int gigs_ssao_ex(gigs_ctx* ctx, int width, int height, float focal_x, float focal_y, float radius, float bias,
                  float thick, float delta, int step, int start, const float* normal_view,
                  const float* pos, float* occlusion, void* scratch, void* stream);
-int gigs_ssr_ex(int width, int height, float focal_x, float focal_y, float radius, float bias,
+int gigs_ssr_ex(gigs_ctx* ctx, int width, int height, float focal_x, float focal_y, float radius, float bias,
                 float thick, float delta, int step, int start, const float* normal_view,
                 const float* pos, const float* rgb, const float* albedo, const float* roughness,
                 const float* metallic, const float* F0, float* color, float* abd, void* scratch, void* stream);
@@ -184,9 +228,9 @@ int gigs_specular_weights_divide(int res, const float* bounds, const uint32_t* o
  * weight sums go to wsum_out [6,res,res].  grad_is_rgb: grad_out is [6,res,res,3] (already divided
  * by wsum by the caller) instead of [6,res,res,4].  avg_window = table length / (6 res^2), the mean
  * number of candidates per texel: a scheduling hint only (lanes per texel), 0 = unknown. */
-int gigs_specular_cubemap_fwd_w(int res, const float* cubemap, const float* bounds, const uint32_t* offsets,
+int gigs_specular_cubemap_fwd_w(gigs_ctx* ctx, int res, const float* cubemap, const float* bounds, const uint32_t* offsets,
                                 const float* weights, int avg_window, float* out, float* wsum_out, void* stream);
-int gigs_specular_cubemap_bwd_w(int res, const float* bounds, const uint32_t* offsets,
+int gigs_specular_cubemap_bwd_w(gigs_ctx* ctx, int res, const float* bounds, const uint32_t* offsets,
                                 const float* weights_swapped, int avg_window, const float* grad_out,
                                 int grad_is_rgb, float* grad_cubemap, void* stream);
 
@@ -205,7 +249,7 @@ typedef struct gigs_spec_level {
   float* dst;
   float* wsum;
 } gigs_spec_level;
-int gigs_specular_cubemap_multi_w(int n_levels, const gigs_spec_level* levels, int backward, void* stream);
+int gigs_specular_cubemap_multi_w(gigs_ctx* ctx, int n_levels, const gigs_spec_level* levels, int backward, void* stream);
 /* cubemap_mip (pbr/light.py:54-79): forward 2x2 average pool [6,2r,2r,C] -> [6,r,r,C]; backward =
  * bilinear cube lookup of 0.25*dout at every fine texel direction, dout [6,r,r,3] -> din [6,2r,2r,3]. */
 int gigs_cubemap_mip_fwd(int res_out, int channels, const float* in, float* out, void* stream);
@@ -268,13 +312,13 @@ typedef struct gigs_shade_ext {
                touched); 2 = d_diffuse / d_spec only (the material outputs may be NULL).  The two parts of one backward may run
                on different streams: the material gradients feed the rasterizer's backward, the light's feed its filters'. */
 } gigs_shade_ext;
-int gigs_shade_fwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+int gigs_shade_fwd_ex(gigs_ctx* ctx, int H, int W, const float* normals, const float* view_dirs, const float* albedo,
                       const float* roughness, const uint8_t* mask, const float* occlusion,
                       const float* metallic, const float* background, const float* diffuse, int diffuse_res,
                       int n_levels, const float* const* spec, const int* spec_res, const float* lut,
                       int lut_w, int lut_h, int tone, int gamma, float* render_rgb, float* diffuse_rgb,
                       float* specular_rgb, float* diffuse_light, const gigs_shade_ext* ext, void* stream);
-int gigs_shade_bwd_ex(int H, int W, const float* normals, const float* view_dirs, const float* albedo,
+int gigs_shade_bwd_ex(gigs_ctx* ctx, int H, int W, const float* normals, const float* view_dirs, const float* albedo,
                       const float* roughness, const uint8_t* mask, const float* occlusion,
                       const float* metallic, const float* diffuse, int diffuse_res, int n_levels,
                       const float* const* spec, const int* spec_res, const float* lut, int lut_w, int lut_h,
@@ -472,7 +516,7 @@ int gigs_selftest_round(unsigned long long* mismatches, void* stream);
  * R/rasterize_points.cu:39-127): colour [3,H,W], opacity [1,H,W] and depth [1,H,W] only, "for baking".  Composites exactly
  * like gigs_forward; the geometry / image callbacks are asked for somewhat more than gigs_required_geom / _image
  * (zero material attributes and the planes that are not returned live there).  Returns num_rendered. */
-int gigs_lite_forward(gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer, void* binning_user,
+int gigs_lite_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_user, gigs_alloc_fn binningBuffer, void* binning_user,
                       gigs_alloc_fn imageBuffer, void* image_user, int P, int D, int M, const float* background, int width,
                       int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -488,8 +532,8 @@ int gigs_ssr_backward(int width, int height, const float* grad_color, const floa
 /* Optional scheduling hook: a hipEvent_t (caller-owned, NULL = none) that gigs_forward records on its stream right
  * before it launches the alpha-blend kernel, so that a caller can start independent work on another stream next to
  * that kernel (it is latency-bound and leaves most CUs idle) rather than next to the bandwidth-bound binning kernels.
- * Process-wide; set it before the forward that should record it. */
-void gigs_set_blend_begin_event(void* hip_event);
+ * Per context: forwards issued with `ctx` record it, others do not. */
+int gigs_ctx_set_blend_begin_event(gigs_ctx* ctx, void* hip_event);
 
 /* One-wave kernel that occupies `stream` for about `nanoseconds` (it spins on the constant-rate wall clock; capped at
  * 1 ms; capturable into a hipGraph).  Inside a graph, kernel nodes that become ready together start in an order the
@@ -500,14 +544,15 @@ int gigs_stream_delay(unsigned nanoseconds, void* stream);
 
 /* Asynchronous binning (gigs-hip extension).  The reference's forward reads the instance count back in the middle
  * (rasterizer_impl.cu:589-594) to size the binning buffer, which serialises host and device and keeps the forward out
- * of a hipGraph.  After gigs_set_async_binning(r_capacity > 0, counters) every gigs_forward asks the binning callback
- * for gigs_required_binning(r_capacity) bytes, bins at most r_capacity instances, reads nothing back and RETURNS
- * r_capacity (pass it to gigs_backward as R: both carve the same layout).  `counters` (device, 2 x u32, may be NULL)
- * receives {actual instance count, the count again if it exceeded the capacity else 0}; on overflow the surplus
+ * of a hipGraph.  After gigs_ctx_set_async_binning(ctx, r_capacity > 0, counters) every gigs_forward(ctx, ...) asks the
+ * binning callback for gigs_required_binning(r_capacity) bytes, bins at most r_capacity instances, reads nothing back
+ * and RETURNS r_capacity (pass it to gigs_backward as R: both carve the same layout).  `counters` (device, 2 x u32, may
+ * be NULL) receives {actual instance count, the count again if it exceeded the capacity else 0}; on overflow the surplus
  * instances are dropped (memory-safe, wrong image): the caller checks the flag when convenient, grows the capacity
  * and repeats the step.  r_capacity = 0 restores the synchronous behaviour.  Needs the tile-bucketed binning path
- * (the default; GIGS_BINNING=legacy selects scan / duplicate / global radix sort) and <= 16384 tiles. */
-void gigs_set_async_binning(int r_capacity, unsigned* device_counters);
+ * (options.binning_legacy = 0) and <= 16384 tiles.  Per context: two contexts may bin with different capacities and
+ * counters on two streams at the same time. */
+int gigs_ctx_set_async_binning(gigs_ctx* ctx, int r_capacity, unsigned* device_counters);
 
 /* In-library stage timing for bench.py.  Between gigs_profile_begin() and gigs_profile_end()
  * every kernel stage launched by this library records a hipEvent pair on its own stream (no

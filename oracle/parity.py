@@ -157,17 +157,14 @@ def diff_planes(a: Dict, b: Dict, keys=GI_PLANES) -> Dict:
 
 
 def gpu_exact_march(sc, cam, gi, sh_degree, light, brdf_lut, dev="cuda:0") -> Dict:
-    """The GI planes of the same view from the product with the EXACT march (GIGS_GI_MARCH=exact: the oracle's sample
+    """The GI planes of the same view from the product with the EXACT march (gi_march = exact: the oracle's sample
     arithmetic bit for bit -- the checker of the default, projective march), through an eager fused step."""
-    import os
-
     import torch
 
+    import gigs_lib
     import pipeline
 
-    old = os.environ.get("GIGS_GI_MARCH")
-    os.environ["GIGS_GI_MARCH"] = "exact"  # read by the library at every launch (csrc/gi.hip::gi_march_mode)
-    try:
+    with gigs_lib.options(gi_march="exact"):  # gigs_options.gi_march of the library context the operators run with
         tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
         g = {k: tt(sc[k]) for k in stage2_ref.KEYS}
         camt = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
@@ -184,11 +181,6 @@ def gpu_exact_march(sc, cam, gi, sh_degree, light, brdf_lut, dev="cuda:0") -> Di
         for k in ("render_rgb", "render_direct", "IRR"):
             out[k] = so[k].detach().cpu().numpy()
         return out
-    finally:
-        if old is None:
-            os.environ.pop("GIGS_GI_MARCH", None)
-        else:
-            os.environ["GIGS_GI_MARCH"] = old
 
 
 def march_noise(orc, sc, cam, gi, sh_degree, gpu: Dict, ref: Dict, light=None, brdf_lut=None, dev="cuda:0") -> Dict:

@@ -66,9 +66,12 @@ def _tick(timings, name, t0):
     return time.perf_counter()
 
 
-def operator_forward(orc, sc, cam, gi, sh_degree, bg=(0.0, 0.0, 0.0), inference=False, keep_state=False, timings=None):
+def operator_forward(orc, sc, cam, gi, sh_degree, bg=(0.0, 0.0, 0.0), inference=False, keep_state=False, timings=None,
+                     derive_normal=True, scale_modifier=1.0):
     """GaussianRasterizer.forward: rasterizer, median(depth), depth->normal, bilateral, median(pos), SSAO on the RAW
-    view-space normal (R/.../__init__.py:475-517).  Returns the 12-tuple's planes by name (+ the Rasterizer)."""
+    view-space normal (R/.../__init__.py:475-517).  derive_normal=False: zeros in place of the derived normal and
+    positions, the bilateral / median still applied to them (:486-504).  Returns the 12-tuple's planes by name (+ the
+    Rasterizer)."""
     H, W = cam["image_height"], cam["image_width"]
     fx, fy = focal(cam)
     t0 = time.perf_counter()
@@ -76,10 +79,13 @@ def operator_forward(orc, sc, cam, gi, sh_degree, bg=(0.0, 0.0, 0.0), inference=
     out = r.forward(bg=np.asarray(bg, _f32), **{k: sc[k] for k in KEYS}, sh_degree=sh_degree,
                     viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
                     tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], image_height=H, image_width=W,
-                    inference=inference)
+                    inference=inference, scale_modifier=scale_modifier)
     t0 = _tick(timings, "rasterizer_fwd", t0)
-    depth_f = orc.median3x3(out["depth"])
-    nd, pos = orc.depth_to_normal(W, H, fx, fy, cam["viewmatrix"], depth_f)
+    if derive_normal:
+        depth_f = orc.median3x3(out["depth"])
+        nd, pos = orc.depth_to_normal(W, H, fx, fy, cam["viewmatrix"], depth_f)
+    else:  # torch.zeros_like(out_normal) twice (:488-489)
+        nd, pos = np.zeros((3, H, W), _f32), np.zeros((3, H, W), _f32)
     nd = orc.bilateral3x3(nd)
     posf = orc.median3x3(pos)
     occ = orc.ssao(W, H, fx, fy, gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"],

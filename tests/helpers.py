@@ -35,3 +35,11 @@ def small_scene(P=300, sh_degree=1, seed=3, W=64, H=48, scale_mu=0.08, view=0):
     sc = scenes.random_scene(P=P, sh_degree=sh_degree, seed=seed, scale_mu=scale_mu)
     cam = scenes.orbit_camera(view, 4, W, H)
     return sc, cam
+
+
+def set_options(monkeypatch, **kw):
+    """Switch gigs_options for the rest of the test: the current library context of this thread is replaced by a derived
+    one (gigs_lib.Context.derive) and restored by monkeypatch at teardown.  Option names are gigs_options members
+    (include/gigs_hip.h); `async_binning=(capacity, counters)` / `False` and `blend_event=` are accepted too."""
+    import gigs_lib
+    monkeypatch.setattr(gigs_lib._tls, "ctx", gigs_lib.current().derive(**kw))

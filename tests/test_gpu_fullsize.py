@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 import torch
 
+import gigs_lib
 import scenes
 from test_gpu_parity import DEV, L1_TOL, _dgr, check_forward, hip_planes, hip_raw_forward, scratch_views, settings, tt
 
@@ -26,7 +27,8 @@ def _structure_checks(sv, hp, R, P, W, H):
     keys = sv["keys"].astype(np.uint64)
     assert np.all(keys[1:] >= keys[:-1]), "tile|depth keys are not sorted"
     assert int(sv["tiles_touched"].astype(np.int64).sum()) == R
-    if os.environ.get("GIGS_BINNING", "") == "legacy":
+    import gigs_lib
+    if gigs_lib.current().option("binning_legacy") == 1:
         assert int(sv["point_offsets"][-1]) == R
         # the sorted list is a permutation of the unsorted (key, value) pairs
         order = np.lexsort((sv["vals_unsorted"], sv["keys_unsorted"]))
@@ -69,8 +71,8 @@ def test_c2_forward_structure_determinism_and_cull(monkeypatch):
     _structure_checks(sv, hp, R, P, W, H)
     # bit-for-bit determinism and cull-invariance of every plane and of the per-pixel state
     res2 = hip_raw_forward(dgr, sc, cam)
-    monkeypatch.setenv("GIGS_BLEND_CULL", "0")
-    res3 = hip_raw_forward(dgr, sc, cam)
+    with gigs_lib.options(blend_cull=0):
+        res3 = hip_raw_forward(dgr, sc, cam)
     for other in (res2, res3):
         sv2, hp2 = scratch_views(dgr, other, P, W, H), hip_planes(other)
         for k in ("n_contrib", "final_T", "point_list"):
@@ -104,9 +106,8 @@ def test_c2_operator_gi_invariance_and_backward_linearity(monkeypatch):
     out, _ = run(None)
     occ = out[6]
     assert float(occ.min()) >= 0.0 and float(occ.max()) <= 1.0 and 0.05 < float(occ.mean()) < 1.0
-    monkeypatch.setenv("GIGS_GI_TILE_LOG2W", "5")
-    out2, _ = run(None)
-    monkeypatch.delenv("GIGS_GI_TILE_LOG2W")
+    with gigs_lib.options(gi_tile_log2w=5):
+        out2, _ = run(None)
     assert torch.equal(occ, out2[6])
     ssr = dgr.Gaussian_SSR(cam["tanfovx"], cam["tanfovy"], W, H, 0.8, 0.01, 0.05, 0.0625, 16, 8)
     rgb = torch.rand(3, H, W, device=DEV)
@@ -114,8 +115,8 @@ def test_c2_operator_gi_invariance_and_backward_linearity(monkeypatch):
     onv = torch.nan_to_num(out[10])
     irr, abd = ssr(onv, out[11], rgb, out[7].detach(), out[8].detach(), out[9].detach(), F0)
     assert torch.isfinite(irr).all() and float(irr.min()) >= 0.0
-    monkeypatch.setenv("GIGS_GI_TILE_LOG2W", "4")
-    irr2, _ = ssr(onv, out[11], rgb, out[7].detach(), out[8].detach(), out[9].detach(), F0)
+    with gigs_lib.options(gi_tile_log2w=4):
+        irr2, _ = ssr(onv, out[11], rgb, out[7].detach(), out[8].detach(), out[9].detach(), F0)
     assert torch.equal(irr, irr2)
     # linearity of the backward: bwd(2 g1 - 3 g2) = 2 bwd(g1) - 3 bwd(g2) up to atomic-order rounding
     torch.manual_seed(0)

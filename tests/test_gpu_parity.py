@@ -15,7 +15,7 @@ import pytest
 import torch
 
 import scenes
-from helpers import GAUSS_KEYS, focal, oracle_forward, random_pix_grads, small_scene
+from helpers import GAUSS_KEYS, focal, oracle_forward, random_pix_grads, set_options, small_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -35,13 +35,14 @@ def tt(a, grad=False):
     return t
 
 
-def settings(dgr, cam, sh_degree, bg=(0, 0, 0), gi=scenes.GI_DEFAULTS, inference=False, argmax_depth=False, debug=False):
+def settings(dgr, cam, sh_degree, bg=(0, 0, 0), gi=scenes.GI_DEFAULTS, inference=False, argmax_depth=False, debug=False,
+             scale_modifier=1.0, prefiltered=False):
     return dgr.GaussianRasterizationSettings(
         image_height=cam["image_height"], image_width=cam["image_width"], tanfovx=cam["tanfovx"],
         tanfovy=cam["tanfovy"], radius=gi["radius"], bias=gi["bias"], thick=gi["thick"], delta=gi["delta"],
-        step=gi["step"], start=gi["start"], bg=tt(np.asarray(bg, np.float32)), scale_modifier=1.0,
+        step=gi["step"], start=gi["start"], bg=tt(np.asarray(bg, np.float32)), scale_modifier=scale_modifier,
         viewmatrix=tt(cam["viewmatrix"]), projmatrix=tt(cam["projmatrix"]), sh_degree=sh_degree,
-        campos=tt(cam["campos"]), prefiltered=False, debug=debug, inference=inference, argmax_depth=argmax_depth)
+        campos=tt(cam["campos"]), prefiltered=prefiltered, debug=debug, inference=inference, argmax_depth=argmax_depth)
 
 
 def hip_raw_forward(dgr, sc, cam, bg=(0, 0, 0), colors_precomp=None, cov3D_precomp=None, **kw):
@@ -53,8 +54,8 @@ def hip_raw_forward(dgr, sc, cam, bg=(0, 0, 0), colors_precomp=None, cov3D_preco
         tt(sc["normal"]), tt(sc["albedo"]), tt(sc["roughness"]), tt(sc["metallic"]),
         e if cov3D_precomp is not None else tt(sc["scales"]), e if cov3D_precomp is not None else tt(sc["rotations"]),
         e if cov3D_precomp is None else tt(cov3D_precomp), e if colors_precomp is not None else tt(sc["shs"]),
-        st.campos, st.viewmatrix, st.projmatrix, 1.0, st.tanfovx, st.tanfovy, st.image_height, st.image_width,
-        st.sh_degree, False, st.argmax_depth, st.inference, st.debug)
+        st.campos, st.viewmatrix, st.projmatrix, st.scale_modifier, st.tanfovx, st.tanfovy, st.image_height, st.image_width,
+        st.sh_degree, st.prefiltered, st.argmax_depth, st.inference, st.debug)
     torch.cuda.synchronize()
     return res
 
@@ -107,7 +108,7 @@ def hip_planes(res):
 
 def check_forward(orc, sc, cam, bg=(0.1, 0.3, 0.2), tag="", **kw):
     dgr = _dgr()
-    okw = {k: v for k, v in kw.items() if k in ("inference", "argmax_depth")}
+    okw = {k: v for k, v in kw.items() if k in ("inference", "argmax_depth", "scale_modifier")}
     extra = {}
     if "colors_precomp" in kw:
         extra.update(shs=None, colors_precomp=kw["colors_precomp"])
@@ -123,7 +124,8 @@ def check_forward(orc, sc, cam, bg=(0.1, 0.3, 0.2), tag="", **kw):
     vis = ref["radii"] > 0
     # integer / index state: bit-exact.  The emission-order arrays (point_offsets, unsorted keys / values) exist only on
     # the reference-shaped path (GIGS_BINNING=legacy); the default tile-bucketed path produces the sorted state directly
-    legacy = os.environ.get("GIGS_BINNING", "") == "legacy"
+    import gigs_lib
+    legacy = gigs_lib.current().option("binning_legacy") == 1
     for k in ("tiles_touched", "ranges") + (("point_offsets",) if legacy else ()):
         np.testing.assert_array_equal(sv[k], r.state(k), err_msg=tag + k)
     if res[0] > 0:
@@ -228,7 +230,7 @@ def test_forward_quadrant_cull_is_exact(orc, monkeypatch):
     _, _, res, _ = check_forward(orc, sc, cam, tag="needles ")
     sv = scratch_views(dgr, res, 6000, 240, 176)
     hp = hip_planes(res)
-    monkeypatch.setenv("GIGS_BLEND_CULL", "0")
+    set_options(monkeypatch, blend_cull=0)
     res0 = hip_raw_forward(dgr, sc, cam, bg=(0.1, 0.3, 0.2))
     sv0 = scratch_views(dgr, res0, 6000, 240, 176)
     hp0 = hip_planes(res0)
@@ -270,17 +272,17 @@ def test_mark_visible(orc):
 
 
 # ------------------------------------------------------------------------------------------
-def _backward_pair(orc, sc, cam, bg, seed, zero=()):
+def _backward_pair(orc, sc, cam, bg, seed, zero=(), scale_modifier=1.0):
     dgr = _dgr()
     H, W = cam["image_height"], cam["image_width"]
-    r, ref = oracle_forward(orc, sc, cam, bg=bg)
+    r, ref = oracle_forward(orc, sc, cam, bg=bg, scale_modifier=scale_modifier)
     pg = random_pix_grads(np.random.default_rng(seed), H, W)
     for k in zero:
         pg[k][:] = 0
     want = r.backward(grad_color=pg["color"], grad_opacity=pg["opacity"], grad_depth=pg["depth"],
                       grad_normal=pg["normal"], grad_albedo=pg["albedo"], grad_roughness=pg["roughness"],
                       grad_metallic=pg["metallic"])
-    st = settings(dgr, cam, sc["sh_degree"], bg=bg)
+    st = settings(dgr, cam, sc["sh_degree"], bg=bg, scale_modifier=scale_modifier)
     t = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
     m2d = torch.zeros_like(t["means3D"], requires_grad=True)
     outs = dgr._RasterizeGaussians.apply(t["means3D"], m2d, t["opacities"], t["normal"], t["albedo"], t["roughness"],
@@ -335,7 +337,7 @@ def test_backward_stage2_pattern_and_linearity(orc, monkeypatch):
         assert np.abs(got[k]).max() == 0.0, k
     # ... which the preprocess backward uses to skip the geometry chain and the SH read of such Gaussians: same
     # result as evaluating everything (GIGS_PRE_BWD_SH_SKIP=0)
-    monkeypatch.setenv("GIGS_PRE_BWD_SH_SKIP", "0")
+    set_options(monkeypatch, pre_bwd_sh_skip=0)
     full, _, _ = _backward_pair(orc, sc, cam, (0, 0, 0), seed=1, zero=zero)
     for k in got:
         if k in ("albedo", "roughness", "metallic"):  # float atomics: equal to rounding
@@ -404,7 +406,7 @@ def test_backward_scratch_gradients_c_abi(orc):
     g = {k: tt(v) for k, v in pg.items()}
     ins = {k: tt(sc[k]) for k in GAUSS_KEYS}
     vm, pm, cp, bg = tt(cam["viewmatrix"]), tt(cam["projmatrix"]), tt(cam["campos"]), tt(np.zeros(3, np.float32))
-    rc = lib.gigs_backward(P, 1, 4, res[0], bg.data_ptr(), W, H, ins["means3D"].data_ptr(), ins["shs"].data_ptr(), None,
+    rc = lib.gigs_backward(None, P, 1, 4, res[0], bg.data_ptr(), W, H, ins["means3D"].data_ptr(), ins["shs"].data_ptr(), None,
                            ins["normal"].data_ptr(), ins["albedo"].data_ptr(), ins["roughness"].data_ptr(),
                            ins["metallic"].data_ptr(), ins["scales"].data_ptr(), ins["rotations"].data_ptr(), None,
                            vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), res[2].data_ptr(), 1.0, cam["tanfovx"], cam["tanfovy"],
@@ -429,10 +431,7 @@ def test_gi_passes_match_oracle(orc, march, monkeypatch):
     """SSAO / SSR against the oracle.  GIGS_GI_MARCH=exact reproduces the oracle's pixel choices (only fp sums differ);
     the default march ("proj") and the other tolerance-spending variants must stay inside a quarter of north_star's
     1e-4 mean L1 with at most 0.2 % of the pixels moved by more than 1e-5 (measured: ~1e-7 / ~1e-4)."""
-    if march != "default":
-        monkeypatch.setenv("GIGS_GI_MARCH", march)
-    else:
-        monkeypatch.delenv("GIGS_GI_MARCH", raising=False)
+    set_options(monkeypatch, gi_march="proj" if march == "default" else march)
     l1_tol, moved_tol = (L1_TOL, 1e-3) if march == "exact" else (2.5e-5, 2e-3)
     dgr = _dgr()
     sc = scenes.surface_scene(P=30_000, sh_degree=1, seed=3, scale_mu=0.02)
@@ -622,9 +621,7 @@ def test_binning_paths_match_oracle(orc, mode, monkeypatch):
     GIGS_LONG_LISTS=1; these scenes have no list long enough to be partitioned, the kernels run empty-handed) -- give the
     oracle's keys, point_list and ranges bit for bit, on a cloud with large footprints (wave-expanded), exact depth ties
     (duplicated Gaussians) and a ragged image."""
-    monkeypatch.setenv("GIGS_BINNING", "legacy" if mode == "legacy" else "bucket")
-    if mode == "long_lists":
-        monkeypatch.setenv("GIGS_LONG_LISTS", "1")
+    set_options(monkeypatch, binning_legacy=int(mode == "legacy"), long_lists=1 if mode == "long_lists" else -1)
     sc = scenes.random_scene(P=6000, sh_degree=1, seed=21, scale_mu=0.12)
     # exact depth ties inside tiles: the same Gaussian several times (ties must come out in index order)
     for k in GAUSS_KEYS:
@@ -640,7 +637,7 @@ def test_binning_paths_match_oracle(orc, mode, monkeypatch):
 
 
 def test_async_binning_capacity_and_overflow(orc):
-    """gigs_set_async_binning: no host read-back; with enough capacity the outputs are those of the synchronous call, the
+    """gigs_ctx_set_async_binning: no host read-back; with enough capacity the outputs are those of the synchronous call, the
     device counters report R; with too little the overflow flag is raised and nothing is written out of bounds."""
     import gigs_lib
     dgr = _dgr()
@@ -651,11 +648,8 @@ def test_async_binning_capacity_and_overflow(orc):
     R = ref[0]
     counters = torch.zeros(2, dtype=torch.int32, device=DEV)
     cap = int(R * 1.3)
-    lib.gigs_set_async_binning(cap, counters.data_ptr())
-    try:
+    with gigs_lib.use(gigs_lib.current().derive(async_binning=(cap, counters))):
         got = hip_raw_forward(dgr, sc, cam)
-    finally:
-        lib.gigs_set_async_binning(0, None)
     assert got[0] == cap and counters.tolist() == [R, 0]
     for a, b in zip(hip_planes(ref).items(), hip_planes(got).items()):
         np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32), err_msg=a[0])
@@ -666,11 +660,8 @@ def test_async_binning_capacity_and_overflow(orc):
     # the backward carves the chunk with the capacity it was given
     small = R // 3
     guard = torch.full((1024,), 0x5A, dtype=torch.uint8, device=DEV)
-    lib.gigs_set_async_binning(small, counters.data_ptr())
-    try:
+    with gigs_lib.use(gigs_lib.current().derive(async_binning=(small, counters))):
         over = hip_raw_forward(dgr, sc, cam)
-    finally:
-        lib.gigs_set_async_binning(0, None)
     assert over[0] == small and counters.tolist() == [R, R]
     sv = scratch_views(dgr, over, P, W, H)
     assert int(sv["ranges"].max()) <= small and torch.all(guard == 0x5A)
@@ -689,7 +680,7 @@ def test_dense_scene_long_lists_sync_and_async(orc, split, monkeypatch):
     dgr = _dgr()
     lib = gigs_lib.lib()
     if split == "off":
-        monkeypatch.setenv("GIGS_LONG_LISTS", "0")
+        set_options(monkeypatch, long_lists=0)
     # ~3 000 instances per tile on average at 96x80 (30 tiles), one screen-filling cluster in front: a very long list
     sc = scenes.surface_scene(P=44_000, sh_degree=1, seed=9, scale_mu=0.08)
     cam = scenes.orbit_camera(1, 5, 96, 80, radius=3.0)
@@ -711,9 +702,8 @@ def test_dense_scene_long_lists_sync_and_async(orc, split, monkeypatch):
     P, W, H = sc["means3D"].shape[0], cam["image_width"], cam["image_height"]
     T = ((W + 15) // 16) * ((H + 15) // 16)
     assert R > 2500 * T, (R, T)  # dense by the library's own criterion
-    monkeypatch.setenv("GIGS_BINNING", "legacy")
-    ref = hip_raw_forward(dgr, sc, cam)
-    monkeypatch.setenv("GIGS_BINNING", "bucket")
+    with gigs_lib.options(binning_legacy=1):
+        ref = hip_raw_forward(dgr, sc, cam)
     assert ref[0] == R
     sa, sb = scratch_views(dgr, ref, P, W, H), scratch_views(dgr, got, P, W, H)
     for k in ("keys", "point_list", "ranges", "n_contrib"):
@@ -724,11 +714,8 @@ def test_dense_scene_long_lists_sync_and_async(orc, split, monkeypatch):
     print("dense test: R", R, "mean list", R // T, "longest", int(lengths.max()))
     counters = torch.zeros(2, dtype=torch.int32, device=DEV)
     cap = 2 * R  # what pipeline.WholeStepGraph sizes: the library reads the density off the capacity
-    lib.gigs_set_async_binning(cap, counters.data_ptr())
-    try:
+    with gigs_lib.use(gigs_lib.current().derive(async_binning=(cap, counters))):
         asy = hip_raw_forward(dgr, sc, cam)
-    finally:
-        lib.gigs_set_async_binning(0, None)
     assert asy[0] == cap and counters.tolist() == [R, 0]
     sc_ = scratch_views(dgr, (cap,) + tuple(asy[1:]), P, W, H)
     np.testing.assert_array_equal(sa["point_list"], sc_["point_list"][:R])
@@ -738,11 +725,8 @@ def test_dense_scene_long_lists_sync_and_async(orc, split, monkeypatch):
         np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32), err_msg=a[0])
     small = max(65536, R // 3)
     guard = torch.full((1024,), 0x5A, dtype=torch.uint8, device=DEV)
-    lib.gigs_set_async_binning(small, counters.data_ptr())
-    try:
+    with gigs_lib.use(gigs_lib.current().derive(async_binning=(small, counters))):
         over = hip_raw_forward(dgr, sc, cam)
-    finally:
-        lib.gigs_set_async_binning(0, None)
     assert over[0] == small and counters.tolist() == [R, R]
     sv = scratch_views(dgr, over, P, W, H)
     assert int(sv["ranges"].max()) <= small and torch.all(guard == 0x5A)
@@ -782,12 +766,143 @@ def test_gi_certification_is_exact(case, monkeypatch):
         a = (gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
         got = {}
         for cert in ("1", "0"):
-            monkeypatch.setenv("GIGS_GI_CERT", cert)
-            occ = dgr._C.SSAO(W, H, fx, fy, *a, raw_nview, posf)
-            col, abd = dgr._C.SSR(W, H, fx, fy, *a, res["out_normal_view"].contiguous(), posf, rgb, res["albedo_map"].contiguous(),
-                                  res["roughness_map"].contiguous(), res["metallic_map"].contiguous(), F0)
+            with gigs_lib.options(gi_cert=int(cert)):
+                occ = dgr._C.SSAO(W, H, fx, fy, *a, raw_nview, posf)
+                col, abd = dgr._C.SSR(W, H, fx, fy, *a, res["out_normal_view"].contiguous(), posf, rgb, res["albedo_map"].contiguous(),
+                                      res["roughness_map"].contiguous(), res["metallic_map"].contiguous(), F0)
             got[cert] = (occ.clone(), col.clone(), abd.clone())
         for x, y in zip(got["1"], got["0"]):
             assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (case, gi)
         hits += int((got["1"][0] < 1.0).sum())
     assert hits > 0, "no ray of the test views hits anything: the comparison would be vacuous"
+
+
+@pytest.mark.parametrize("march", ["proj", "proj_nocert", "proj_quarters", "proj_nr", "hoist", "hoist_fma", "exact"])
+def test_gi_zero_weight_rays_are_exact(march):
+    """The theta = 0 rays of the reference's ray set (forward.cu:679-681, 796-797: 32 of 512 at delta 0.0625, 16 of 144
+    at 0.125, 65 of 2080 at 0.03125) have weight cos * sin = 0 and one direction, the normal.  By default they are not
+    marched (SSAO) / marched once (SSR, for the NaN a non-finite hit pixel produces: forward.cu:824-826).  Marching all of
+    them (gigs_options.gi_zero_rays = 1) must not change a bit of occlusion, colour or abd -- in every march mode, for
+    interleaved and contiguous ray splits, with NaN / Inf radiance in the image."""
+    import gigs_lib
+    import pipeline
+    dgr = _dgr()
+    sc = scenes.surface_scene(P=40_000, sh_degree=1, seed=11, scale_mu=0.02)
+    cam = scenes.orbit_camera(2, 9, 333, 251, radius=3.3)
+    g = {k: tt(sc[k]) for k in GAUSS_KEYS}
+    camt = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    W, H = cam["image_width"], cam["image_height"]
+    fx, fy = focal(cam)
+    with torch.no_grad():
+        res = pipeline.render(camt, g, 1, torch.zeros(3, device=DEV), dict(scenes.GI_DEFAULTS, start=16))
+        out, _, _ = pipeline.rasterize(camt, g, 1, torch.zeros(3, device=DEV), dict(scenes.GI_DEFAULTS, start=16))
+    raw_nview, posf = out[10].contiguous(), out[11].contiguous()
+    F0 = torch.full((3, H, W), 0.04, device=DEV)
+    rgb = res["albedo_map"].clamp(0, 1).contiguous().clone()
+    # non-finite radiance on a band of covered pixels: every ray that hits there turns the pixel's sum into NaN,
+    # zero-weight rays included (0 * inf, 0 * nan)
+    rgb[0, H // 2 - 6:H // 2 + 6, :] = float("inf")
+    rgb[1, :, W // 2 - 5:W // 2 + 5] = float("nan")
+    opts = dict(gi_march=march.split("_no")[0].split("_quarters")[0])
+    if march == "proj_nocert":
+        opts["gi_cert"] = 0
+    if march == "proj_quarters":
+        opts["gi_interleave"] = 0
+    gis = [scenes.GI_DEFAULTS, dict(scenes.GI_DEFAULTS, delta=0.125, start=4, radius=1.2)]
+    if march in ("proj", "exact"):
+        gis.append(dict(scenes.GI_DEFAULTS, delta=0.03125, start=12))  # 2 080 rays, 65 of weight zero
+    hits = nans = 0
+    for gi in gis:
+        a = (gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
+        got = {}
+        for zero in (0, 1):
+            with gigs_lib.options(gi_zero_rays=zero, **opts):
+                occ = dgr._C.SSAO(W, H, fx, fy, *a, raw_nview, posf)
+                col, abd = dgr._C.SSR(W, H, fx, fy, *a, res["out_normal_view"].contiguous(), posf, rgb, res["albedo_map"].contiguous(),
+                                      res["roughness_map"].contiguous(), res["metallic_map"].contiguous(), F0)
+            got[zero] = (occ.clone(), col.clone(), abd.clone())
+        for name, x, y in zip(("occlusion", "color", "abd"), got[0], got[1]):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (march, gi, name)
+        hits += int((got[0][0] < 1.0).sum())
+        nans += int(torch.isnan(got[0][1]).sum())
+    assert hits > 0 and nans > 0, "vacuous: no ray hits / no non-finite radiance was picked up"
+
+
+def test_two_contexts_on_two_streams_equal_the_serial_runs(orc):
+    """the library is re-entrant per stream.  Two contexts with different switches and different
+    asynchronous-binning capacities / counters / events drive two views on two streams of one process, their calls
+    interleaved and nothing synchronised in between; every output equals the serial, one-context-at-a-time run bit for
+    bit (integer state, planes, occlusion, gradients of the deterministic -- atomic-free -- outputs)."""
+    import gigs_lib
+    dgr = _dgr()
+    scA = scenes.surface_scene(P=30_000, sh_degree=1, seed=3, scale_mu=0.02)
+    scB = scenes.surface_scene(P=18_000, sh_degree=2, seed=4, scale_mu=0.03)
+    camA = scenes.orbit_camera(0, 4, 304, 240, radius=3.5)
+    camB = scenes.orbit_camera(1, 5, 251, 333, radius=3.2)
+    giA, giB = scenes.GI_DEFAULTS, dict(scenes.GI_DEFAULTS, delta=0.125, start=4)
+    RA = hip_raw_forward(dgr, scA, camA)[0]
+    RB = hip_raw_forward(dgr, scB, camB)[0]
+    cntA, cntB = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV)
+    evA, evB = torch.cuda.Event(), torch.cuda.Event()
+    evA.record(); evB.record()
+    base = gigs_lib.current()
+    ctxA = base.derive(async_binning=(int(RA * 1.5), cntA), blend_event=evA, gi_march="exact", blend_cull=0, gi_tile_log2w=4)
+    ctxB = base.derive(async_binning=(int(RB * 2.2), cntB), blend_event=evB, gi_march="proj", gi_cert=0, long_lists=1,
+                       pre_bwd_sh_skip=0, gi_zero_rays=1)
+    assert ctxA.ptr != ctxB.ptr
+
+    def inputs(sc):
+        return {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+
+    def fwd(ctx, sc, cam, gi, t):
+        with gigs_lib.use(ctx):
+            st = settings(dgr, cam, sc["sh_degree"], gi=gi)
+            return dgr.GaussianRasterizer(st)(t["means3D"], torch.zeros_like(t["means3D"], requires_grad=True), t["opacities"],
+                                              t["normal"], t["albedo"], t["roughness"], t["metallic"], shs=t["shs"],
+                                              scales=t["scales"], rotations=t["rotations"])
+
+    def bwd(ctx, out):
+        with gigs_lib.use(ctx):  # the backward reads its context's switches too (pre_bwd_sh_skip)
+            (out[0].sum() * 0.5 + (out[7] * out[7]).sum() + out[3].sum() * 0.1).backward()
+
+    def collect(out, t, cnt):
+        torch.cuda.synchronize()
+        return ([o.detach().clone() for o in out], {k: v.grad.clone() for k, v in t.items() if v.grad is not None}, cnt.tolist())
+
+    # serial: A completely, then B completely
+    tA, tB = inputs(scA), inputs(scB)
+    oA = fwd(ctxA, scA, camA, giA, tA); bwd(ctxA, oA); refA = collect(oA, tA, cntA)
+    oB = fwd(ctxB, scB, camB, giB, tB); bwd(ctxB, oB); refB = collect(oB, tB, cntB)
+    assert refA[2] == [RA, 0] and refB[2] == [RB, 0]
+    # interleaved on two streams, no synchronisation between the calls
+    cntA.zero_(); cntB.zero_()
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    tA, tB = inputs(scA), inputs(scB)
+    with torch.cuda.stream(sA):
+        oA = fwd(ctxA, scA, camA, giA, tA)
+    with torch.cuda.stream(sB):
+        oB = fwd(ctxB, scB, camB, giB, tB)
+    with torch.cuda.stream(sA):
+        bwd(ctxA, oA)
+    with torch.cuda.stream(sB):
+        bwd(ctxB, oB)
+    gotA, gotB = collect(oA, tA, cntA), collect(oB, tB, cntB)
+    assert evA.query() and evB.query()
+    for tag, ref, got in (("A", refA, gotA), ("B", refB, gotB)):
+        assert ref[2] == got[2], tag
+        for i, (x, y) in enumerate(zip(ref[0], got[0])):
+            assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x,
+                               y.view(torch.int32) if y.dtype == torch.float32 else y), (tag, "output", i)
+        for k in ref[1]:
+            # per-Gaussian sums of the blend backward are float atomics over quadrants: equal to rounding, not bit for bit
+            np.testing.assert_allclose(got[1][k].cpu().numpy(), ref[1][k].cpu().numpy(), rtol=2e-4,
+                                       atol=1e-6 * max(float(ref[1][k].abs().max()), 1e-20), err_msg=tag + " grad " + k)
+    # and both equal the default context's synchronous results where the switches are bit-neutral (A: exact march differs)
+    with gigs_lib.use(base):
+        tB2 = inputs(scB)
+        oB2 = fwd(base, scB, camB, giB, tB2)
+    torch.cuda.synchronize()
+    for i in (0, 1, 2, 3, 5, 6, 7, 8, 9):  # colour, radii, opacity, depth, normal, occlusion (cert / zero rays: same bits), materials
+        x, y = oB2[i].detach(), gotB[0][i]
+        assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y), i

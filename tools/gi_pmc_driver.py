@@ -19,7 +19,8 @@ sc = scenes.surface_scene(P=300_000, sh_degree=2, seed=0)
 cam = scenes.orbit_camera(5, 64, 800, 800, radius=3.5)
 gi = scenes.GI_DEFAULTS
 gb = gi_variants.gbuffer(sc, cam, gi, 2)
-os.environ["GIGS_GI_CERT"] = cert
+import gigs_lib  # noqa: E402
+gigs_lib.set_options(gi_cert=int(cert))
 _, t = gi_variants.run_mode(mode, gb, cam, gi, 3)
 torch.cuda.synchronize()
 print(mode, cert, t)

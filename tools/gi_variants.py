@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import diff_gaussian_rasterization as dgr  # noqa: E402
+import gigs_lib  # noqa: E402
 import pipeline  # noqa: E402
 import scenes  # noqa: E402
 
@@ -36,7 +37,7 @@ KEYS = ["means3D", "opacities", "normal", "albedo", "roughness", "metallic", "sh
 def gbuffer(sc, cam, gi, sh_degree):
     g = {k: torch.from_numpy(sc[k]).to(DEV) for k in KEYS}
     camt = {k: (torch.from_numpy(v).to(DEV) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
-    os.environ["GIGS_GI_MARCH"] = "exact"
+    gigs_lib.set_options(gi_march="exact")
     with torch.no_grad():
         res = pipeline.render(camt, g, sh_degree, torch.zeros(3, device=DEV), dict(gi, start=gi["step"]))
         out, _, st = pipeline.rasterize(camt, g, sh_degree, torch.zeros(3, device=DEV), dict(gi, start=gi["step"]))
@@ -51,7 +52,7 @@ def gbuffer(sc, cam, gi, sh_degree):
 
 
 def run_mode(mode, gb, cam, gi, reps):
-    os.environ["GIGS_GI_MARCH"] = mode
+    gigs_lib.set_options(gi_march=mode)
     W, H = cam["image_width"], cam["image_height"]
     fx, fy = W / (2 * cam["tanfovx"]), H / (2 * cam["tanfovy"])
     a = (gi["radius"], gi["bias"], gi["thick"], gi["delta"], gi["step"], gi["start"])
@@ -139,18 +140,18 @@ def main():
         gb = gbuffer(sc, cam, gi, 2)
         report["tile_sweep"] = {}
         for log2w in (2, 3, 4, 5, 6):
-            os.environ["GIGS_GI_TILE_LOG2W"] = str(log2w)
+            gigs_lib.set_options(gi_tile_log2w=log2w)
             row = {}
             for mode in ("exact", "hoist_fma", "proj"):
                 _, t = run_mode(mode, gb, cam, gi, args.reps)
                 row[mode] = t
-            os.environ["GIGS_GI_CERT"] = "0"
+            gigs_lib.set_options(gi_cert=0)
             _, row["proj_nocert"] = run_mode("proj", gb, cam, gi, args.reps)
-            os.environ.pop("GIGS_GI_CERT")
+            gigs_lib.set_options(gi_cert=1)
             report["tile_sweep"]["%dx%d" % (1 << log2w, 64 >> log2w)] = row
             print("tile %2dx%-2d " % (1 << log2w, 64 >> log2w) + "  ".join("%s %.3f/%.3f ms" % (m, v["ssao_ms"], v["ssr_ms"]) for m, v in row.items()), flush=True)
-        os.environ.pop("GIGS_GI_TILE_LOG2W", None)
-    os.environ.pop("GIGS_GI_MARCH", None)
+        gigs_lib.set_options(gi_tile_log2w=3)
+    gigs_lib.set_options(gi_march="proj")
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:
