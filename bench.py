@@ -210,7 +210,10 @@ def cpu_baseline_and_parity(sc, cam, gi, sh_degree, light, brdf_lut, stepper, co
         # core): the SAME scene through the same oracle sequence at a reduced square resolution, light pre-filter
         # (resolution-independent: 6 x 256^2 texels, minutes on one core) excluded and said so
         import numpy as _np
-        small = scenes.orbit_camera(cam.get("index", 0), cam.get("n_views", 64), single_thread_res, single_thread_res, radius=3.5)
+        if "eye_target" in cam:  # a --scene view: the same pose at the reduced resolution
+            small = scenes.look_at_camera(cam["eye_target"][0], cam["eye_target"][1], single_thread_res, single_thread_res, cam["fovx"])
+        else:
+            small = scenes.orbit_camera(cam.get("index", 0), cam.get("n_views", 64), single_thread_res, single_thread_res, radius=3.5)
         orc.set_threads(1)
         t1 = {}
         t0 = time.perf_counter()
@@ -317,6 +320,13 @@ def parse_args(argv=None):
     ap.add_argument("--iteration", action="store_true",
                     help="print the complete training iteration (it/s, `iteration` / `iteration_stage1`) beside the metric even "
                          "under --no-extras (it is part of the default line)")
+    ap.add_argument("--scene", default=None,
+                    help="a trained scene instead of the synthetic stand-in: point_cloud.ply (GaussianModel.save_ply) or "
+                         "chkpntN.pth (train.py); Gaussian count and SH degree come from the file (SURVEY 8(d): real "
+                         "TensoIR / Mip-NeRF360 data if present on the box)")
+    ap.add_argument("--cameras", default=None,
+                    help="with --scene: a Blender / NeRF-synthetic transforms_*.json whose poses and field of view replace "
+                         "the orbit cameras (rendered at the config's resolution)")
     ap.add_argument("--cpu-single-res", type=int, default=200,
                     help="resolution of the bounded single-thread CPU sample (0 = skip)")
     args = ap.parse_args(argv)
@@ -327,6 +337,43 @@ def parse_args(argv=None):
     args.H = args.height or args.res or cH
     args.cname = cname
     return args
+
+
+def load_workload(args, W, H):
+    """(scene arrays, camera list, `data` tag).  Default: the synthetic stand-ins of SURVEY 8(d) (seed 0, 64 orbit views).
+    --scene: a trained point_cloud.ply / chkpntN.pth through gi-gs_amd/scene_io.py (the reference's own formats,
+    scene/gaussian_model.py:397-465, train.py:466-490); --cameras: the poses of a transforms_*.json
+    (scene/dataset_readers.py:223-281), else 64 orbit views around the cloud's median at 2.5 x its 90 % extent."""
+    import numpy as np
+    import scenes
+    if not args.scene:
+        sc = scenes.surface_scene(P=args.gaussians, sh_degree=args.sh_degree, seed=0)
+        n_views = 64
+        cams = [dict(scenes.orbit_camera(i, n_views, W, H, radius=3.5), index=i, n_views=n_views) for i in range(n_views)]
+        return sc, cams, "synthetic"
+    import dataset_readers
+    import scene_io
+    if not os.path.exists(args.scene):
+        raise SystemExit("bench.py --scene: %s does not exist" % args.scene)
+    sc = scene_io.load_scene(args.scene)
+    args.sh_degree = int(sc["sh_degree"])
+    args.gaussians = int(sc["means3D"].shape[0])
+    if args.cameras:
+        cams = dataset_readers.cameras_from_transforms(args.cameras, W, H)
+        tag = "%s, poses of %s (synthetic ground-truth images)" % (args.scene, args.cameras)
+    else:
+        centre = np.median(sc["means3D"], axis=0)
+        extent = float(np.quantile(np.linalg.norm(sc["means3D"] - centre, axis=1), 0.9))
+        n_views = 64
+        cams = []
+        for i in range(n_views):
+            az = 2.0 * np.pi * (i + 0.25) / n_views
+            eye = centre + 2.5 * extent * np.array([np.cos(0.5) * np.cos(az), np.cos(0.5) * np.sin(az), np.sin(0.5)])
+            cams.append(dict(scenes.look_at_camera(eye, centre, W, H, 0.6911), eye_target=(eye, centre)))
+        tag = "%s, 64 orbit views (synthetic ground-truth images)" % args.scene
+    n = len(cams)
+    cams = [dict(c, index=i, n_views=n) for i, c in enumerate(cams)]
+    return sc, cams, tag
 
 
 def self_launch(args, argv) -> int:
@@ -428,11 +475,10 @@ def run(args):
 
     shade = "hip"
     gi = dict(scenes.GI_DEFAULTS, start=args.start)
-    sc = scenes.surface_scene(P=args.gaussians, sh_degree=args.sh_degree, seed=0)
+    sc, cams, data_tag = load_workload(args, W, H)
     P, M = sc["means3D"].shape[0], sc["shs"].shape[1]
     g = {k: torch.from_numpy(sc[k]).to(dev).requires_grad_(True) for k in PARAM_KEYS}
-    n_views = 64
-    cams = [dict(scenes.orbit_camera(i, n_views, W, H, radius=3.5), index=i, n_views=n_views) for i in range(n_views)]
+    n_views = len(cams)
     cams_t = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
     yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, W, device=dev), indexing="ij")
     gt_image = torch.stack([0.5 + 0.3 * torch.sin(6 * xx), 0.5 + 0.3 * torch.cos(5 * yy), 0.4 + 0.2 * xx * yy])
@@ -543,6 +589,27 @@ def run(args):
                "ms_per_step_min": round(per_step[0], 4), "ms_per_step_max": round(per_step[-1], 4),
                "value_median": round(args.steps * world / (1e-3 * per_step[len(per_step) // 2] * args.steps), 3)}
 
+    # multi-rank: the COMPLETE training iterations under data parallelism, on every rank (their collectives need all of
+    # them): Stage2Trainer.data_parallel() reduces the stage-2 gradient set, Stage1Trainer.data_parallel() every gradient
+    # (what GIGS_BENCH_REDUCE=all measures for the metric's step) -- each with its own `comm`
+    dp_extras = {}
+    if use_dist and not inference and (not args.no_extras or args.iteration):
+        import train_iteration
+        for p_ in flat_params:
+            p_.grad = None
+        if stepper is not None:
+            stepper.close()  # the headline step's graphs: their memory pool is not needed beside the trainers'
+        kw = dict(steps=max(20, args.steps), warmup=5, data_parallel=True, force=force_coll, rank=rank, world=world)
+        # a failure here (the same on every rank: SPMD) must not cost the headline line above
+        try:
+            dp_extras["iteration"] = train_iteration.bench_iteration(sc, light, brdf_lut, gi, args.sh_degree, cams_t, view_dirs,
+                                                                     gt_image, **kw)
+        except Exception as ex:  # noqa: BLE001
+            dp_extras["iteration"] = {"error": repr(ex)[:400]}
+        try:
+            dp_extras["iteration_stage1"] = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image, **kw)
+        except Exception as ex:  # noqa: BLE001
+            dp_extras["iteration_stage1"] = {"error": repr(ex)[:400]}
     line = None
     if rank == 0:
         # V (visible), R (instances) averaged over the views of the timed region (outside it)
@@ -610,10 +677,22 @@ def run(args):
                         "frac": round(a / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom), "timed": kernels[dom]["timed"]}
             vb = pmc_valu_busy(dom)
             if vb is not None:
-                # what actually binds the kernel when it is not HBM: the share of its cycles with the vector ALUs issuing.
-                # NOT measured in this run (PMC needs rocprofv3): read from the committed pass named here
-                roofline["limiter"] = {"resource": "valu_issue" if vb > roofline["frac"] else "hbm",
-                                       "valu_busy_from_committed_pmc": vb, "pmc_summary": _pmc_file()}
+                # What actually binds the kernel when it is not HBM: the share of its cycles with the vector ALUs issuing.
+                # FLAT fields (the driver's parser keeps only those).  The instruction stream's VALU-active cycles come
+                # from the committed PMC pass named in `pmc_summary` (PMC needs rocprofv3: not collectable inside this
+                # run), the duration they are divided by is THIS run's live average: `frac` = VALU-active SIMD cycles per
+                # second against 1024 SIMDs x 2.4 GHz.  `bound` names the larger of the two fractions; the HBM figures the
+                # contract asks for stay beside it as hbm_*.
+                roofline["valu_busy"] = vb
+                roofline["pmc_summary"] = _pmc_file()
+                active = _pmc_entry(dom).get("SQ_ACTIVE_INST_VALU", {}).get("mean_per_launch")
+                dur_s = kernels[dom]["avg_ms"] * 1e-3
+                valu_frac = (4.0 * active / (1024.0 * 2.4e9 * dur_s)) if active else vb
+                roofline["limiter_resource"] = "valu_issue" if valu_frac > roofline["frac"] else "hbm"
+                if valu_frac > roofline["frac"]:
+                    roofline.update({"hbm_achieved": a, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": roofline["frac"],
+                                     "bound": "valu", "achieved": round(valu_frac * 1024 * 2.4, 1), "peak": round(1024 * 2.4, 1),
+                                     "unit": "G VALU-active SIMD cycles/s", "frac": round(valu_frac, 4)})
             if dom in ("ssao", "ssr"):
                 roofline["note"] = ("dominant kernel by time; contract fields are its HBM roofline (algorithmic bytes / duration), "
                                     "which does not bind it: its z-plane lookups are served by L2/L1 (the plane is 2.5 MB) and most "
@@ -638,10 +717,10 @@ def run(args):
             "metric": "%s at %dx%d; PSNR vs the CPU oracle" % (what, W, H),
             "value": round(args.steps * world / elapsed, 3), "unit": "renders/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s (%s): %dk surface Gaussians, %dx%d, SH deg %d, GI step=%d start=%d delta=%g"
-                                   % (args.config.upper(), cname, P // 1000, W, H, args.sh_degree, gi["step"], gi["start"],
-                                      gi["delta"]),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": data_tag,
+            "config": {"workload": "%s (%s): %dk %s Gaussians, %dx%d, SH deg %d, GI step=%d start=%d delta=%g"
+                                   % (args.config.upper(), cname, P // 1000, "trained (--scene)" if args.scene else "surface",
+                                      W, H, args.sh_degree, gi["step"], gi["start"], gi["delta"]),
                        "P": P, "V": round(V), "R": round(R), "N": N, "M": M, "shade": shade, "hip_graphs": args.graphs, "fused_glue": args.fused,
                        "gi_march": gigs_lib.GI_MARCHES[gigs_lib.current().option("gi_march")],
                        "rasterizer": ("one hipGraph per view" if inference and args.graphs == "on" else
@@ -660,6 +739,7 @@ def run(args):
             "kernels": kernels,
         }
         line.update(extras)
+        line.update(dp_extras)
         if parity_rep is not None:
             # the timed GPU path vs the CPU oracle on one view of this very workload (oracle/parity.py)
             line["psnr_vs_oracle_db"] = parity_rep.get("psnr_render_rgb")

@@ -23,6 +23,29 @@ _OUT_OF = dict(opacities="opacity", normal="normal", albedo="albedo", roughness=
                scales="scaling", rotations="rotation")
 
 
+_sink = None
+
+
+class grad_sink:
+    """`with grad_sink({"albedo": t0, "f_dc": t1, ...}):` -- the backward of `activate` writes the gradient of the named raw
+    parameter into the given tensor instead of a fresh one (names: RAW; a tensor is used only if shape, dtype and device
+    fit).  With views of a dp.GradSlab the raw gradients are born inside the all-reduce buffer, which the captured Adam
+    launch then reads in place (train_iteration.Stage2Trainer.data_parallel)."""
+
+    def __init__(self, tensors):
+        self.tensors = dict(tensors)
+
+    def __enter__(self):
+        global _sink
+        self._prev, _sink = _sink, self.tensors
+        return self
+
+    def __exit__(self, *exc):
+        global _sink
+        _sink = self._prev
+        return False
+
+
 class _Activate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *raw):
@@ -52,7 +75,12 @@ class _Activate(torch.autograd.Function):
         raw = ctx.saved_tensors
         dev = raw[0].device
         g = [None if t is None else t.contiguous().float() for t in g_out]
-        d = [torch.empty_like(t) for t in raw]
+        sink = _sink or {}
+        d = []
+        for name, t in zip(RAW, raw):
+            v = sink.get(name)
+            ok = v is not None and v.shape == t.shape and v.dtype == t.dtype and v.device == t.device and v.is_contiguous()
+            d.append(v if ok else torch.empty_like(t))
         a = gigs_lib.ActivationRaw(*[t.data_ptr() for t in raw])
         b = gigs_lib.ActivationOut(*[None if t is None else t.data_ptr() for t in g])
         c = gigs_lib.ActivationRaw(*[t.data_ptr() for t in d])

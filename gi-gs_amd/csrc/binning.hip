@@ -394,9 +394,14 @@ __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t
   }
   if (__syncthreads_or(tie)) {
     // odd-even transposition restricted to neighbours of equal depth: runs of equal depth are sorted by index, nothing else
-    // moves; as many rounds as the longest run is long (bit-identical depths inside one tile: duplicated Gaussians)
+    // moves; as many rounds as the longest run is long (bit-identical depths inside one tile: duplicated Gaussians).  The
+    // rounds are bounded: a run longer than kFixRounds keys (a cloned cloud, a plane seen head-on: thousands of identical
+    // depths would mean thousands of rounds of three barriers each) is sorted over the COMPLETE key instead -- the radix
+    // passes the depth-only sort saved, spent once, on this list only.
     constexpr unsigned kPairs = (unsigned)kBlock * kItems / 2;
-    for (;;) {
+    constexpr int kFixRounds = 64;
+    bool more = true;
+    for (int round = 0; round < kFixRounds && more; round++) {
       bool swapped = false;
 #pragma unroll
       for (int phase = 0; phase < 2; phase++) {
@@ -409,7 +414,17 @@ __device__ __forceinline__ void sort_tile_radix(Storage& storage, const uint64_t
         }
         __syncthreads();
       }
-      if (!__syncthreads_or(swapped)) break;
+      more = __syncthreads_or(swapped);  // uniform
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < kItems; i++) k[i] = s_k[threadIdx.x * kItems + i];  // padding (all ones) included
+      __syncthreads();  // s_k aliases the sorter's storage
+      sorter().sort(k, storage, 0, idx_bits + hi);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kItems; i++) s_k[threadIdx.x * kItems + i] = k[i];
+      __syncthreads();
     }
   }
   for (unsigned idx = threadIdx.x; idx < n; idx += kBlock) {  // coalesced

@@ -131,6 +131,26 @@ def camera_from_info(info: CameraInfo, resolution: int = 1, resolution_scale: fl
                 gt_alpha_mask=mask.float().to(device), image_name=info.image_name, uid=info.uid)
 
 
+def cameras_from_transforms(transformsfile: str, width: int, height: int) -> List[Dict]:
+    """The poses of a Blender / NeRF-synthetic `transforms_*.json` (scene/dataset_readers.py:223-281) as camera dicts at a
+    GIVEN resolution, without opening the image files (bench.py --cameras: the poses and the field of view are what the
+    workload needs).  Same matrices as camera_from_info for an image of that size."""
+    with open(transformsfile) as f:
+        contents = json.load(f)
+    fovx = float(contents["camera_angle_x"])
+    fovy = focal2fov(fov2focal(fovx, width), height)
+    cams = []
+    for idx, frame in enumerate(contents["frames"]):
+        R, T = pose_from_transform(frame["transform_matrix"])
+        viewmatrix = np.ascontiguousarray(world2view(R, T).T)
+        P = projection_matrix(0.01, 100.0, fovx, fovy)
+        cams.append(dict(viewmatrix=viewmatrix, projmatrix=np.ascontiguousarray((viewmatrix @ P.T).astype(np.float32)),
+                         campos=np.ascontiguousarray(np.linalg.inv(viewmatrix)[3, :3].astype(np.float32)),
+                         tanfovx=math.tan(fovx * 0.5), tanfovy=math.tan(fovy * 0.5), image_width=int(width),
+                         image_height=int(height), fovx=fovx, fovy=fovy, image_name=os.path.basename(str(frame.get("file_path", idx))), uid=idx))
+    return cams
+
+
 def random_init_cloud(num_pts: int = 100_000, rng: Optional[np.random.Generator] = None) -> Dict[str, np.ndarray]:
     """scene/dataset_readers.py:303-312: uniform points in [-1.3, 1.3]^3, colours SH2RGB(u / 255), zero normals."""
     rng = rng or np.random.default_rng()

@@ -161,7 +161,7 @@ class GradSlab:
         return pieces
 
     def allreduce_async(self, average: bool = False, force: bool = False, only: Optional[Sequence[int]] = None,
-                        check_rest_zero: bool = False) -> None:
+                        check_rest_zero: bool = False, packed: bool = False) -> None:
         """Sum (or average) the slab over all ranks on the communication stream.  Parameters whose .grad is None
         here contribute zeros.  `force` issues the collective even with a single rank (a one-GPU rehearsal of the
         whole code path: process group, communication stream, RCCL launch).
@@ -171,12 +171,18 @@ class GradSlab:
         loss reaches only albedo / roughness / metallic and the light (the blend weights are detached from the material
         planes: SURVEY App. D, tests/test_gpu_parity.py::test_backward_stage2_pattern_and_linearity); a sum of zeros is
         zero, so the result equals the full reduction with 5 of 46 floats per Gaussian on the wire.  Adjacent parameters
-        share one collective (order the slab accordingly).  `check_rest_zero` verifies the premise (one device read)."""
+        share one collective (order the slab accordingly).  `check_rest_zero` verifies the premise (one device read).
+
+        `packed`: the slab already HOLDS this step's gradients -- the backward wrote them into the views (grad_sink of the
+        rasterizer / of the activations inside a captured step) -- and `.grad` of the parameters is not in play (the
+        captured Adam launch reads the views): nothing is gathered before and nothing assigned after the collective."""
         world = _world(self.group)
+        self._packed = bool(packed)
         if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
             self._pending = False
             return
-        self._gather_stray()
+        if not packed:
+            self._gather_stray()
         self._average = average
         pieces = self._ranges(only)
         if only is not None and check_rest_zero:
@@ -225,10 +231,11 @@ class GradSlab:
             if self._average:
                 for piece in self._pieces:
                     piece.div_(_world(self.group))
-        # agree_presence: one small read-back per step, after the collective; otherwise the local pattern is everyone's
-        pres = self.presence.tolist() if self.agree_presence else self._local_presence
-        for p, v, has in zip(self.params, self.views, pres):
-            p.grad = v if has > 0 else None
+        if not getattr(self, "_packed", False):
+            # agree_presence: one small read-back per step, after the collective; otherwise the local pattern is everyone's
+            pres = self.presence.tolist() if self.agree_presence else self._local_presence
+            for p, v, has in zip(self.params, self.views, pres):
+                p.grad = v if has > 0 else None
         self._pending = False
 
     def comm_stats(self, reset: bool = True) -> Optional[Dict[str, float]]:

@@ -440,9 +440,45 @@ class WholeStepGraph:
     def _key(self, g):
         import diff_gaussian_rasterization as dgr
         sink = dgr._grad_sink or {}
+        slabv = getattr(self.owner, "grad_slab", None) or {}
         return (tuple((t.data_ptr(), tuple(t.shape)) for t in self._params(g)),
                 tuple(sorted((k, v.data_ptr()) for k, v in sink.items())),
+                tuple(sorted((k, v.data_ptr()) for k, v in slabv.items())),
                 self.adam.key() if self.adam is not None else None)
+
+    def _slab_sinks(self):
+        """The owner's gradient slab (train_iteration: data_parallel) as gradient sinks of the captured step: the raw
+        gradients are written into the slab's views by the activations' backward, xyz's by the rasterizer's."""
+        import contextlib
+        slabv = getattr(self.owner, "grad_slab", None)
+        stack = contextlib.ExitStack()
+        if slabv:
+            import activations
+            import diff_gaussian_rasterization as dgr
+            stack.enter_context(activations.grad_sink({k: v for k, v in slabv.items() if k in activations.RAW}))
+            if "xyz" in slabv:
+                stack.enter_context(dgr.grad_sink({"means3D": slabv["xyz"]}))
+        return stack
+
+    def _into_slab(self, g, grads):
+        """Inside the backward capture: every gradient ends up in its slab view (most were born there; the light's is
+        copied by one node), and the views are what the captured Adam launch reads."""
+        slabv = getattr(self.owner, "grad_slab", None)
+        if not slabv:
+            return list(grads)
+        names = list(g.keys()) + (["cubemap"] if getattr(self.owner, "light", None) is not None else [])
+        out = list(grads)
+        with torch.no_grad():
+            for i, name in enumerate(names):
+                v = slabv.get(name)
+                if v is None:
+                    continue
+                if out[i] is None:
+                    v.zero_()
+                elif out[i].data_ptr() != v.data_ptr():
+                    v.copy_(out[i])
+                out[i] = v
+        return out
 
     def _capture(self, cam, g, gt_image, view_dirs):
         import gc
@@ -482,9 +518,10 @@ class WholeStepGraph:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                with self.bin:
-                    res = self.inner(self.s_cam, prep(g), self.s_gt, self.s_vd)
-                torch.autograd.grad(res.pop("_loss"), params + [res["viewspace_points"]], allow_unused=True)
+                with self._slab_sinks():
+                    with self.bin:
+                        res = self.inner(self.s_cam, prep(g), self.s_gt, self.s_vd)
+                    torch.autograd.grad(res.pop("_loss"), params + [res["viewspace_points"]], allow_unused=True)
                 del res
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -510,7 +547,7 @@ class WholeStepGraph:
             # thread_local: a re-capture (binning overflow) may happen while RCCL's proxy thread is alive and issuing HIP
             # calls of its own, which the default (global) capture mode turns into a capture failure
             with torch.cuda.graph(gf, stream=cap, capture_error_mode="thread_local"):
-                with self.bin:
+                with self.bin, self._slab_sinks():
                     res = self.inner(self.s_cam, prep(g), self.s_gt, self.s_vd)
                 self.bin.host.copy_(self.bin.counters, non_blocking=True)
             loss = res.pop("_loss")
@@ -525,8 +562,10 @@ class WholeStepGraph:
                 with torch.cuda.graph(gb, pool=gf.pool(), stream=cap, capture_error_mode="thread_local"):
                     # the seed gradient as a persistent tensor: autograd's own ones_like(loss) is a fill node at the head of
                     # the backward graph
-                    grads = torch.autograd.grad(loss, params + [res["viewspace_points"]], grad_outputs=self._seed.reshape(loss.shape),
-                                                allow_unused=True)
+                    with self._slab_sinks():
+                        grads = torch.autograd.grad(loss, params + [res["viewspace_points"]],
+                                                    grad_outputs=self._seed.reshape(loss.shape), allow_unused=True)
+                    grads = self._into_slab(g, grads)
             finally:
                 light_ops.bwd_head_start_ns = 0
             del loss
@@ -1037,13 +1076,11 @@ def _close_stepper(self):
     """Deterministic teardown of everything that owns hipGraphs (WholeStepGraphs, graphed callables, the graphed
     rasterizer): synchronise, release, synchronise.  The stepper captures again if it is called afterwards.  Steppers and
     trainers are context managers (`with Stage2Trainer(...) as tr:`) that close on exit."""
+    # the WholeStepGraph objects stay (they remember the binning capacity and count their captures); their graphs go
     for w in list(getattr(self, "_wholes", {}).values()):
         w.close()
     if getattr(self, "whole", None) is not None:
         self.whole.close()
-    self.whole = None
-    if hasattr(self, "_wholes"):
-        self._wholes.clear()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     if getattr(self, "_captured", False):  # piecewise path: the two graphed callables

@@ -179,3 +179,37 @@ def load_checkpoint(path: str, map_location: Optional[str] = "cpu") -> Dict:
         if k not in ckpt:
             raise ValueError(f"{path}: not a GI-GS checkpoint (no '{k}')")
     return ckpt
+
+
+def ply_sh_degree(path: str) -> int:
+    """The SH degree a point_cloud.ply was saved with, from its f_rest_* property count (3 * ((deg + 1)^2 - 1))."""
+    v = read_ply_vertices(path)
+    n_rest = sum(1 for n in v if n.startswith("f_rest_"))
+    K = n_rest // 3 + 1
+    deg = int(round(K ** 0.5)) - 1
+    if (deg + 1) ** 2 != K or n_rest % 3:
+        raise ValueError(f"{path}: {n_rest} f_rest_* properties do not make a whole SH degree")
+    return deg
+
+
+def load_scene(path: str) -> Dict[str, np.ndarray]:
+    """A trained scene from disk -- `point_cloud.ply` (GaussianModel.save_ply, scene/gaussian_model.py:397-465) or
+    `chkpntN.pth` (train.py:466-490) -- as the POST-ACTIVATION arrays the rasterizer takes (the getters of
+    scene/gaussian_model.py:178-263 applied on the CPU): the dictionary layout of gi-gs_amd/scenes.py
+    (means3D, shs [P,K,3], opacities, normal, albedo, roughness, metallic, scales, rotations, sh_degree) + "raw"."""
+    if path.endswith(".ply"):
+        deg = ply_sh_degree(path)
+        raw = load_ply(path, deg)
+    else:
+        ckpt = load_checkpoint(path)
+        _, raw, _, _, _ = restore(ckpt["gaussians"])
+        raw = {k: (v.detach().float().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in raw.items()}
+        K = 1 + int(raw["f_rest"].shape[1])
+        deg = int(round(K ** 0.5)) - 1
+    F = torch.nn.functional
+    f32 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)  # noqa: E731
+    return dict(means3D=f32(raw["xyz"]), shs=f32(torch.cat((raw["f_dc"], raw["f_rest"]), dim=1)),
+                opacities=f32(torch.sigmoid(raw["opacity"])), normal=f32(F.normalize(raw["normal"], dim=-1)),
+                albedo=f32(torch.sigmoid(raw["albedo"])), roughness=f32(torch.sigmoid(raw["roughness"])),
+                metallic=f32(torch.sigmoid(raw["metallic"])), scales=f32(torch.exp(raw["scaling"])),
+                rotations=f32(F.normalize(raw["rotation"])), sh_degree=deg, raw={k: f32(v) for k, v in raw.items()})

@@ -131,6 +131,10 @@ class Stage2Trainer:
             raise ValueError("replace_parameters: the tensors must be the ones the optimizer's groups hold")
         self.stepper.close()  # the graphs around the old tensors are released here, with the device idle
         self.raw = {k: raw[k] for k in RAW_KEYS}
+        if getattr(self, "_dp_args", None) is not None:  # the gradient slab follows the new tensors
+            timing = self.slab.timing
+            _attach_slab(self, *self._dp_args, light=self.light)
+            self.slab.timing = timing
 
     # the tensors a stage-2 iteration's loss reaches (train.py:330-420): everything else gets exact zeros
     STAGE2_TRAINABLE = ("albedo", "roughness", "metallic", "cubemap")
@@ -147,21 +151,45 @@ class Stage2Trainer:
             return {n: by_id[id(leaves[n])] for n in names if by_id.get(id(leaves[n])) is not None}
         return {n: leaves[n].grad for n in names if leaves[n].grad is not None}
 
-    def data_parallel(self, group=None, names=STAGE2_TRAINABLE, average: bool = False) -> None:
+    def data_parallel(self, group=None, names=STAGE2_TRAINABLE, average: bool = False, force: bool = False):
         """View-parallel training: every rank runs `iteration` on its own view; between the backward and the
-        update the gradients of `names` are summed over the ranks IN PLACE -- in the buffers the (captured) Adam launch
-        reads -- so identically initialised ranks take identical updates.  A stage-2 iteration reaches only the default
-        `names`; pass every raw name for stage-1 style losses.  (bench.py's metric step, whose rasterizer inputs ARE the
-        leaves, uses dp.GradSlab + grad_sink instead: one flat collective.)"""
-        import torch.distributed as dist
+        update the gradients of `names` are summed over the ranks -- ONE collective on the communication stream, over one
+        contiguous stretch of a dp.GradSlab that holds every raw gradient and the light's (the slab is ordered so that
+        `names` are adjacent, at its end).  On the graph path the backward writes the raw gradients straight into the slab
+        (activations.grad_sink; the rasterizer's grad_sink for xyz; the light's is copied in by a node of the backward graph)
+        and the captured Adam launch reads the slab's views, so nothing is packed or unpacked per step; the eager path packs
+        `.grad` once.  Identically initialised ranks take identical updates.  A stage-2 iteration reaches only the default
+        `names` (every other gradient is an exact zero on every rank); pass every raw name for stage-1 style losses.
+        `force` issues the collective with a single rank too (a one-GPU RCCL rehearsal).  Returns the slab
+        (`.timing = True` + `.comm_stats()` for measurements)."""
+        return _attach_slab(self, group, names, average, force, light=self.light)
 
-        def hook():
-            world = dist.get_world_size(group)
-            for t in self.grad_buffers(names).values():
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                if average:
-                    t.div_(world)
-        self.stepper.before_update = hook
+
+def _attach_slab(trainer, group, names, average, force, light=None):
+    import dp
+    raw = trainer.raw
+    leaves = dict(raw)
+    if light is not None:
+        leaves["cubemap"] = light.base
+    unknown = [n for n in names if n not in leaves]
+    if unknown:
+        raise KeyError("data_parallel: unknown parameter name(s) " + ", ".join(unknown))
+    order = [k for k in leaves if k not in names] + [k for k in leaves if k in names]  # the reduced stretch last: one piece
+    slab = dp.GradSlab([leaves[k] for k in order], group)
+    only = [i for i, k in enumerate(order) if k in names]
+    trainer.slab, trainer.slab_order = slab, order
+    trainer._dp_args = (group, tuple(names), average, force)
+    stepper = trainer.stepper
+    stepper.grad_slab = {k: v for k, v in zip(order, slab.views)}
+
+    def hook():
+        wsg = stepper.whole
+        packed = wsg is not None and wsg.gf is not None  # the captured backward has written the views
+        slab.allreduce_async(average=average, force=force, only=None if len(only) == len(order) else only, packed=packed)
+        slab.wait()
+    stepper.before_update = hook
+    stepper.close()  # graphs captured before this call hand their gradients out elsewhere
+    return slab
 
 
 class Stage1Trainer:
@@ -206,60 +234,111 @@ class Stage1Trainer:
         self.close()
         return False
 
+    def data_parallel(self, group=None, names=RAW_KEYS, average: bool = False, force: bool = False):
+        """As Stage2Trainer.data_parallel; a stage-1 loss reaches every Gaussian group, so the whole slab is one collective."""
+        return _attach_slab(self, group, names, average, force)
+
     def replace_parameters(self, raw: Dict[str, torch.Tensor]) -> None:
         held = {id(g["params"][0]) for g in self.optimizer.param_groups}
         if any(k not in raw or id(raw[k]) not in held for k in RAW_KEYS):
             raise ValueError("replace_parameters: pass the tensors the optimizer's groups hold, under the reference's names")
         self.stepper.close()
         self.raw = {k: raw[k] for k in RAW_KEYS}
+        if getattr(self, "_dp_args", None) is not None:
+            timing = self.slab.timing
+            _attach_slab(self, *self._dp_args)
+            self.slab.timing = timing
 
 
-def bench_stage1_iteration(sc, gi, sh_degree, cams_t, gt_image, steps=40, warmup=5, compute_occlusion=True) -> Dict:
-    """bench.py's `iteration_stage1` field."""
-    raw = raw_from_scene(sc, gt_image.device)
-    tr = Stage1Trainer(raw, gi, sh_degree, graphs=True, compute_occlusion=compute_occlusion)
-    n = len(cams_t)
+def _dp_timed(run, steps, warmup, slab):
+    """`steps` iterations between two (barrier + synchronize) brackets; with a process group the maximum over the ranks."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
     for i in range(warmup):
-        tr.iteration(cams_t[i % n], gt_image)
+        run(i)
+    if slab is not None:
+        torch.cuda.synchronize()
+        slab.comm_stats()  # drop the warm-up collectives' events
+    if on:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        out = tr.iteration(cams_t[(warmup + i) % n], gt_image)
+        out = run(warmup + i)
+    if on:
+        dist.barrier()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = time.perf_counter() - t0
+    if on:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt / steps, out
+
+
+def _dp_fields(slab, world, P):
+    if slab is None:
+        return {}
+    comm = slab.comm_stats() or {}
+    comm["floats_per_gaussian"] = round(comm.get("bytes", 0) / 4 / max(P, 1), 2)
+    return {"data_parallel": {"ranks": world, "views_per_iteration": world, "comm": comm,
+                              "how": "ONE all-reduce of a contiguous stretch of the gradient slab on the communication stream, "
+                                     "between the backward graph and the captured Adam (which reads the slab's views)"}}
+
+
+def bench_stage1_iteration(sc, gi, sh_degree, cams_t, gt_image, steps=40, warmup=5, compute_occlusion=True,
+                           data_parallel=False, force=False, rank=0, world=1) -> Dict:
+    """bench.py's `iteration_stage1` field.  data_parallel: every rank trains on its own view and EVERY raw gradient is
+    summed over the ranks (a stage-1 loss reaches every Gaussian group) before the update."""
+    import dp
+    raw = raw_from_scene(sc, gt_image.device)
+    tr = Stage1Trainer(raw, gi, sh_degree, graphs=True, compute_occlusion=compute_occlusion)
+    slab = None
+    if data_parallel:
+        slab = tr.data_parallel(force=force)
+        slab.timing = True
+    n = len(cams_t)
+    dt, out = _dp_timed(lambda i: tr.iteration(cams_t[dp.view_for(i, rank, world, n)], gt_image), steps, warmup, slab)
     formulation = "3 hipGraphs (fwd, bwd, update)" if tr.stepper.whole is not None else "eager"
     final_loss = float(out["loss"])
     del out
+    extra = _dp_fields(slab, world, raw["xyz"].shape[0])
     tr.close()
-    return {"iterations_per_s": round(1.0 / dt, 2), "ms_per_iteration": round(1e3 * dt, 3), "steps": steps, "final_loss": final_loss,
+    return {"iterations_per_s": round(world / dt, 2), "ms_per_iteration": round(1e3 * dt, 3), "steps": steps, "final_loss": final_loss, **extra,
             "what": "activations + rasterizer + in-op filters + SSAO + G-buffer post-processing + L1 + D-SSIM + masked normal L1 + "
                     "normal TV + backward (colour and normal gradients: the blend backward's full chain) + Adam (train.py:266-331, 517-520)",
             "formulation": formulation}
 
 
-def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_image, steps=40, warmup=5) -> Dict:
-    """bench.py's `iteration` field: complete iterations/s of the C-config workload on the fast path (three hipGraphs)."""
+def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_image, steps=40, warmup=5,
+                    data_parallel=False, force=False, rank=0, world=1) -> Dict:
+    """bench.py's `iteration` field: complete iterations/s of the C-config workload on the fast path (three hipGraphs).
+    data_parallel: Stage2Trainer.data_parallel() -- every rank trains on its own view, the stage-2 gradient set (materials
+    and light) is summed over the ranks before the update; `iterations_per_s` then counts views (ranks x iterations)."""
+    import dp
     dev = gt_image.device
     raw = raw_from_scene(sc, dev)
     base0 = light.base.detach().clone()
     tr = Stage2Trainer(raw, light, brdf_lut, gi, sh_degree, graphs=True)
+    slab = None
+    if data_parallel:
+        slab = tr.data_parallel(force=force)
+        slab.timing = True
     n = len(cams_t)
-    for i in range(warmup):
-        tr.iteration(cams_t[i % n], gt_image, view_dirs[i % n])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        out = tr.iteration(cams_t[(warmup + i) % n], gt_image, view_dirs[(warmup + i) % n])
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+
+    def run(i):
+        v = dp.view_for(i, rank, world, n)
+        return tr.iteration(cams_t[v], gt_image, view_dirs[v])
+    dt, out = _dp_timed(run, steps, warmup, slab)
     whole = tr.stepper.whole is not None
     final_loss = float(out["loss"])
     del out
+    extra = _dp_fields(slab, world, raw["xyz"].shape[0])
     tr.close()
     with torch.no_grad():
         light.base.copy_(base0)  # bench.py's light is shared with the legs that follow
-    return {"iterations_per_s": round(1.0 / dt, 2), "ms_per_iteration": round(1e3 * dt, 3), "steps": steps,
-            "final_loss": final_loss,
+    return {"iterations_per_s": round(world / dt, 2), "ms_per_iteration": round(1e3 * dt, 3), "steps": steps,
+            "final_loss": final_loss, **extra,
             "what": "activations + rasterizer + SSAO + build_mips + shade + SSR + L1 + lamb + masked BRDF TV + envmap TV + "
                     "backward + Adam (10 Gaussian groups + light) + clamp (train.py:247-523 without data loading / densification)",
             "formulation": "3 hipGraphs (fwd, bwd, update)" if whole else "eager rasterizer (dense scene / fallback), fused glue"}

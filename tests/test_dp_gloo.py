@@ -81,6 +81,19 @@ def _worker(rank, world, port, out_dir):
     except RuntimeError:
         only_caught = True
 
+    # packed: the slab already holds the step's gradients (a captured backward wrote the views) and `.grad` is not in play:
+    # nothing is gathered before the collective (a parameter whose .grad is None must NOT have its view zeroed) and nothing
+    # is assigned afterwards (train_iteration.Stage2Trainer.data_parallel on the graph path)
+    slabp = dp.GradSlab(params[:3])
+    for p in params:
+        p.grad = None
+    pk = [torch.randn(p.shape, generator=g) for p in params[:3]]
+    for v, t in zip(slabp.views, pk):
+        v.copy_(t)
+    slabp.allreduce_async(only=[1, 2], packed=True)
+    slabp.wait()
+    packed_out = dict(local=pk, reduced=[v.clone() for v in slabp.views], grads_none=all(p.grad is None for p in params[:3]))
+
     # densification replaces the parameter OBJECTS (cat_tensors_to_optimizer, scene/gaussian_model.py:669-706): the slab is
     # rebuilt from the current list and reduces the grown tensors
     grown = [torch.zeros(P + 5 + rank * 0, 3, requires_grad=True), params[1]]
@@ -119,7 +132,7 @@ def _worker(rank, world, port, out_dir):
     dens = {n: model["params"][n].clone() for n in densify_ref.NAMES}
     assert dens["xyz"].shape[0] != P  # something was cloned / split / pruned
     views = [dp.view_for(s, rank, world, 7) for s in range(5)]
-    torch.save(dict(conv=conv, local=grads, slab=out, only=only_out, rebuilt=rebuilt, only_caught=only_caught, vg=vg, radii=radii, stats=st, views=views, dens=dens),
+    torch.save(dict(conv=conv, local=grads, slab=out, only=only_out, packed=packed_out, rebuilt=rebuilt, only_caught=only_caught, vg=vg, radii=radii, stats=st, views=views, dens=dens),
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -150,6 +163,11 @@ def test_view_parallel_reduction_world2(tmp_path):
             want = r[0]["only"]["local"][i] + r[1]["only"]["local"][i] if i in (1, 2, 4) else torch.zeros_like(r[0]["only"]["local"][i])
             torch.testing.assert_close(r[k]["only"]["reduced"][i], want)
     assert r[0]["only_caught"] and r[1]["only_caught"]
+    for k in range(world):  # packed: the reduced stretch is summed in place, the rest of the slab and every .grad untouched
+        assert r[k]["packed"]["grads_none"]
+        torch.testing.assert_close(r[k]["packed"]["reduced"][0], r[k]["packed"]["local"][0])
+        for i in (1, 2):
+            torch.testing.assert_close(r[k]["packed"]["reduced"][i], r[0]["packed"]["local"][i] + r[1]["packed"]["local"][i])
     for i in range(2):  # the slab rebuilt around a grown parameter
         for k in range(world):
             torch.testing.assert_close(r[k]["rebuilt"]["reduced"][i], r[0]["rebuilt"]["local"][i] + r[1]["rebuilt"]["local"][i])

@@ -146,16 +146,23 @@ def test_c3_inference_planes():
         np.testing.assert_array_equal(ha[k], hb[k])
 
 
-def _oracle_parity(orc, sc, cam, deg, light_res, tag, grads_only=None, per_pixel=False):
-    """One view through the product (timed formulation: fused stage-2 node) and through the oracle composition."""
+def _oracle_parity(orc, sc, cam, deg, light_res, tag, grads_only=None, per_pixel=False, graphs=False):
+    """One view through the product (timed formulation: fused stage-2 node; graphs=True: replayed from the whole-step
+    hipGraphs under asynchronous binning, exactly what bench.py times) and through the oracle composition."""
     import pbr
+    import pipeline
     from oracle import parity
     orc.set_threads(orc.max_threads())  # full-size views: use every host core (conftest caps the small tests at 8)
     try:
         torch.manual_seed(0)
         light = pbr.CubemapLight(base_res=light_res).to(DEV)
         gi = scenes.GI_DEFAULTS
-        gpu = parity.gpu_capture(sc, cam, gi, deg, light=light, brdf_lut=pbr.get_brdf_lut().to(DEV), grads_only=grads_only, dev=DEV)
+        lut = pbr.get_brdf_lut().to(DEV)
+        stepper = pipeline.Stage2Step(light, lut, gi, deg, graphs=True, fused=True) if graphs else None
+        gpu = parity.gpu_capture(sc, cam, gi, deg, light=light, brdf_lut=lut, grads_only=grads_only, dev=DEV, stepper=stepper)
+        if stepper is not None:
+            assert stepper.whole is not None and stepper.whole.gf is not None, "the view did not take the whole-step graphs"
+            stepper.close()
         ref, _ = parity.oracle_capture(orc, sc, cam, gi, deg, light_base=gpu["light_base"], grads_only=grads_only)
         noise = parity.march_noise(orc, sc, cam, gi, deg, gpu, ref, light=light, brdf_lut=pbr.get_brdf_lut().to(DEV),
                                    dev=DEV) if per_pixel else None
@@ -249,3 +256,78 @@ def test_c4_forward_matches_oracle_at_native_size(orc):
     finally:
         orc.set_threads(min(8, orc.max_threads()))
     assert res[0] > 20_000_000 and nflip <= 1e-4 * 1237 * 822
+
+
+def test_c5_native_size_matches_oracle_through_the_graphed_step(orc):
+    """BASELINE configs[4] (Mip-NeRF360 garden images_4, the 8-GPU configuration) at its own per-GPU workload: 3 M Gaussians,
+    SH 3, 1297x840, --metallic --indirect, ONE view through the timed formulation (fused stage-2 node replayed from the
+    whole-step hipGraphs, dense-scene asynchronous binning) against the oracle: indices bit for bit, every plane within
+    1e-4 mean L1, the stage-2 gradient set within 1e-3, PSNR of the stage-2 image."""
+    sc = scenes.surface_scene(P=3_000_000, sh_degree=3, seed=0)
+    cam = scenes.orbit_camera(3, 64, 1297, 840, radius=3.5)
+    rep = _oracle_parity(orc, sc, cam, 3, 256, "C5", grads_only=("albedo", "roughness", "metallic"), graphs=True)
+    assert rep["num_rendered"][0] > 20_000_000
+
+
+def test_c5_eight_views_through_the_gradient_slab_sum_like_eight_backward_passes():
+    """configs[4] shards by view: rank r renders view r and ONE flat all-reduce sums the ranks' gradient slabs
+    (dp.GradSlab; SURVEY 8(e), train.py:247-279).  The arithmetic that collective must reproduce, in one process at the
+    native workload (3 M Gaussians, SH 3, 1297x840): eight views through the graphed step writing into the slab
+    (dgr.grad_sink), their slabs added up -- equal to the sum of eight plain backward passes (eager stepper, ordinary
+    `.grad`), on the stage-2 trainable stretch that bench.py reduces and, exactly zero, everywhere else."""
+    import diff_gaussian_rasterization as dgr
+    import dp
+    import pbr
+    import pipeline
+    P, W, H, deg = 3_000_000, 1297, 840, 3
+    sc = scenes.surface_scene(P=P, sh_degree=deg, seed=0)
+    gi = scenes.GI_DEFAULTS
+    cams = [scenes.orbit_camera(8 * i + 1, 64, W, H, radius=3.5) for i in range(8)]
+    camts = [{k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    rays = pipeline.canonical_rays(cams[0], DEV)
+    vds = [pipeline.view_dirs_for(c, rays, DEV) for c in camts]
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=DEV), torch.linspace(0, 1, W, device=DEV), indexing="ij")
+    gt = torch.stack([0.5 + 0.3 * torch.sin(6 * xx), 0.5 + 0.3 * torch.cos(5 * yy), 0.4 + 0.2 * xx * yy])
+    torch.manual_seed(0)
+    light = pbr.CubemapLight(base_res=256).to(DEV)
+    lut = pbr.get_brdf_lut().to(DEV)
+    keys = ["means3D", "opacities", "normal", "shs", "scales", "rotations", "albedo", "roughness", "metallic"]  # bench.py's slab order
+    sink_name = {"opacities": "opacity", "shs": "sh"}
+    g = {k: tt(sc[k], grad=True) for k in keys}
+    flat = [g[k] for k in keys] + list(light.parameters())
+    first_trainable = keys.index("albedo")
+    # (1) eight plain backward passes, summed in fp64 on the trainable stretch
+    eager = pipeline.Stage2Step(light, lut, gi, deg, graphs=False, fused=True)
+    want = [torch.zeros(p.shape, dtype=torch.float64, device=DEV) for p in flat[first_trainable:]]
+    for v in range(8):
+        for p in flat:
+            p.grad = None
+        eager(camts[v], g, gt, vds[v])
+        for acc, p in zip(want, flat[first_trainable:]):
+            acc += p.grad.double()
+        for p in flat[:first_trainable]:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0  # stage 2 reaches the materials and the light only
+    # (2) the same views through the graphed step into the slab; the "all-reduce" = the sum of the eight slabs
+    slab = dp.GradSlab(flat)
+    sink = slab.sink([sink_name.get(k, k) for k in keys])
+    step = pipeline.Stage2Step(light, lut, gi, deg, graphs=True, fused=True)
+    total = torch.zeros_like(slab.flat, dtype=torch.float64)
+    for v in range(8):
+        for p in flat:
+            p.grad = None
+        with dgr.grad_sink(sink):
+            step(camts[v], g, gt, vds[v])
+        assert step.whole is not None, "C5 did not take the whole-step graphs"
+        slab._gather_stray()  # what allreduce_async does first: a gradient born outside the slab (the light's) is copied in once
+        total += slab.flat.double()
+    torch.cuda.synchronize()
+    off = slab.offsets[first_trainable]
+    assert float(total[:off].abs().max()) == 0.0, "a non-trainable gradient is not an exact zero"
+    for acc, p, o in zip(want, flat[first_trainable:], slab.offsets[first_trainable:]):
+        got = total[o:o + p.numel()].view(p.shape)
+        scale = float(acc.abs().max())
+        assert scale > 0
+        rel = float((got - acc).abs().sum() / acc.abs().sum())
+        assert rel <= 1e-4, (tuple(p.shape), rel)  # float atomics in the blend / shade backward: equal to rounding
+        assert float((got - acc).abs().max()) <= 2e-3 * scale, tuple(p.shape)
+    step.close()

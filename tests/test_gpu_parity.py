@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 import torch
 
+import gigs_lib
 import scenes
 from helpers import GAUSS_KEYS, focal, oracle_forward, random_pix_grads, set_options, small_scene
 
@@ -906,3 +907,19 @@ def test_two_contexts_on_two_streams_equal_the_serial_runs(orc):
     for i in (0, 1, 2, 3, 5, 6, 7, 8, 9):  # colour, radii, opacity, depth, normal, occlusion (cert / zero rays: same bits), materials
         x, y = oB2[i].detach(), gotB[0][i]
         assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y), i
+
+
+@pytest.mark.parametrize("mode", ["bucket", "long_lists"])
+def test_long_runs_of_identical_depths_sort_in_bounded_time(orc, mode, monkeypatch):
+    """A tile that holds thousands of bit-identical depths (a cloned Gaussian: 4 500 copies; a second run of 70, just over
+    the fix-up's round budget): the LDS sorts order them by index through the bounded fix-up / the complete-key sort
+    (csrc/binning.hip::sort_tile_radix) -- keys, point_list and ranges equal the oracle's stable sort bit for bit."""
+    set_options(monkeypatch, long_lists=1 if mode == "long_lists" else -1)
+    sc = scenes.random_scene(P=9000, sh_degree=1, seed=23, scale_mu=0.05)
+    for k in GAUSS_KEYS:
+        sc[k][2000:6500] = sc[k][321]
+        sc[k][7000:7070] = sc[k][654]
+    sc["opacities"][2000:6500] = 0.01  # faint: the walk goes through all of them
+    cam = scenes.orbit_camera(1, 6, 160, 128)
+    _, _, res, _ = check_forward(orc, sc, cam, tag="identical depths " + mode + " ")
+    assert res[0] > 4500

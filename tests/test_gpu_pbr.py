@@ -689,3 +689,89 @@ def test_shade_backward_in_two_launches_equals_one(monkeypatch):
         for k in ref[1]:
             assert torch.equal(got[1][k], ref[1][k]) or rel_peak(got[1][k].cpu().numpy(), ref[1][k].cpu().numpy()) < 1e-6, k
         assert rel_peak(got[2].cpu().numpy(), ref[2].cpu().numpy()) < 2e-3  # float atomics: order-dependent rounding
+
+
+def test_hipgraph_lifetime_is_deterministic(monkeypatch):
+    """The round-3 host segfault (hip::Graph::UpdateStreams at the first replay of a fresh exec) came from graph execs that
+    a cyclic-GC pass destroyed at an arbitrary moment: WholeStepGraph <-> Stage2Step was a reference cycle.  Now the owner
+    is held weakly and teardown is explicit: (a) dropping the last reference to a stepper destroys its graphs at once, with
+    the collector switched OFF (no cycle); (b) close() leaves nothing captured and the stepper captures again on the next
+    call; (c) the bisected sequence -- earlier captures, an eager full-size step, a new capture, its first replay -- runs
+    with the collector enabled.  Run once; the autouse teardown of the GPU tests is not what keeps it alive."""
+    import gc
+    import weakref
+
+    import pbr
+    import pipeline
+    import train_iteration
+    monkeypatch.setenv("GIGS_STEP_GRAPH", "1")
+    monkeypatch.setenv("GIGS_RASTER_GRAPH", "0")
+    sc = scenes.surface_scene(P=6000, sh_degree=2, seed=21, scale_mu=0.03)
+    gi = scenes.GI_DEFAULTS
+    H, W = 112, 144
+    cam = scenes.orbit_camera(0, 6, W, H, radius=3.5)
+    camt = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    vd = pipeline.view_dirs_for(camt, pipeline.canonical_rays(cam, DEV), DEV)
+
+    def make():
+        torch.manual_seed(6)
+        light = pbr.CubemapLight(base_res=64, device=DEV)
+        g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        return pipeline.Stage2Step(light, lut, gi, 2, fused=True, graphs=True), g
+
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        # (a) no cycle: the graphs die with the last reference, collector off
+        step, g = make()
+        loss0 = float(step(camt, g, gt, vd)["loss"])
+        whole = weakref.ref(step.whole)
+        gf = weakref.ref(step.whole.gf)
+        assert whole() is not None and gf() is not None
+        del step
+        assert whole() is None and gf() is None, "a reference cycle keeps the graph execs alive until the collector runs"
+        # (b) close(): nothing captured afterwards, and the next call captures again with the same result
+        step, g = make()
+        step(camt, g, gt, vd)
+        w = step.whole
+        assert w.gf is not None
+        step.close()
+        assert w.gf is None and w.gb is None and w.res is None and w.inner is None
+        assert abs(float(step(camt, g, gt, vd)["loss"]) - loss0) <= 1e-6 * max(1.0, abs(loss0))
+        assert step.whole is w and w.gf is not None and w.recaptures == 2
+        # a trainer (trainer <-> stepper IS a cycle through bound methods): close() is what releases its graphs
+        raw = train_iteration.raw_from_scene(sc, DEV)
+        with train_iteration.Stage2Trainer(raw, pbr.CubemapLight(base_res=64, device=DEV), lut, gi, 2, graphs=True) as tr:
+            tr.iteration(camt, gt, vd)
+            tw = tr.stepper.whole
+            assert tw is not None and tw.gf is not None
+        assert tw.gf is None and tw.gb is None and tw.go is None
+    finally:
+        if was:
+            gc.enable()
+    # (c) the bisected sequence, collector enabled: earlier captures (above, still alive in `step`), an eager full-size
+    # step, a new capture, its first replay
+    Hf, Wf = 800, 800
+    camf = scenes.orbit_camera(5, 64, Wf, Hf, radius=3.5)
+    camft = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in camf.items()}
+    big = scenes.surface_scene(P=120_000, sh_degree=2, seed=0)
+    gb = {k: tt(big[k], grad=True) for k in GAUSS_KEYS}
+    gtf = torch.rand(3, Hf, Wf, device=DEV) * 0.5
+    vdf = pipeline.view_dirs_for(camft, pipeline.canonical_rays(camf, DEV), DEV)
+    lightf = pbr.CubemapLight(base_res=64, device=DEV)
+    pipeline.Stage2Step(lightf, lut, gi, 2, fused=True, graphs=False)(camft, gb, gtf, vdf)  # eager, full size
+    new = pipeline.Stage2Step(lightf, lut, gi, 2, fused=True, graphs=True)
+    for t in list(gb.values()) + [lightf.base]:
+        t.grad = None
+    o1 = new(camft, gb, gtf, vdf)   # capture + first replay
+    l1 = float(o1["loss"])
+    for t in list(gb.values()) + [lightf.base]:
+        t.grad = None
+    o2 = new(camft, gb, gtf, vdf)   # second replay
+    torch.cuda.synchronize()
+    assert np.isfinite(l1) and abs(float(o2["loss"]) - l1) <= 1e-6 * max(1.0, abs(l1))
+    new.close()
+    step.close()

@@ -132,3 +132,60 @@ def test_fused_adam_checkpoint_resumes_under_torch_adam(tmp_path):
     sd["param_groups"][0]["amsgrad"] = True
     with pytest.raises(ValueError):
         back.load_state_dict(sd)
+
+
+def test_bench_real_scene_hook_reads_a_saved_ply(tmp_path):
+    """bench.py --scene / --cameras (real data if present on the box): a point_cloud.ply written by save_ply
+    and a transforms json come back as the post-activation arrays of the getters (scene/gaussian_model.py:178-263) and
+    as camera dicts at the bench resolution; the same through a chkpntN.pth."""
+    import argparse
+    import importlib
+    import json
+    import sys
+
+    import numpy as np
+    import torch
+
+    import activations
+    import densify
+    import scene_io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    torch.manual_seed(0)
+    P, deg = 500, 2
+    K = (deg + 1) ** 2
+    raw = dict(xyz=torch.randn(P, 3), f_dc=torch.randn(P, 1, 3), f_rest=torch.randn(P, K - 1, 3) * 0.1, opacity=torch.randn(P, 1),
+               normal=torch.randn(P, 3), albedo=torch.randn(P, 3), roughness=torch.randn(P, 1), metallic=torch.randn(P, 1),
+               scaling=torch.randn(P, 3) * 0.3 - 3.0, rotation=torch.randn(P, 4))
+    ply = str(tmp_path / "point_cloud.ply")
+    scene_io.save_ply(ply, raw)
+    assert scene_io.ply_sh_degree(ply) == deg
+    # poses: two frames of a NeRF-synthetic style json
+    c2w = np.eye(4)
+    c2w[:3, 3] = [0.0, -4.0, 0.5]
+    tf = str(tmp_path / "transforms_train.json")
+    with open(tf, "w") as f:
+        json.dump({"camera_angle_x": 0.6911, "frames": [{"file_path": "./train/r_0", "transform_matrix": c2w.tolist()},
+                                                        {"file_path": "./train/r_1", "transform_matrix": c2w.tolist()}]}, f)
+    args = argparse.Namespace(scene=ply, cameras=tf, gaussians=None, sh_degree=None)
+    sc, cams, tag = bench.load_workload(args, 96, 64)
+    assert args.gaussians == P and args.sh_degree == deg and ply in tag and len(cams) == 2
+    want = activations.activate_torch(raw)
+    for k in ("means3D", "shs", "opacities", "normal", "albedo", "roughness", "metallic", "scales", "rotations"):
+        np.testing.assert_allclose(sc[k], want[k].numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+    assert sc["shs"].shape == (P, K, 3)
+    assert cams[0]["image_width"] == 96 and cams[0]["image_height"] == 64 and cams[0]["viewmatrix"].shape == (4, 4)
+    assert abs(cams[0]["tanfovx"] - np.tan(0.6911 / 2)) < 1e-6 and np.allclose(cams[0]["campos"], [0.0, -4.0, 0.5], atol=1e-6)
+    # without --cameras: 64 orbit views around the cloud
+    args2 = argparse.Namespace(scene=ply, cameras=None, gaussians=None, sh_degree=None)
+    _, cams2, tag2 = bench.load_workload(args2, 80, 80)
+    assert len(cams2) == 64 and "orbit" in tag2 and "eye_target" in cams2[0]
+    # the same scene from a checkpoint
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in raw.items()}
+    opt = torch.optim.Adam([{"params": [params[k]], "lr": 1e-3, "name": k} for k in scene_io.NAMES], lr=0.0, eps=1e-15)
+    ck = str(tmp_path / "chkpnt30000.pth")
+    scene_io.save_checkpoint(ck, scene_io.capture(deg, params, densify.DensifyState(P, "cpu"), opt, 1.0), {}, {}, 30000)
+    sc3, _, _ = bench.load_workload(argparse.Namespace(scene=ck, cameras=None, gaussians=None, sh_degree=None), 64, 64)
+    for k in ("means3D", "shs", "opacities", "scales"):
+        np.testing.assert_allclose(sc3[k], sc[k], rtol=1e-6, atol=1e-7, err_msg=k)
