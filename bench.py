@@ -792,6 +792,9 @@ def secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n
         import train_iteration
         out["iteration"] = train_iteration.bench_iteration(sc, light, brdf_lut, gi, args.sh_degree, cams_t, view_dirs, gt_image,
                                                            steps=max(20, args.steps), warmup=5)
+        out["iteration_cached_geometry"] = train_iteration.bench_iteration(sc, light, brdf_lut, gi, args.sh_degree, cams_t, view_dirs,
+                                                                           gt_image, steps=max(20, args.steps), warmup=5,
+                                                                           geometry_cache=True)
         out["iteration_stage1"] = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image,
                                                                          steps=max(20, args.steps), warmup=5)
         lean = train_iteration.bench_stage1_iteration(sc, gi, args.sh_degree, cams_t, gt_image, steps=max(20, args.steps),

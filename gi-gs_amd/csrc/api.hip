@@ -182,7 +182,7 @@ const Options& default_options() {
   return o;
 }
 const Ctx& default_ctx() {
-  static const Ctx c = {default_options(), 0u, nullptr, nullptr};
+  static const Ctx c = {default_options(), 0u, nullptr, nullptr, 0};
   return c;
 }
 }  // namespace gigs
@@ -239,8 +239,8 @@ long long gigs_image_offset(int width, int height, int which) {
   char* base = nullptr;
   char* p = base;
   gigs::ImageState s = gigs::ImageState::fromChunk(p, N, T);
-  const void* ptrs[] = {s.final_T, s.n_contrib, s.ranges};
-  if (which < 0 || which >= 3) return -1;
+  const void* ptrs[] = {s.final_T, s.n_contrib, s.ranges, s.tile_order};
+  if (which < 0 || which >= 4) return -1;
   return (long long)((const char*)ptrs[which] - base);
 }
 
@@ -277,6 +277,11 @@ int gigs_ctx_set_options(gigs_ctx* ctx, const gigs_options* in) {
   o.gi_march = in->gi_march; o.gi_cert = in->gi_cert != 0; o.gi_interleave = in->gi_interleave != 0;
   o.gi_tile_log2w = in->gi_tile_log2w; o.gi_zero_rays = in->gi_zero_rays != 0; o.spec_max8 = in->spec_max8;
   o.spec_max16 = in->spec_max16; o.shade_lds_floats = in->shade_lds_floats; o.shade_bwd_blocks = in->shade_bwd_blocks;
+  return 0;
+}
+int gigs_ctx_set_reuse_binning(gigs_ctx* ctx, int on) {
+  if (!ctx) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_reuse_binning: the default context is immutable, create one");
+  reinterpret_cast<gigs::Ctx*>(ctx)->reuse_binning = on != 0;
   return 0;
 }
 int gigs_ctx_set_blend_begin_event(gigs_ctx* ctx, void* hip_event) {
@@ -407,7 +412,19 @@ int gigs_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_user, g
     return est_mean > (size_t)opt.bucket_max_mean;
   };
   bool dense = false;
-  if (bucket) {
+  if (cx.reuse_binning) {
+    // Frozen geometry (gigs_ctx_set_reuse_binning): the caller's binning and image chunks still hold ranges / tile_order /
+    // point_list of an earlier forward of this very view and geometry; only the per-Gaussian records (preprocess, above)
+    // and the blend (below) run.  The layout is the asynchronous one, so the capacity names it.
+    if (async_cap == 0 || !bucket)
+      return fail(GIGS_ERR_INVALID, "reuse_binning needs asynchronous binning (gigs_ctx_set_async_binning) on the tile-bucketed path");
+    num_rendered = (int)async_cap;
+    const size_t sort_sz = sort_size_cached(num_rendered);
+    const size_t bin_bytes = gigs::required_bytes<gigs::BinningState>((size_t)num_rendered, sort_sz);
+    char* bin_chunk = binningBuffer(bin_bytes, binning_user);
+    if (!bin_chunk) return fail(GIGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
+    bin = gigs::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, sort_sz);
+  } else if (bucket) {
     // Tile-bucketed binning (binning.hip): count -> prefix -> scatter -> per-tile sort, the instance count stays on
     // the device.  Synchronous calls (the reference's API returns num_rendered) read it back once, BEFORE the scatter,
     // to size the binning chunk exactly; with gigs_set_async_binning the chunk has the caller's capacity and nothing

@@ -254,6 +254,7 @@ struct Ctx {
   unsigned async_capacity;  // gigs_ctx_set_async_binning
   unsigned* async_counters;
   void* blend_begin_event;  // gigs_ctx_set_blend_begin_event
+  int reuse_binning;        // gigs_ctx_set_reuse_binning
 };
 const Options& default_options();  // api.hip
 const Ctx& default_ctx();          // options = default_options(), no async binning, no event

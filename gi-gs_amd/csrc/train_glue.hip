@@ -385,6 +385,9 @@ struct AdamGroups {
   // = {step_size, bc2_sqrt}, which the host refreshes before every replay (NULL: the by-value members above)
   const float* dyn;
   int dyn_base;
+  // gigs_adam_step_watch: bit k set = group k of this launch is watched; *changed |= 1 when one of its parameters changes
+  unsigned watch_mask;
+  unsigned* changed;
 };
 
 struct AdamConsts { float b2, omb1, omb2, eps; };  // beta2, 1 - beta1, 1 - beta2 (rounded from double as torch does), eps
@@ -410,6 +413,8 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
   const float ss = G.dyn ? G.dyn[2 * (G.dyn_base + gi)] : G.step_size[gi];
   const float bs = G.dyn ? G.dyn[2 * (G.dyn_base + gi) + 1] : G.bc2_sqrt[gi];
   const bool vec = ((((uintptr_t)P | (uintptr_t)Gr | (uintptr_t)M | (uintptr_t)V) & 15) == 0) && base + kAdamChunk <= n;
+  const bool watched = (G.watch_mask >> gi) & 1u;
+  bool moved = false;
   if (vec) {
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -417,10 +422,13 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
       float4 p = *reinterpret_cast<float4*>(P + i), m = *reinterpret_cast<float4*>(M + i);
       float4 v = *reinterpret_cast<float4*>(V + i);
       const float4 g = *reinterpret_cast<const float4*>(Gr + i);
+      const float4 p0 = p;
       adam_one(p.x, g.x, m.x, v.x, K, ss, bs);
       adam_one(p.y, g.y, m.y, v.y, K, ss, bs);
       adam_one(p.z, g.z, m.z, v.z, K, ss, bs);
       adam_one(p.w, g.w, m.w, v.w, K, ss, bs);
+      moved |= (__float_as_uint(p.x) != __float_as_uint(p0.x)) | (__float_as_uint(p.y) != __float_as_uint(p0.y)) |
+               (__float_as_uint(p.z) != __float_as_uint(p0.z)) | (__float_as_uint(p.w) != __float_as_uint(p0.w));
       *reinterpret_cast<float4*>(P + i) = p;
       *reinterpret_cast<float4*>(M + i) = m;
       *reinterpret_cast<float4*>(V + i) = v;
@@ -431,11 +439,15 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
       const long long i = base + r * 256 + threadIdx.x;
       if (i >= n) break;
       float p = P[i], m = M[i], v = V[i];
+      const float p0 = p;
       adam_one(p, Gr[i], m, v, K, ss, bs);
+      moved |= __float_as_uint(p) != __float_as_uint(p0);
       P[i] = p; M[i] = m; V[i] = v;
       if (zero_grad) Gr[i] = 0.0f;
     }
   }
+  // frozen geometry: no wave of a watched group sees a change, no atomic is issued
+  if (watched && G.changed && __any(moved) && (threadIdx.x & 63) == 0) atomicOr(G.changed, 1u);
 }
 
 // ---- parameter activations (scene/gaussian_model.py:48-58, 178-263) ------------------------------------------
@@ -798,6 +810,11 @@ void gigs_adam_scalars(double lr, int step, double beta1, double beta2, float* o
 
 int gigs_adam_step_dyn(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
                        const float* dyn, void* stream) {
+  return gigs_adam_step_watch(n_groups, groups, beta1, beta2, eps, zero_grad, dyn, nullptr, nullptr, stream);
+}
+
+int gigs_adam_step_watch(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
+                         const float* dyn, const unsigned char* watch, unsigned* changed, void* stream) {
   if (n_groups < 0 || (n_groups > 0 && !groups)) return gigs_internal_fail(GIGS_ERR_INVALID, "adam_step: bad argument");
   hipStream_t s = (hipStream_t)stream;
   void* tok; gigs_internal_stage_begin(26, stream, &tok);
@@ -823,6 +840,7 @@ int gigs_adam_step_dyn(int n_groups, const gigs_adam_group* groups, double beta1
       if (k == 0) G.dyn_base = done;
       G.param[k] = g.param; G.grad[k] = g.grad; G.exp_avg[k] = g.exp_avg; G.exp_avg_sq[k] = g.exp_avg_sq;
       G.n[k] = g.n;
+      if (watch && changed && watch[done]) G.watch_mask |= 1u << k;
       G.first_chunk[k] = chunks;
       chunks += (unsigned)c;
       // torch/optim/adam.py (_single_tensor_adam): python-float bias corrections, then fp32 tensor ops
@@ -836,6 +854,7 @@ int gigs_adam_step_dyn(int n_groups, const gigs_adam_group* groups, double beta1
     }
     G.count = k;
     G.dyn = dyn;
+    G.changed = changed;
     G.first_chunk[k] = chunks;
     if (k == 0 || chunks == 0) {
       if (k == 0 && done < n_groups) {  // a single group too large for one grid

@@ -129,6 +129,63 @@ class after_blend:
 
 _grad_sink = None
 _async = None
+_view = None  # (ViewSlot, "record" | "replay") while a frozen-geometry view cache is active
+
+
+class ViewSlot:
+    """Where a view's geometry-dependent, material-independent state lives while a step runs (gigs-hip extension, off by
+    default): the binning and image chunks of the rasterizer's forward (ranges, tile order, sorted point list) and the
+    operator's occlusion plane, at FIXED addresses, so that a hipGraph can be captured once to write them ("record") and
+    once to read them ("replay").  `export()` / `load()` move the parts that matter (point_list, ranges, tile_order,
+    occlusion: ~18 MB at 800 x 800 with 1.9 M instances) to and from a per-view entry -- pipeline.GeometryCache."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.binning, self.img = _Scratch(self.device), _Scratch(self.device)
+        self.occlusion = None
+        self.extra = {}   # further per-view planes a caller caches under the same protocol (SSR's hit list)
+        self.meta = None  # (P, W, H, capacity) of the forward that sized the chunks
+
+    def _parts(self):
+        P, W, H, cap = self.meta
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        b, i = self.binning.t, self.img.t
+        ob = int(_lib.gigs_binning_offset(cap, 3))
+        orng, oord = int(_lib.gigs_image_offset(W, H, 2)), int(_lib.gigs_image_offset(W, H, 3))
+        parts = {"point_list": b[ob:ob + 4 * cap], "ranges": i[orng:orng + 8 * T], "tile_order": i[oord:oord + 4 * T]}
+        if self.occlusion is not None:
+            parts["occlusion"] = self.occlusion
+        parts.update(self.extra)
+        return parts
+
+    def export(self) -> dict:
+        return {k: v.clone() for k, v in self._parts().items()}
+
+    def load(self, entry: dict) -> None:
+        for k, v in self._parts().items():
+            v.copy_(entry[k], non_blocking=True)
+
+
+class view_cache:
+    """`with view_cache(slot, "record"):` -- the rasterizer's forward bins into the slot's chunks and the operator's SSAO
+    writes the slot's occlusion plane; `with view_cache(slot, "replay"):` -- the forward REUSES the slot's tile lists
+    (gigs_ctx_set_reuse_binning: preprocess + blend only) and SSAO returns the slot's plane without marching.  Valid only
+    while positions, covariances, opacities and normals are what they were at the recording -- the caller's knowledge."""
+
+    def __init__(self, slot: ViewSlot, mode: str):
+        if mode not in ("record", "replay"):
+            raise ValueError("view_cache: mode must be 'record' or 'replay'")
+        self.pair = (slot, mode)
+
+    def __enter__(self):
+        global _view
+        self._prev, _view = _view, self.pair
+        return self
+
+    def __exit__(self, *exc):
+        global _view
+        _view = self._prev
+        return False
 
 
 class BinningOverflow(RuntimeError):
@@ -277,6 +334,16 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
     out_pos, out_albedo = slab[9:12], slab[12:15]
     out_opacity, out_depth, out_roughness, out_metallic = slab[15:16], slab[16:17], slab[17:18], slab[18:19]
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+    ctx_ptr = gigs_lib.ctx_ptr()
+    if _view is not None and P != 0:
+        # frozen-geometry view cache: bin into (record) / blend from (replay) the slot's fixed chunks
+        slot, mode = _view
+        if _async is None:
+            raise RuntimeError("view_cache needs asynchronous binning (AsyncBinning): the slot's chunks have its capacity")
+        binning, img = slot.binning, slot.img
+        slot.meta = (P, W, H, _async.capacity)
+        if mode == "replay":
+            ctx_ptr = gigs_lib.current().derive(reuse_binning=True).ptr
     rendered = 0
     if P != 0:
         M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
@@ -289,7 +356,7 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
 
         with torch.cuda.device(dev):
             rendered = _lib.gigs_forward(
-                gigs_lib.ctx_ptr(), geom.cb, None, binning.cb, None, img.cb, None, P, int(sh_degree), M, p(bg, "bg"), W, H,
+                ctx_ptr, geom.cb, None, binning.cb, None, img.cb, None, P, int(sh_degree), M, p(bg, "bg"), W, H,
                 p(means3D, "means3D"), p(sh, "sh"), p(colors_precomp, "colors_precomp"),
                 p(opacities, "opacities"), p(normal, "normal"), p(albedo, "albedo"),
                 p(roughness, "roughness"), p(metallic, "metallic"), p(scales, "scales"),
@@ -402,7 +469,17 @@ def _depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depthMap):
 def _SSAO(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, out_normal, out_pos):
     _need_gpu(out_normal, "out_normal")
     dev = out_normal.device
-    occlusion = _new("occlusion", (1, height, width), dev)  # every pixel is written
+    if _view is not None:
+        slot, mode = _view
+        if slot.occlusion is None or tuple(slot.occlusion.shape) != (1, height, width):
+            if mode == "replay":
+                raise RuntimeError("view_cache('replay'): the slot holds no occlusion plane of this size")
+            slot.occlusion = torch.empty((1, height, width), dtype=torch.float32, device=dev)
+        if mode == "replay":
+            return slot.occlusion  # what the march wrote when this view was recorded: geometry has not changed since
+        occlusion = slot.occlusion
+    else:
+        occlusion = _new("occlusion", (1, height, width), dev)  # every pixel is written
     n, k0 = _fptr(out_normal, "out_normal")
     ps, k1 = _fptr(out_pos, "out_pos")
     scratch = _gi_scratch(int(width), int(height), dev)

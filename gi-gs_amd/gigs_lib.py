@@ -109,6 +109,8 @@ SIGNATURES = {
     "gigs_adam_step": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, C.c_void_p]),
     "gigs_adam_step_dyn": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, _f, C.c_void_p]),
     "gigs_adam_scalars": (None, [C.c_double, _i, C.c_double, C.c_double, C.POINTER(C.c_float)]),
+    "gigs_adam_step_watch": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, _f, C.c_char_p, _f, C.c_void_p]),
+    "gigs_ctx_set_reuse_binning": (_i, [C.c_void_p, _i]),
     "gigs_activate_fwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gigs_activate_bwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gigs_densify_stats": (_i, [_i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
@@ -243,10 +245,11 @@ class Context:
     _cache: dict = {}
     _lock = threading.Lock()
 
-    def __init__(self, opts: tuple, async_capacity: int, async_counters, blend_event):
+    def __init__(self, opts: tuple, async_capacity: int, async_counters, blend_event, reuse_binning: bool = False):
         l = lib()
         self.opts, self.async_capacity = tuple(opts), int(async_capacity)
         self.async_counters, self.blend_event = async_counters, blend_event  # kept alive with the context
+        self.reuse_binning = bool(reuse_binning)
         self.ptr = l.gigs_ctx_create()
         if not self.ptr:
             raise GigsError("gigs_ctx_create failed")
@@ -261,6 +264,8 @@ class Context:
                   "gigs_ctx_set_async_binning")
         if blend_event is not None:
             check(l.gigs_ctx_set_blend_begin_event(self.ptr, blend_event.cuda_event), "gigs_ctx_set_blend_begin_event")
+        if self.reuse_binning:
+            check(l.gigs_ctx_set_reuse_binning(self.ptr, 1), "gigs_ctx_set_reuse_binning")
 
     def __del__(self):
         try:
@@ -271,20 +276,22 @@ class Context:
             pass
 
     @classmethod
-    def get(cls, opts: tuple, async_capacity: int = 0, async_counters=None, blend_event=None) -> "Context":
+    def get(cls, opts: tuple, async_capacity: int = 0, async_counters=None, blend_event=None, reuse_binning=False) -> "Context":
         key = (tuple(int(v) for v in opts), int(async_capacity),
-               None if async_counters is None else async_counters.data_ptr(), None if blend_event is None else id(blend_event))
+               None if async_counters is None else async_counters.data_ptr(), None if blend_event is None else id(blend_event),
+               bool(reuse_binning))
         with cls._lock:
             c = cls._cache.get(key)
             if c is None:
                 if len(cls._cache) > 512:  # contexts of long-gone buffers: start over (live ones are re-created on demand)
                     cls._cache.clear()
-                c = cls._cache[key] = cls(key[0], async_capacity, async_counters, blend_event)
+                c = cls._cache[key] = cls(key[0], async_capacity, async_counters, blend_event, reuse_binning)
         return c
 
-    def derive(self, async_binning=None, blend_event="keep", **options) -> "Context":
+    def derive(self, async_binning=None, blend_event="keep", reuse_binning=None, **options) -> "Context":
         """The context with some settings changed: option names of gigs_options (gi_march also by name), `async_binning` =
-        (capacity, counters tensor) or False to switch it off, `blend_event` = a torch.cuda.Event or None."""
+        (capacity, counters tensor) or False to switch it off, `blend_event` = a torch.cuda.Event or None, `reuse_binning`
+        = True / False (gigs_ctx_set_reuse_binning)."""
         opts = list(self.opts)
         for k, v in options.items():
             if k == "gi_march" and isinstance(v, str):
@@ -296,7 +303,7 @@ class Context:
         elif async_binning is not None:
             cap, cnt = async_binning
         ev = self.blend_event if isinstance(blend_event, str) else blend_event
-        return Context.get(tuple(opts), cap, cnt, ev)
+        return Context.get(tuple(opts), cap, cnt, ev, self.reuse_binning if reuse_binning is None else reuse_binning)
 
     def option(self, name: str) -> int:
         return self.opts[OPTION_NAMES.index(name)]

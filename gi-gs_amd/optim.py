@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+from typing import Optional
+
 import torch
 
 import gigs_lib
@@ -184,20 +186,28 @@ class CapturedAdam:
             out.append((p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
         return tuple(out)
 
-    def launch(self) -> None:
+    def launch(self, watch=None, changed: Optional[torch.Tensor] = None) -> None:
+        """`watch` (group names) + `changed` (device int32[1]): gigs_adam_step_watch ORs 1 into `changed` when the update
+        moves a bit of a watched group (pipeline.GeometryCache: the geometry groups of a stage-2 iteration)."""
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             row = 0
             for (b1, b2, eps), idx in self.buckets.items():
-                groups = []
+                groups, flags = [], []
                 for i in idx:
-                    o, _, p, gr = self.entries[i]
+                    o, grp, p, gr = self.entries[i]
                     st = o.state[p]
                     groups.append(gigs_lib.AdamGroup(p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(),
                                                      st["exp_avg_sq"].data_ptr(), p.numel(), 0.0, 0))
+                    flags.append(1 if (watch is not None and grp.get("name") in watch) else 0)
                 arr = (gigs_lib.AdamGroup * len(groups))(*groups)
-                gigs_lib.check(_lib.gigs_adam_step_dyn(len(groups), C.cast(arr, C.c_void_p), b1, b2, eps, 0,
-                                                       self.table[row:].data_ptr(), stream), "adam_step_dyn")
+                if changed is not None and any(flags):
+                    gigs_lib.check(_lib.gigs_adam_step_watch(len(groups), C.cast(arr, C.c_void_p), b1, b2, eps, 0,
+                                                             self.table[row:].data_ptr(), bytes(flags), changed.data_ptr(),
+                                                             stream), "adam_step_watch")
+                else:
+                    gigs_lib.check(_lib.gigs_adam_step_dyn(len(groups), C.cast(arr, C.c_void_p), b1, b2, eps, 0,
+                                                           self.table[row:].data_ptr(), stream), "adam_step_dyn")
                 row += len(idx)
 
     def advance(self) -> None:

@@ -364,6 +364,80 @@ def _graphed_inference(mod, sample):
     return run
 
 
+class GeometryCache:
+    """Per-view reuse of what frozen geometry makes constant in stage-2 training (secondary metric only; the headline step
+    always runs everything).  A stage-2 iteration of train.py (:330-420) sends gradients to albedo / roughness / metallic
+    and the light only, so once Adam's residual momentum has died out positions, covariances, opacities and normals stop
+    changing bit for bit -- and with them, per view, the tile lists (`ranges`, `point_list`: the whole binning), the
+    operator's occlusion plane (the SSAO march) and the indirect-light hit list.  288 GB of HBM hold them for a whole
+    training set (~18 MB per 800 x 800 view without the hit list).
+
+    Protocol.  The optimizer step reports whether it moved a bit of a geometry group (gigs_adam_step_watch -> `flag_dev`,
+    copied to pinned memory by a node of the update graph).  A view is RECORDED by a complete step (dgr.view_cache: the
+    forward bins into the slot's chunks, SSAO writes the slot's plane; `store` copies the parts to the view's entry) and
+    REPLAYED from its entry afterwards (`load` -> slot; preprocess + blend only, no binning, no SSAO march).  The host
+    learns about update k only while step k + 1 runs, so a replay is optimistic: if the flag read after the forward says
+    the previous update moved geometry, every entry is dropped and the step is repeated as a recording before anything of
+    it is consumed (the update graph has not been replayed yet) -- the same repeat protocol as a binning overflow.
+    Entries are also dropped when the parameter tensors are replaced (densification) or modified behind the library's
+    back (tensor version counters)."""
+
+    WATCH = ("xyz", "scaling", "rotation", "opacity", "normal")              # raw (pre-activation) group names
+    WATCH_ACTIVATED = ("means3D", "scales", "rotations", "opacities", "normal")  # the same for post-activation dictionaries
+
+    def __init__(self, device):
+        from diff_gaussian_rasterization import ViewSlot
+        self.device = torch.device(device)
+        self.slot = ViewSlot(self.device)
+        self.entries: Dict = {}
+        self.holds = None          # view key whose state the slot currently holds
+        self.param_key = None
+        self.capacity = 0
+        self.flag_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.stats = dict(recorded=0, replayed=0, repeated=0, invalidated=0)
+        self.recorded_R: Dict = {}
+
+    @staticmethod
+    def view_key(cam: Dict):
+        for k in ("uid", "index"):
+            if k in cam:
+                return (k, int(cam[k]), int(cam["image_width"]), int(cam["image_height"]))
+        vm = cam["viewmatrix"]
+        return ("ptr", vm.data_ptr(), vm._version, int(cam["image_width"]), int(cam["image_height"]))
+
+    def _geometry_key(self, g: Dict[str, torch.Tensor]):
+        names = self.WATCH if "xyz" in g else self.WATCH_ACTIVATED
+        return tuple((n, g[n].data_ptr(), tuple(g[n].shape), g[n]._version) for n in names if n in g)
+
+    def invalidate(self) -> None:
+        if self.entries:
+            self.stats["invalidated"] += 1
+        self.entries.clear()
+        self.holds = None
+
+    def mode(self, vkey, g) -> str:
+        k = self._geometry_key(g)
+        if k != self.param_key:   # new tensors (densification) or an in-place edit outside the captured update
+            self.invalidate()
+            self.param_key = k
+        return "replay" if vkey in self.entries else "record"
+
+    def load(self, vkey) -> None:
+        if self.holds != vkey:
+            self.slot.load(self.entries[vkey])
+            self.holds = vkey
+
+    def store(self, vkey) -> None:
+        self.entries[vkey] = self.slot.export()
+        self.holds = vkey
+        self.stats["recorded"] += 1
+
+    def geometry_moved(self) -> bool:
+        """What the LAST completed update reported (valid once a later forward of the same stream has finished)."""
+        return int(self.flag_host[0]) != 0
+
+
 class WholeStepGraph:
     """One stage-2 iteration -- rasterizer, SSAO, light filter, shade, SSR, loss, and the whole backward -- captured by
     hand into TWO hipGraphs (forward, backward) that share one memory pool:
@@ -391,7 +465,9 @@ class WholeStepGraph:
     host waits for the forward only.  On overflow the capacity grows, both graphs are re-captured and the step is
     repeated; its gradients are never handed out."""
 
-    def __init__(self, owner: "Stage2Step", cam: Dict, g: Dict[str, torch.Tensor]):
+    def __init__(self, owner: "Stage2Step", cam: Dict, g: Dict[str, torch.Tensor], cache: Optional["GeometryCache"] = None,
+                 mode: Optional[str] = None):
+        self.cache, self.mode = cache, mode  # frozen-geometry variant: "record" / "replay" under dgr.view_cache(cache.slot, mode)
         # a weak reference: the stepper owns its WholeStepGraphs, not the other way round -- no reference cycle, so the
         # graph execs die where the code says (close(), or the owner's last reference going away), never "whenever the
         # cyclic collector happens to run" (the round-3 host segfault in hip::Graph::UpdateStreams: DESIGN.md section 5)
@@ -448,10 +524,14 @@ class WholeStepGraph:
 
     def _slab_sinks(self):
         """The owner's gradient slab (train_iteration: data_parallel) as gradient sinks of the captured step: the raw
-        gradients are written into the slab's views by the activations' backward, xyz's by the rasterizer's."""
+        gradients are written into the slab's views by the activations' backward, xyz's by the rasterizer's.  Also enters
+        the frozen-geometry view cache of this variant."""
         import contextlib
         slabv = getattr(self.owner, "grad_slab", None)
         stack = contextlib.ExitStack()
+        if self.cache is not None:
+            from diff_gaussian_rasterization import view_cache
+            stack.enter_context(view_cache(self.cache.slot, self.mode))
         if slabv:
             import activations
             import diff_gaussian_rasterization as dgr
@@ -488,12 +568,18 @@ class WholeStepGraph:
         prep = o.prepare if o.prepare is not None else (lambda raw: raw)
         with torch.no_grad():
             ga = prep(g)  # the rasterizer's inputs (for the probe and the shapes); the capture re-derives them
+        if self.cache is not None and self.cache.capacity > self.capacity:
+            self.capacity = self.cache.capacity  # the record and the replay variant share the slot's chunks
         if self.capacity <= 0:
             probe = GraphedRaster(cam, ga, o.gi, o.sh_degree)._probe(cam, ga, bg)
             tiles = ((H + 15) // 16) * ((W + 15) // 16)
             if _declined_as_dense(probe, tiles):
                 raise DenseScene(f"{probe} instances over {tiles} tiles")
             self.capacity = max(65536, -(-2 * probe // 65536) * 65536)
+        if self.cache is not None:
+            if self.cache.capacity != self.capacity:
+                self.cache.invalidate()  # entries are carved for the old capacity
+            self.cache.capacity = self.capacity
         self.bin = AsyncBinning(self.capacity, self.dev)
         self.inner = o._make_inner()  # the eager step that is captured: returns its attached loss instead of differentiating
         self.inner._defer_backward = True
@@ -577,7 +663,13 @@ class WholeStepGraph:
                 adam = CapturedAdam(o.optimizers, params, list(grads[:-1]))
                 go = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(go, pool=gf.pool(), stream=cap, capture_error_mode="thread_local"):
-                    adam.launch()
+                    if self.cache is not None:
+                        # the update reports whether it moved a geometry bit; the word travels to pinned memory and is cleared
+                        adam.launch(watch=GeometryCache.WATCH, changed=self.cache.flag_dev)
+                        self.cache.flag_host.copy_(self.cache.flag_dev, non_blocking=True)
+                        self.cache.flag_dev.zero_()
+                    else:
+                        adam.launch()
                     if o.post_update is not None:
                         with torch.no_grad():
                             o.post_update()
@@ -611,10 +703,17 @@ class WholeStepGraph:
             static.copy_(src, non_blocking=True)
             self._src[name] = (src, src._version)
 
-    def __call__(self, cam, g, gt_image, view_dirs):
+    def __call__(self, cam, g, gt_image, view_dirs, vkey=None):
+        """Returns None (frozen-geometry variants only) when the step must be repeated as a recording: the previous update
+        moved geometry, which the host can only know once this step's forward has run."""
         if (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"])) != self.cfg:
             raise ValueError("WholeStepGraph: image size / field of view differ from the captured ones")
+        cache = self.cache
         for _ in range(4):
+            if cache is not None and self.mode == "replay":
+                if cache.capacity != self.capacity or vkey not in cache.entries:
+                    return None  # the recording variant re-sized the chunks / dropped the entry: record again
+                cache.load(vkey)  # the view's tile lists and occlusion plane into the slot (a no-op for the same view)
             if self.gf is None or self.key != self._key(g):
                 self._capture(cam, g, gt_image, view_dirs)
             self._fill("camera", self.s_pack, self._pack(cam))
@@ -633,8 +732,27 @@ class WholeStepGraph:
             r, over = int(self.bin.host[0]), int(self.bin.host[1])
             if over:
                 self.capacity = -(-int(1.5 * over) // 65536) * 65536
+                if cache is not None:
+                    cache.invalidate()
+                    cache.capacity = self.capacity
                 self._drop_graphs()  # waits for the backward replay that is still running, then releases the execs
                 continue
+            if cache is not None:
+                # this forward has finished, so the previous update has too: did it move geometry?
+                moved = cache.geometry_moved()
+                if moved:
+                    cache.flag_host.zero_()
+                    cache.invalidate()
+                    if self.mode == "replay":
+                        cache.stats["repeated"] += 1
+                        return None  # the replayed lists were stale: nothing of this step has been consumed, repeat it
+                if self.mode == "record":
+                    if not moved:  # while geometry still drifts every entry would be dropped at the next step anyway
+                        cache.store(vkey)
+                        cache.recorded_R[vkey] = r
+                else:
+                    cache.stats["replayed"] += 1
+                    r = cache.recorded_R.get(vkey, r)
             params = self._params(g)
             if self.go is not None:
                 # complete iteration: all-reduce (multi-GPU) -> Adam + clamp from the third graph; the gradients are
@@ -728,7 +846,8 @@ class Stage2Step:
 
     def __init__(self, light, brdf_lut, gi: Dict, sh_degree: int, metallic: bool = True, indirect: bool = True,
                  gamma: bool = False, tone: bool = False, graphs: bool = False, fused: bool = False,
-                 prepare=None, regularizer=None, optimizers=None, post_update=None, before_update=None):
+                 prepare=None, regularizer=None, optimizers=None, post_update=None, before_update=None,
+                 geometry_cache: bool = False):
         """The last five arguments turn the step into a COMPLETE training iteration (train_iteration.Stage2Trainer):
         `prepare(raw) -> g` maps the optimizer's tensors to the rasterizer's inputs (the GaussianModel getters;
         `__call__` then takes the raw dictionary), `regularizer(maps) -> scalar` adds the BRDF / envmap terms of
@@ -750,6 +869,8 @@ class Stage2Step:
         self._captured = False
         self._defer_backward = False  # WholeStepGraph's inner step: return the attached loss, the caller differentiates
         self.whole, self._wholes = None, {}
+        # frozen-geometry reuse (GeometryCache; graph path only, off by default: the headline step never uses it)
+        self.geometry_cache, self.geom_cache = bool(geometry_cache), None
 
     def _capture(self, front_args, loss_args):
         def clone(args):
@@ -768,11 +889,15 @@ class Stage2Step:
             try:
                 # one capture per (image size, field of view): datasets with per-camera intrinsics keep a few of them
                 cfg = (int(cam["image_height"]), int(cam["image_width"]), float(cam["tanfovx"]), float(cam["tanfovy"]))
-                if self.whole is None or self.whole.cfg != cfg:
+                if self.geometry_cache:
+                    out = self._cached_geometry_step(cfg, cam, raw, gt_image, view_dirs)
+                    if out is not None:
+                        return out
+                elif self.whole is None or self.whole.cfg != cfg:
                     self.whole = self._wholes.get(cfg)
                     if self.whole is None and len(self._wholes) < 4:
                         self.whole = self._wholes[cfg] = WholeStepGraph(self, cam, g)
-                if self.whole is not None:
+                if self.whole is not None and not self.geometry_cache:
                     return self.whole(cam, raw, gt_image, view_dirs)
                 # more than four distinct camera models: the fifth onwards takes the piecewise path below
             except DenseScene:
@@ -1103,6 +1228,33 @@ def _enter(self):
 def _exit(self, *exc):
     self.close()
     return False
+
+def _cached_geometry_step(self, cfg, cam, raw, gt_image, view_dirs):
+    """One step through the frozen-geometry variants of the whole-step graphs: replayed from the view's entry when there
+    is one, recorded otherwise; a replay that turns out stale (the previous update moved geometry) is repeated as a
+    recording.  Returns None when this camera model has no slot left (more than four models): the caller's other paths."""
+    if self.geom_cache is None:
+        self.geom_cache = GeometryCache(next(iter(raw.values())).device)
+    cache = self.geom_cache
+    vkey = cache.view_key(cam)
+    mode = cache.mode(vkey, raw)
+    for _ in range(3):
+        key = (cfg, mode)
+        whole = self._wholes.get(key)
+        if whole is None:
+            if len(self._wholes) >= 8:
+                return None
+            whole = self._wholes[key] = WholeStepGraph(self, cam, raw, cache=cache, mode=mode)
+        self.whole = whole
+        out = whole(cam, raw, gt_image, view_dirs, vkey=vkey)
+        if out is not None:
+            return out
+        mode = "record"
+    raise RuntimeError("Stage2Step: the frozen-geometry step kept being invalidated")
+
+
+Stage2Step._cached_geometry_step = _cached_geometry_step
+
 
 def _make_inner(self):
     return Stage2Step(self.light, self.brdf_lut, self.gi, self.sh_degree, graphs=False, fused=True, regularizer=self.regularizer,

@@ -443,6 +443,13 @@ int gigs_adam_step(int n_groups, const gigs_adam_group* groups, double beta1, do
 int gigs_adam_step_dyn(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
                        const float* dyn, void* stream);
 void gigs_adam_scalars(double lr, int step, double beta1, double beta2, float* out2);
+/* gigs_adam_step_dyn that also reports whether the update CHANGED a bit of any watched group: `watch` is a HOST array of
+ * n_groups flags (non-zero = watched), `changed` a DEVICE word that is OR-ed with 1 when a parameter of a watched group
+ * differs from its value before the step (it is never cleared here).  A stage-2 trainer watches the geometry groups: as
+ * long as the word stays 0, per-view tile lists, occlusion planes and indirect-light hit lists remain valid
+ * (gigs_ctx_set_reuse_binning). */
+int gigs_adam_step_watch(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
+                         const float* dyn, const unsigned char* watch, unsigned* changed, void* stream);
 
 /* The parameter getters of GaussianModel (scene/gaussian_model.py:48-58, 178-263) as one pass each way:
  * shs = cat(f_dc [P,1,3], f_rest [P,K-1,3]) -> [P,K,3]; opacities / albedo / roughness / metallic = sigmoid(raw);
@@ -497,7 +504,7 @@ int gigs_dist2(int P, const float* points, float* mean_dists, void* scratch, siz
  * 7 tiles_touched u32[P], 8 point_offsets u32[P];  binning 0 keys_unsorted u64[R],
  * 1 values_unsorted u32[R], 2 keys u64[R], 3 point_list u32[R], 4 hit_mask u8[4R] (byte w of instance i: quadrant
  * w of its tile blended it);  image 0 final_T f32[N],
- * 1 n_contrib u32[N], 2 ranges u32[2T]. */
+ * 1 n_contrib u32[N], 2 ranges u32[2T], 3 tile_order u32[T] (the blend kernels' workgroup -> tile map, longest lists first). */
 long long gigs_geom_offset(int P, int which);
 long long gigs_binning_offset(int num_rendered, int which);
 long long gigs_image_offset(int width, int height, int which);
@@ -528,6 +535,16 @@ int gigs_lite_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_us
  * 671-693): grad_albedo [3,H,W] = grad_color * abd; roughness / metallic / F0 receive nothing.  (The reference also exports
  * a CUDA SSR_BACKWARD whose only call is commented out; this entry is the live arithmetic, not that kernel.) */
 int gigs_ssr_backward(int width, int height, const float* grad_color, const float* abd, float* grad_albedo, void* stream);
+
+/* Frozen geometry (gigs-hip extension).  A stage-2 iteration of train.py updates materials and light only
+ * (train.py:330-420): positions, covariances and opacities -- hence every tile list -- are the same from one visit of a
+ * view to the next.  After gigs_ctx_set_reuse_binning(ctx, 1) a gigs_forward(ctx, ...) runs the preprocess (the per-Gaussian
+ * records carry the material attributes) and the blend, and SKIPS count / prefix / scatter / sort: the binning and image
+ * chunks its callbacks return must still hold what an earlier forward of the SAME view and geometry left there (ranges,
+ * tile order, sorted point list; asynchronous layout: needs gigs_ctx_set_async_binning with the same capacity).  Outputs
+ * are then those of a complete forward bit for bit.  Whether the geometry is unchanged is the caller's knowledge
+ * (gigs_adam_step_watch reports it from the optimizer step). */
+int gigs_ctx_set_reuse_binning(gigs_ctx* ctx, int on);
 
 /* Optional scheduling hook: a hipEvent_t (caller-owned, NULL = none) that gigs_forward records on its stream right
  * before it launches the alpha-blend kernel, so that a caller can start independent work on another stream next to

@@ -379,3 +379,88 @@ def test_trainer_with_the_gradient_slab_follows_the_plain_trajectory(stage):
         assert (plain[1] - slabbed[1]).abs().max().item() <= 2e-3
         for k in ("xyz", "scaling", "rotation", "opacity", "f_dc", "normal"):  # exact zeros either way: stage 2 reaches none
             assert torch.equal(plain[0][k], slabbed[0][k]), k
+
+
+def test_frozen_geometry_cache_replays_the_tile_lists_and_follows_the_plain_trainer():
+    """pipeline.GeometryCache (a secondary figure): in stage 2 the loss reaches materials and light only,
+    so once Adam's residual momentum has died out the geometry stops changing bit for bit and, per view, the tile lists and
+    the occlusion plane are reused (gigs_ctx_set_reuse_binning; no binning, no SSAO march).  Here the optimizer starts WITH
+    momentum on positions, scales and opacities (as after stage 1): geometry drifts for a few dozen iterations -- every one
+    of them must be recorded, none replayed from a stale entry -- and then freezes.  The cached trainer takes the updates of
+    the plain one (losses and parameters to the rounding of the float-atomic gradient sums), geometry bit for bit; a replayed
+    forward equals the recorded one bit for bit; a learning-rate kick that moves geometry again drops every entry."""
+    import pbr
+    import pipeline
+    import scenes
+    import train_iteration as ti
+    dev = torch.device("cuda:0")
+    H = W = 96
+    sc = scenes.surface_scene(P=5000, sh_degree=1, seed=8, scale_mu=0.035)
+    n_views = 4
+    cams = [scenes.orbit_camera(i, n_views, W, H, radius=3.5) for i in range(n_views)]
+    cams = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    gi = scenes.GI_DEFAULTS
+    lut = pbr.get_brdf_lut().to(dev)
+    rays = pipeline.canonical_rays(cams[0], dev)
+    vds = [pipeline.view_dirs_for(c, rays, dev) for c in cams]
+    torch.manual_seed(1)
+    gts = [torch.rand(3, H, W, device=dev) * 0.6 for _ in cams]
+
+    def make(cached):
+        torch.manual_seed(3)
+        raw = ti.raw_from_scene(sc, dev)
+        light = pbr.CubemapLight(base_res=64, device=dev)
+        tr = ti.Stage2Trainer(raw, light, lut, gi, 1, graphs=True, geometry_cache=cached)
+        gen = torch.Generator(device=dev).manual_seed(5)
+        for name, scale in (("xyz", 1e-3), ("scaling", 1e-3), ("opacity", 1e-2)):  # residual momentum of an earlier stage
+            p = raw[name]
+            tr.optimizer.state[p] = {"step": torch.tensor(200.0), "exp_avg": torch.randn(p.shape, device=dev, generator=gen) * scale,
+                                     "exp_avg_sq": torch.full_like(p, scale * scale)}
+        return tr, raw, light
+
+    def run(tr, n, first=0):
+        return [float(tr.iteration(cams[i % n_views], gts[i % n_views], vds[i % n_views])["loss"]) for i in range(first, first + n)]
+
+    plain, raw_p, light_p = make(False)
+    cached, raw_c, light_c = make(True)
+    xyz0 = raw_c["xyz"].detach().clone()
+    lp, lc = run(plain, 300), run(cached, 300)
+    torch.cuda.synchronize()
+    cache = cached.stepper.geom_cache
+    st = dict(cache.stats)
+    print("geometry cache:", st)
+    assert not torch.equal(raw_c["xyz"].detach(), xyz0), "the test's momentum did not move the geometry at all"
+    assert st["replayed"] >= 150, st          # the frozen phase replays
+    assert st["recorded"] >= n_views and st["replayed"] < 300 - 20, st  # the drifting phase (>= 20 iterations) is never replayed
+    for a, b in zip(lp, lc):
+        assert abs(a - b) <= 5e-5 * max(1.0, abs(a)), (a, b)
+    for k in ("xyz", "scaling", "rotation", "opacity", "normal", "f_dc", "f_rest"):  # zero gradients: deterministic drift
+        assert torch.equal(raw_p[k].detach(), raw_c[k].detach()), k
+    for k in ("albedo", "roughness", "metallic"):
+        assert (raw_p[k] - raw_c[k]).abs().max().item() <= 5e-3, k
+    assert (light_p.base - light_c.base).abs().max().item() <= 5e-3
+    # a replayed forward equals a recorded one bit for bit (same parameters: learning rates zero, two visits of one view)
+    for g_ in cached.optimizer.param_groups + cached.light_optimizer.param_groups:
+        g_["lr"] = 0.0
+    before = dict(cache.stats)
+    a = cached.iteration(cams[1], gts[1], vds[1])
+    a = {k: a[k].detach().clone() for k in ("render_rgb", "render_direct", "IRR")} | {"loss": float(a["loss"])}
+    assert cache.stats["replayed"] == before["replayed"] + 1
+    cache.invalidate()
+    b = cached.iteration(cams[1], gts[1], vds[1])
+    assert cache.stats["recorded"] == before["recorded"] + 1
+    assert float(b["loss"]) == a["loss"]
+    for k in ("render_rgb", "render_direct", "IRR"):
+        assert torch.equal(a[k].view(torch.int32), b[k].detach().view(torch.int32)), k
+    # geometry moves again (a position learning rate and fresh momentum): the next replay is found stale and repeated
+    cached.iteration(cams[2], gts[2], vds[2])  # view 2 has an entry again
+    p = raw_c["xyz"]
+    cached.optimizer.state[p]["exp_avg"].normal_(0.0, 1e-3)
+    cached.set_lr("xyz", 1e-3)
+    r0 = cache.stats["repeated"]
+    cached.iteration(cams[3], gts[3], vds[3])   # this update moves xyz
+    cached.iteration(cams[2], gts[2], vds[2])   # optimistic replay of view 2 -> stale -> repeated as a recording
+    torch.cuda.synchronize()
+    assert cache.stats["repeated"] == r0 + 1 and cache.stats["invalidated"] >= 2, cache.stats
+    plain.close()
+    cached.close()
