@@ -692,6 +692,41 @@ int gigs_ssr_ex(gigs_ctx* ctx, int width, int height, float focal_x, float focal
   HIP_TRY(hipGetLastError());
   return 0;
 }
+int gigs_ssr_hits(gigs_ctx* ctx, int width, int height, float focal_x, float focal_y, float radius, float bias, float thick,
+                  float delta, int step, int start, const float* normal_view, const float* pos, const float* rgb,
+                  const float* albedo, const float* roughness, const float* metallic, const float* F0, float* color, float* abd,
+                  int mode, unsigned* counts, const unsigned* offsets, void* entries, unsigned capacity, void* scratch,
+                  void* stream) {
+  if (width <= 0 || height <= 0 || !normal_view || !pos || !rgb || !albedo || !metallic || !F0 || !color || !abd)
+    return fail(GIGS_ERR_INVALID, "bad argument");
+  if (width >= (1 << 15) || height >= (1 << 15)) return fail(GIGS_ERR_INVALID, "image side above 32767 pixels");
+  if ((mode != 1 && mode != 2) || (mode == 1 && !counts) || (mode == 2 && (!offsets || (!entries && capacity > 0))))
+    return fail(GIGS_ERR_INVALID, "ssr_hits: mode 1 needs counts, mode 2 offsets and entries");
+  StageScope sc(kSsr, (hipStream_t)stream);
+  const int rc = gigs::launch_ssr(ctx_of(ctx).opt, width, height, focal_x, focal_y, radius, bias, thick, delta, step, start,
+                                  normal_view, pos, rgb, albedo, roughness, metallic, F0, color, abd, scratch,
+                                  (hipStream_t)stream, mode, counts, offsets, entries, capacity);
+  if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
+  if (rc == -3) return fail(GIGS_ERR_INVALID, "ssr_hits: the hit list is recorded by the default march only (gi_march = proj, start < step)");
+  if (rc) return fail(GIGS_ERR_HIP, "ray table upload failed");
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int gigs_ssr_apply(int width, int height, float delta, const unsigned* offsets, const void* entries, const float* normal_view,
+                   const float* pos, const float* rgb, const float* albedo, const float* metallic, const float* F0,
+                   float* color, float* abd, void* stream) {
+  if (width <= 0 || height <= 0 || !offsets || !normal_view || !pos || !rgb || !albedo || !metallic || !F0 || !color || !abd)
+    return fail(GIGS_ERR_INVALID, "bad argument");
+  StageScope sc(kSsr, (hipStream_t)stream);
+  const int rc = gigs::launch_ssr_apply(width, height, delta, offsets, entries, normal_view, pos, rgb, albedo, metallic, F0, color,
+                                        abd, (hipStream_t)stream);
+  if (rc == -1) return fail(GIGS_ERR_INVALID, "delta=%g gives an unbounded or oversized ray set", (double)delta);
+  if (rc) return fail(GIGS_ERR_HIP, "ray table upload failed");
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int gigs_ssr(int width, int height, float focal_x, float focal_y, float radius, float bias,
              float thick, float delta, int step, int start, const float* normal_view,
              const float* pos, const float* rgb, const float* albedo, const float* roughness,

@@ -1036,13 +1036,61 @@ ssao_kernel(GiParams p, const float4* __restrict__ rays, float sum_w,
   }
 }
 
-template <bool kPow2, int kMode, bool kCert>
+// The hit list of the indirect-light march (frozen-geometry reuse, pipeline.GeometryCache): WHICH pixel every ray of
+// every pixel hits depends on normals and positions only -- not on the radiance that is gathered there -- so a view whose
+// geometry does not change marches once and afterwards only gathers (ssr_apply_kernel).  kHits = 1 counts the hits of each
+// (pixel, wave) -- the wave's rays are marched in a fixed order, so its hits form a sequence --, kHits = 2 writes them as
+// (hit pixel, ray index) at the positions an exclusive prefix of the counts assigns.  Both also produce the normal outputs.
+struct SsrHits {
+  unsigned* counts;         // kHits 1: [4 N], entry 4 * pixel + wave
+  const unsigned* offsets;  // kHits 2: [4 N + 1] exclusive prefix of the counts
+  uint2* entries;           // kHits 2: {hit pixel, ray index}
+  unsigned capacity;        // entries beyond it are dropped (the caller compares offsets[4 N] with it and repeats)
+};
+
+// the part of SSRCUDA behind the march (forward.cu:832-909; fresnelSchlick ssr.h:13-16): shared by the march and the gather
+__device__ __forceinline__ void ssr_finish(v3 diffuse, const Tbn& tbn, v3 pos, size_t pix_id, size_t HW, int nrays_total,
+                                           const float* __restrict__ albedo_map, const float* __restrict__ metallic_map,
+                                           const float* __restrict__ F0_map, float* __restrict__ color, float* __restrict__ abd) {
+  const v3 N = tbn.n;
+  const v3 alb = {albedo_map[pix_id], albedo_map[HW + pix_id], albedo_map[2 * HW + pix_id]};
+  const v3 F0 = {F0_map[pix_id], F0_map[HW + pix_id], F0_map[2 * HW + pix_id]};
+  const float metallic = metallic_map[pix_id];
+  const v3 V = normalize3({-pos.x, -pos.y, -pos.z});
+  // fresnelSchlick (ssr.h:13-16): pow evaluated in double
+  const float cosTheta = fmaxf(dot3(N, V), (float)0.0000001);
+  const float pw = (float)pow((double)fminf(fmaxf((float)(1.0 - (double)cosTheta), (float)0.000001), 1.0f), 5.0);
+  const v3 F = {F0.x + (1.0f - F0.x) * pw, F0.y + (1.0f - F0.y) * pw, F0.z + (1.0f - F0.z) * pw};
+  v3 kD = {(float)(1.0 - (double)F.x), (float)(1.0 - (double)F.y), (float)(1.0 - (double)F.z)};
+  kD.x = (float)((double)kD.x * (1.0 - (double)metallic));
+  kD.y = (float)((double)kD.y * (1.0 - (double)metallic));
+  kD.z = (float)((double)kD.z * (1.0 - (double)metallic));
+  const float nrSamples = (float)nrays_total;  // += 1 per ray in fp32 is exact below 2^24
+  v3 gd;
+  if (nrSamples > 0.0f) {
+    gd.x = (float)((double)(kPiF * diffuse.x) * (1.0 / (double)nrSamples) * (double)kD.x);
+    gd.y = (float)((double)(kPiF * diffuse.y) * (1.0 / (double)nrSamples) * (double)kD.y);
+    gd.z = (float)((double)(kPiF * diffuse.z) * (1.0 / (double)nrSamples) * (double)kD.z);
+    diffuse = {gd.x * alb.x, gd.y * alb.y, gd.z * alb.z};
+  } else {
+    diffuse = {(float)0.0000001, (float)0.0000001, (float)0.0000001};
+    gd = diffuse;
+  }
+  color[pix_id] = diffuse.x;
+  color[HW + pix_id] = diffuse.y;
+  color[2 * HW + pix_id] = diffuse.z;
+  abd[pix_id] = gd.x;
+  abd[HW + pix_id] = gd.y;
+  abd[2 * HW + pix_id] = gd.z;
+}
+
+template <bool kPow2, int kMode, bool kCert, int kHits = 0>
 __global__ void __launch_bounds__(256) GIGS_SSR_OCC
 ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict__ nrm,
            const float* __restrict__ pos_map, const float* __restrict__ rgb,
            const float* __restrict__ albedo_map, const float* __restrict__ metallic_map,
            const float* __restrict__ F0_map, float* __restrict__ color, float* __restrict__ abd,
-           const float2* __restrict__ cert_tab) {
+           const float2* __restrict__ cert_tab, SsrHits hits) {
   __shared__ float s_part[kGiWaves][3][64];
   extern __shared__ float2 s_cert[];
   constexpr int kCertOff = sizeof(float) * kGiWaves * 3 * 64;  // dynamic LDS follows the static array
@@ -1060,6 +1108,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
   const v3 pos = {pos_map[pix_id], pos_map[HW + pix_id], pos_map[2 * HW + pix_id]};
   const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
   v3 diffuse = {0, 0, 0};
+  unsigned hpos = 0;  // kHits: hits of this (pixel, wave) so far / the next entry's position
   if (inside && p.start < p.step && !tbn_never_hits(tbn)) {
     const __amdgpu_buffer_rsrc_t pos_z = z_plane_rsrc(pos_map + 2 * HW, HW);
     const float a = 1 + pos.z / 100;
@@ -1067,13 +1116,20 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
     const int chunk = (p.n_live + kGiWaves - 1) / kGiWaves;  // see ssao_kernel
     const int r0 = wave * chunk, r1 = min(p.n_live, r0 + chunk);
     const bool mag_ok = gi_mag_ok(pos, a, p.radius);
-    auto add_hit = [&](int q, float cos_t, float sin_t) {
+    if constexpr (kHits == 2) hpos = hits.offsets[4 * pix_id + wave];
+    auto add_hit = [&](int q, float cos_t, float sin_t, int ray) {
       if (q >= 0) {
         // rgb * cosf(theta) * sinf(theta), left to right (forward.cu:824-826)
         diffuse.x += rgb[q] * cos_t * sin_t;
         diffuse.y += rgb[HW + q] * cos_t * sin_t;
         diffuse.z += rgb[2 * HW + q] * cos_t * sin_t;
+        if constexpr (kHits == 1) hpos++;
+        if constexpr (kHits == 2) {
+          if (hpos < hits.capacity) hits.entries[hpos] = make_uint2((unsigned)q, (unsigned)ray);
+          hpos++;
+        }
       }
+      (void)ray;
     };
     if constexpr (kMode > 0) {
       if (mag_ok) {  // see ssao_kernel
@@ -1095,8 +1151,8 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
           else march2_fast<kMode, kGiGroup>(p, c, Bxy, Bz2, pos_z, hit);
           if (rb == r) hit[1] = -1;
           if (__any(hit[0] >= 0 || hit[1] >= 0)) {
-            add_hit(hit[0], ra0.w, rays[2 * r + 1].x);
-            add_hit(hit[1], ra1.w, rays[2 * rb + 1].x);
+            add_hit(hit[0], ra0.w, rays[2 * r + 1].x, r);
+            add_hit(hit[1], ra1.w, rays[2 * rb + 1].x, rb);
           }
         };
         for (int r = rs; r < re; r += rstep) pair(r, min(r + 1, re - 1));
@@ -1123,7 +1179,7 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
       for (int k = 0; k < kGiRays; k++) any_hit = any_hit || hit[k] >= 0;
       if (__any(any_hit)) {  // hits are rare: one wave-uniform test per ray pair
 #pragma unroll
-        for (int k = 0; k < kGiRays; k++) add_hit(hit[k], ct[k], st[k]);
+        for (int k = 0; k < kGiRays; k++) add_hit(hit[k], ct[k], st[k], r + k);
       }
     }
     auto single = [&](int q) {
@@ -1131,11 +1187,14 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
       const v3 sv = tbn_apply(tbn, ra.x, ra.y, ra.z);
       int hit;
       march<kPow2, kGiGroup, 1>(p, pos, a, &sv, cx, cy, pos_z, mag_ok, sv_min_bits, &hit);
-      add_hit(hit, ra.w, rays[2 * q + 1].x);
+      add_hit(hit, ra.w, rays[2 * q + 1].x, q);
     };
     for (; r < r1; r++) single(r);
     for (r = p.n_live + wave; r < p.nrays; r += kGiWaves) single(r);
     }
+  }
+  if constexpr (kHits == 1) {
+    if (inside) hits.counts[4 * pix_id + wave] = hpos;
   }
   s_part[wave][0][lane] = diffuse.x;
   s_part[wave][1][lane] = diffuse.y;
@@ -1145,37 +1204,39 @@ ssr_kernel(GiParams p, const float4* __restrict__ rays, const float* __restrict_
   diffuse.x = ((s_part[0][0][lane] + s_part[1][0][lane]) + s_part[2][0][lane]) + s_part[3][0][lane];
   diffuse.y = ((s_part[0][1][lane] + s_part[1][1][lane]) + s_part[2][1][lane]) + s_part[3][1][lane];
   diffuse.z = ((s_part[0][2][lane] + s_part[1][2][lane]) + s_part[2][2][lane]) + s_part[3][2][lane];
+  ssr_finish(diffuse, tbn, pos, pix_id, HW, p.nrays_total, albedo_map, metallic_map, F0_map, color, abd);
+}
 
-  const v3 N = tbn.n;
-  const v3 alb = {albedo_map[pix_id], albedo_map[HW + pix_id], albedo_map[2 * HW + pix_id]};
-  const v3 F0 = {F0_map[pix_id], F0_map[HW + pix_id], F0_map[2 * HW + pix_id]};
-  const float metallic = metallic_map[pix_id];
-  const v3 V = normalize3({-pos.x, -pos.y, -pos.z});
-  // fresnelSchlick (ssr.h:13-16): pow evaluated in double
-  const float cosTheta = fmaxf(dot3(N, V), (float)0.0000001);
-  const float pw = (float)pow((double)fminf(fmaxf((float)(1.0 - (double)cosTheta), (float)0.000001), 1.0f), 5.0);
-  const v3 F = {F0.x + (1.0f - F0.x) * pw, F0.y + (1.0f - F0.y) * pw, F0.z + (1.0f - F0.z) * pw};
-  v3 kD = {(float)(1.0 - (double)F.x), (float)(1.0 - (double)F.y), (float)(1.0 - (double)F.z)};
-  kD.x = (float)((double)kD.x * (1.0 - (double)metallic));
-  kD.y = (float)((double)kD.y * (1.0 - (double)metallic));
-  kD.z = (float)((double)kD.z * (1.0 - (double)metallic));
-  const float nrSamples = (float)p.nrays_total;  // += 1 per ray in fp32 is exact below 2^24
-  v3 gd;
-  if (nrSamples > 0.0f) {
-    gd.x = (float)((double)(kPiF * diffuse.x) * (1.0 / (double)nrSamples) * (double)kD.x);
-    gd.y = (float)((double)(kPiF * diffuse.y) * (1.0 / (double)nrSamples) * (double)kD.y);
-    gd.z = (float)((double)(kPiF * diffuse.z) * (1.0 / (double)nrSamples) * (double)kD.z);
-    diffuse = {gd.x * alb.x, gd.y * alb.y, gd.z * alb.z};
-  } else {
-    diffuse = {(float)0.0000001, (float)0.0000001, (float)0.0000001};
-    gd = diffuse;
+// The gather that replaces the march for a view whose hit list is known (see SsrHits): per pixel the four waves' hit
+// sequences are summed in their recorded order, the four partial sums combined as the march combines them, and the same
+// tail evaluated -- the march's outputs bit for bit for the geometry the list was recorded with.
+__global__ void __launch_bounds__(256)
+ssr_apply_kernel(int W, int H, int nrays_total, const float4* __restrict__ rays, const unsigned* __restrict__ offsets,
+                 const uint2* __restrict__ entries, const float* __restrict__ nrm, const float* __restrict__ pos_map,
+                 const float* __restrict__ rgb, const float* __restrict__ albedo_map, const float* __restrict__ metallic_map,
+                 const float* __restrict__ F0_map, float* __restrict__ color, float* __restrict__ abd) {
+  const size_t HW = (size_t)H * W;
+  const size_t pix_id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix_id >= HW) return;
+  const v3 pos = {pos_map[pix_id], pos_map[HW + pix_id], pos_map[2 * HW + pix_id]};
+  const Tbn tbn = make_tbn({nrm[pix_id], nrm[HW + pix_id], nrm[2 * HW + pix_id]});
+  v3 part[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    v3 d = {0, 0, 0};
+    const unsigned e0 = offsets[4 * pix_id + w], e1 = offsets[4 * pix_id + w + 1];
+    for (unsigned e = e0; e < e1; e++) {
+      const uint2 h = entries[e];
+      const float cos_t = rays[2 * h.y].w, sin_t = rays[2 * h.y + 1].x;
+      d.x += rgb[h.x] * cos_t * sin_t;
+      d.y += rgb[HW + h.x] * cos_t * sin_t;
+      d.z += rgb[2 * HW + h.x] * cos_t * sin_t;
+    }
+    part[w] = d;
   }
-  color[pix_id] = diffuse.x;
-  color[HW + pix_id] = diffuse.y;
-  color[2 * HW + pix_id] = diffuse.z;
-  abd[pix_id] = gd.x;
-  abd[HW + pix_id] = gd.y;
-  abd[2 * HW + pix_id] = gd.z;
+  const v3 diffuse = {((part[0].x + part[1].x) + part[2].x) + part[3].x, ((part[0].y + part[1].y) + part[2].y) + part[3].y,
+                      ((part[0].z + part[1].z) + part[2].z) + part[3].z};
+  ssr_finish(diffuse, tbn, pos, pix_id, HW, nrays_total, albedo_map, metallic_map, F0_map, color, abd);
 }
 
 static GiParams make_params(const Options& o, int W, int H, float fx, float fy, float radius, float bias, float thick,
@@ -1308,10 +1369,23 @@ int launch_ssao(const Options& o, int W, int H, float fx, float fy, float radius
   return 0;
 }
 
+int launch_ssr_apply(int W, int H, float delta, const unsigned* offsets, const void* entries, const float* normal,
+                     const float* pos, const float* rgb, const float* albedo, const float* metallic, const float* F0,
+                     float* color, float* abd, hipStream_t s) {
+  RayTable t;
+  const int rc = get_ray_table(delta, s, t);
+  if (rc) return rc;
+  const size_t HW = (size_t)W * H;
+  hipLaunchKernelGGL(ssr_apply_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, W, H, t.nrays, t.dev, offsets,
+                     (const uint2*)entries, normal, pos, rgb, albedo, metallic, F0, color, abd);
+  return 0;
+}
+
 int launch_ssr(const Options& o, int W, int H, float fx, float fy, float radius, float bias, float thick,
                float delta, int step, int start, const float* normal, const float* pos,
                const float* rgb, const float* albedo, const float* /*roughness*/,
-               const float* metallic, const float* F0, float* color, float* abd, void* scratch, hipStream_t s) {
+               const float* metallic, const float* F0, float* color, float* abd, void* scratch, hipStream_t s,
+               int hits_mode, unsigned* hit_counts, const unsigned* hit_offsets, void* hit_entries, unsigned hit_capacity) {
   RayTable t;
   const int rc = get_ray_table(delta, s, t);
   if (rc) return rc;
@@ -1322,9 +1396,22 @@ int launch_ssr(const Options& o, int W, int H, float fx, float fy, float radius,
   const int mode = gi_march_mode(o, step, start);
   const size_t cert = (start < step) ? prepare_cert(o, p, mode, pos, scratch, s) : 0;
   const float2* tab = (const float2*)scratch;
+  const SsrHits hits = {hit_counts, hit_offsets, (uint2*)hit_entries, hit_capacity};
+  if (hits_mode != 0) {
+    // the hit-list variants exist for the default march only (mode 4, with or without certification); -3 = not available
+    if (mode != 4 || (hits_mode != 1 && hits_mode != 2) || !(start < step)) return -3;
+    if (hits_mode == 1) {
+      if (cert) hipLaunchKernelGGL((ssr_kernel<false, 4, true, 1>), grid, dim3(256), cert, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd, tab, hits);
+      else hipLaunchKernelGGL((ssr_kernel<false, 4, false, 1>), grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd, tab, hits);
+    } else {
+      if (cert) hipLaunchKernelGGL((ssr_kernel<false, 4, true, 2>), grid, dim3(256), cert, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd, tab, hits);
+      else hipLaunchKernelGGL((ssr_kernel<false, 4, false, 2>), grid, dim3(256), 0, s, p, t.dev, normal, pos, rgb, albedo, metallic, F0, color, abd, tab, hits);
+    }
+    return 0;
+  }
 #define GIGS_SSR_LAUNCH(POW2, MODE, CERT, LDS)                                                                          \
   hipLaunchKernelGGL((ssr_kernel<POW2, MODE, CERT>), grid, dim3(256), LDS, s, p, t.dev, normal, pos, rgb, albedo, metallic, \
-                     F0, color, abd, tab)
+                     F0, color, abd, tab, hits)
   switch (mode) {
     case 1: GIGS_SSR_LAUNCH(false, 1, false, 0); break;
     case 2: GIGS_SSR_LAUNCH(false, 2, false, 0); break;

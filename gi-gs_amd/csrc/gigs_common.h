@@ -322,7 +322,12 @@ size_t gi_scratch_bytes(int W, int H);
 int launch_ssr(const Options& o, int W, int H, float fx, float fy, float radius, float bias, float thick,
                float delta, int step, int start, const float* normal, const float* pos,
                const float* rgb, const float* albedo, const float* roughness,
-               const float* metallic, const float* F0, float* color, float* abd, void* scratch, hipStream_t s);
+               const float* metallic, const float* F0, float* color, float* abd, void* scratch, hipStream_t s,
+               int hits_mode = 0, unsigned* hit_counts = nullptr, const unsigned* hit_offsets = nullptr,
+               void* hit_entries = nullptr, unsigned hit_capacity = 0);
+int launch_ssr_apply(int W, int H, float delta, const unsigned* offsets, const void* entries, const float* normal,
+                     const float* pos, const float* rgb, const float* albedo, const float* metallic, const float* F0,
+                     float* color, float* abd, hipStream_t s);
 void launch_median3x3(int C, int H, int W, const float* in, float* out, hipStream_t s);
 void launch_median3x3_bwd(int C, int H, int W, const float* in, const float* gout, float* gin,
                           hipStream_t s);

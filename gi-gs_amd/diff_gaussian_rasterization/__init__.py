@@ -143,7 +143,6 @@ class ViewSlot:
         self.device = torch.device(device)
         self.binning, self.img = _Scratch(self.device), _Scratch(self.device)
         self.occlusion = None
-        self.extra = {}   # further per-view planes a caller caches under the same protocol (SSR's hit list)
         self.meta = None  # (P, W, H, capacity) of the forward that sized the chunks
 
     def _parts(self):
@@ -155,26 +154,55 @@ class ViewSlot:
         parts = {"point_list": b[ob:ob + 4 * cap], "ranges": i[orng:orng + 8 * T], "tile_order": i[oord:oord + 4 * T]}
         if self.occlusion is not None:
             parts["occlusion"] = self.occlusion
-        parts.update(self.extra)
         return parts
 
     def export(self) -> dict:
         return {k: v.clone() for k, v in self._parts().items()}
 
+    def export_hits(self) -> dict:
+        n = int(self.ssr_total_host[0])  # valid: the caller exports after the recording forward has finished
+        return {"ssr_offsets": self.ssr_offsets.clone(), "ssr_entries": self.ssr_entries[:n].clone()}
+
     def load(self, entry: dict) -> None:
         for k, v in self._parts().items():
             v.copy_(entry[k], non_blocking=True)
+        self.ssr_loaded = "ssr_offsets" in entry
+        if self.ssr_loaded:
+            self.ssr_offsets.copy_(entry["ssr_offsets"], non_blocking=True)
+            self.ssr_entries[:entry["ssr_entries"].shape[0]].copy_(entry["ssr_entries"], non_blocking=True)
+
+    # -- the indirect-light hit list (gigs_ssr_hits / gigs_ssr_apply) ------------------------------------------------
+    ssr_offsets = ssr_counts = ssr_entries = ssr_total_host = None
+    ssr_capacity = 0
+    ssr_loaded = False
+
+    def ssr_ok(self) -> bool:
+        """After a recording forward has finished: did the hit list fit its buffer?"""
+        return self.ssr_total_host is not None and int(self.ssr_total_host[0]) <= self.ssr_capacity
+
+    def ssr_prepare(self, n_pixels: int, total_hint=None) -> None:
+        """(Re)allocates the hit-list buffers: offsets / counts by the image size, entries with 30 % headroom over
+        `total_hint` hits.  Outside a hipGraph capture only (the recording step's eager warm-up sizes them)."""
+        if self.ssr_offsets is None or self.ssr_offsets.numel() != 4 * n_pixels + 1:
+            self.ssr_offsets = torch.zeros(4 * n_pixels + 1, dtype=torch.int32, device=self.device)
+            self.ssr_counts = torch.zeros(4 * n_pixels, dtype=torch.int32, device=self.device)
+            self.ssr_total_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        if total_hint is not None and total_hint > self.ssr_capacity:
+            self.ssr_capacity = max(1 << 16, int(1.3 * total_hint))
+            self.ssr_entries = torch.empty((self.ssr_capacity, 2), dtype=torch.int32, device=self.device)
 
 
 class view_cache:
     """`with view_cache(slot, "record"):` -- the rasterizer's forward bins into the slot's chunks and the operator's SSAO
     writes the slot's occlusion plane; `with view_cache(slot, "replay"):` -- the forward REUSES the slot's tile lists
-    (gigs_ctx_set_reuse_binning: preprocess + blend only) and SSAO returns the slot's plane without marching.  Valid only
-    while positions, covariances, opacities and normals are what they were at the recording -- the caller's knowledge."""
+    (gigs_ctx_set_reuse_binning: preprocess + blend only), SSAO returns the slot's plane without marching and Gaussian_SSR
+    gathers at the slot's hit list when it holds one (gigs_ssr_apply); "replay_rec" = replay whose Gaussian_SSR still marches
+    and RECORDS that hit list (a view's first visit after its geometry is known to be frozen).  Valid only while positions,
+    covariances, opacities and normals are what they were at the recording -- the caller's knowledge."""
 
     def __init__(self, slot: ViewSlot, mode: str):
-        if mode not in ("record", "replay"):
-            raise ValueError("view_cache: mode must be 'record' or 'replay'")
+        if mode not in ("record", "replay", "replay_rec"):
+            raise ValueError("view_cache: mode must be 'record', 'replay' or 'replay_rec'")
         self.pair = (slot, mode)
 
     def __enter__(self):
@@ -342,7 +370,7 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
             raise RuntimeError("view_cache needs asynchronous binning (AsyncBinning): the slot's chunks have its capacity")
         binning, img = slot.binning, slot.img
         slot.meta = (P, W, H, _async.capacity)
-        if mode == "replay":
+        if mode != "record":
             ctx_ptr = gigs_lib.current().derive(reuse_binning=True).ptr
     rendered = 0
     if P != 0:
@@ -472,10 +500,10 @@ def _SSAO(width, height, focal_x, focal_y, radius, bias, thick, delta, step, sta
     if _view is not None:
         slot, mode = _view
         if slot.occlusion is None or tuple(slot.occlusion.shape) != (1, height, width):
-            if mode == "replay":
+            if mode != "record":
                 raise RuntimeError("view_cache('replay'): the slot holds no occlusion plane of this size")
             slot.occlusion = torch.empty((1, height, width), dtype=torch.float32, device=dev)
-        if mode == "replay":
+        if mode != "record":
             return slot.occlusion  # what the march wrote when this view was recorded: geometry has not changed since
         occlusion = slot.occlusion
     else:
@@ -511,11 +539,40 @@ def _SSR(width, height, focal_x, focal_y, radius, bias, thick, delta, step, star
         ptrs.append(ptr)
         keep.append(k)
     scratch = _gi_scratch(int(width), int(height), dev)
+    sp = None if scratch is None else scratch.data_ptr()
+    W, H = int(width), int(height)
+    a = (W, H, float(focal_x), float(focal_y), float(radius), float(bias), float(thick), float(delta), int(step), int(start))
+    hit_list = (_view is not None and gigs_lib.current().option("gi_march") == 4 and int(start) < int(step)
+                and os.environ.get("GIGS_SSR_HIT_LIST", "1") == "1")
     with torch.cuda.device(dev):
-        gigs_lib.check(_lib.gigs_ssr_ex(gigs_lib.ctx_ptr(), int(width), int(height), float(focal_x), float(focal_y), float(radius),
-                                        float(bias), float(thick), float(delta), int(step), int(start), *ptrs,
-                                        color.data_ptr(), abd.data_ptr(), None if scratch is None else scratch.data_ptr(),
-                                        _stream()), "SSR")
+        if hit_list and _view[1] == "replay" and _view[0].ssr_loaded:
+            # frozen geometry: gather the radiance at the recorded hits instead of marching (gigs_ssr_apply)
+            slot = _view[0]
+            normal_p, pos_p, rgb_p, albedo_p, _rough_p, metallic_p, F0_p = ptrs
+            gigs_lib.check(_lib.gigs_ssr_apply(W, H, float(delta), slot.ssr_offsets.data_ptr(), slot.ssr_entries.data_ptr(),
+                                               normal_p, pos_p, rgb_p, albedo_p, metallic_p, F0_p, color.data_ptr(),
+                                               abd.data_ptr(), _stream()), "SSR (gather)")
+        elif hit_list and _view[1] == "replay_rec":
+            # record the hit list beside the normal outputs: count per (pixel, wave), prefix, fill.  Outside a capture (the
+            # recording step's eager warm-up) the buffers are sized from the count; inside, an overflow is noticed by the
+            # caller (ViewSlot.ssr_ok) after the forward and the view is simply not cached with its hit list
+            slot = _view[0]
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
+                slot.ssr_prepare(W * H)
+            if slot.ssr_offsets is None:
+                raise RuntimeError("view_cache('replay_rec'): the hit-list buffers must be sized by an eager step before a capture")
+            gigs_lib.check(_lib.gigs_ssr_hits(gigs_lib.ctx_ptr(), *a, *ptrs, color.data_ptr(), abd.data_ptr(), 1,
+                                              slot.ssr_counts.data_ptr(), None, None, 0, sp, _stream()), "SSR (count)")
+            torch.cumsum(slot.ssr_counts, 0, dtype=torch.int32, out=slot.ssr_offsets[1:])
+            if not capturing:
+                slot.ssr_prepare(W * H, total_hint=int(slot.ssr_offsets[-1]))  # one read-back, in the warm-up only
+            gigs_lib.check(_lib.gigs_ssr_hits(gigs_lib.ctx_ptr(), *a, *ptrs, color.data_ptr(), abd.data_ptr(), 2, None,
+                                              slot.ssr_offsets.data_ptr(), slot.ssr_entries.data_ptr(), slot.ssr_capacity, sp,
+                                              _stream()), "SSR (fill)")
+            slot.ssr_total_host.copy_(slot.ssr_offsets[-1:], non_blocking=True)
+        else:
+            gigs_lib.check(_lib.gigs_ssr_ex(gigs_lib.ctx_ptr(), *a, *ptrs, color.data_ptr(), abd.data_ptr(), sp, _stream()), "SSR")
     return color, abd
 
 

@@ -60,6 +60,9 @@ SIGNATURES = {
     "gigs_ssao_ex": (_i, [C.c_void_p, _i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, C.c_void_p]),
     "gigs_ssr_ex": (_i, [C.c_void_p, _i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,
                          C.c_void_p]),
+    "gigs_ssr_hits": (_i, [C.c_void_p, _i, _i, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f,
+                           _i, _f, _f, _f, C.c_uint, _f, C.c_void_p]),
+    "gigs_ssr_apply": (_i, [_i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "gigs_median3x3": (_i, [_i, _i, _i, _f, _f, C.c_void_p]),
     "gigs_median3x3_backward": (_i, [_i, _i, _i, _f, _f, _f, C.c_void_p]),
     "gigs_bilateral3x3": (_i, [_i, _i, _i, _fl, _fl, _fl, _f, _f, C.c_void_p]),

@@ -395,8 +395,11 @@ class GeometryCache:
         self.capacity = 0
         self.flag_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.stats = dict(recorded=0, replayed=0, repeated=0, invalidated=0)
+        self.stats = dict(recorded=0, replayed=0, repeated=0, invalidated=0, hit_lists=0)
         self.recorded_R: Dict = {}
+        import gigs_lib as _gl
+        # the hit list of the indirect-light march is recorded by the default march only (gigs_ssr_hits)
+        self.hit_lists = os.environ.get("GIGS_SSR_HIT_LIST", "1") == "1" and _gl.current().option("gi_march") == 4
 
     @staticmethod
     def view_key(cam: Dict):
@@ -417,11 +420,16 @@ class GeometryCache:
         self.holds = None
 
     def mode(self, vkey, g) -> str:
+        """"record" (no entry: bin, march SSAO, store), "replay_rec" (entry without a hit list: reuse tile lists and
+        occlusion, march the indirect light once more and record its hits), "replay" (reuse everything)."""
         k = self._geometry_key(g)
         if k != self.param_key:   # new tensors (densification) or an in-place edit outside the captured update
             self.invalidate()
             self.param_key = k
-        return "replay" if vkey in self.entries else "record"
+        e = self.entries.get(vkey)
+        if e is None:
+            return "record"
+        return "replay_rec" if (self.hit_lists and "ssr_offsets" not in e) else "replay"
 
     def load(self, vkey) -> None:
         if self.holds != vkey:
@@ -432,6 +440,19 @@ class GeometryCache:
         self.entries[vkey] = self.slot.export()
         self.holds = vkey
         self.stats["recorded"] += 1
+
+    def store_hits(self, vkey) -> bool:
+        """After a "replay_rec" forward has finished: keep the view's hit list -- or, if it did not fit the buffer, enlarge
+        the buffer (the variants that use it re-capture: its address is part of their key) and try again at the next visit."""
+        slot = self.slot
+        if slot.ssr_ok():
+            self.entries[vkey].update(slot.export_hits())
+            slot.ssr_loaded = True
+            self.stats["hit_lists"] += 1
+            return True
+        torch.cuda.synchronize(self.device)
+        slot.ssr_prepare(slot.ssr_counts.numel() // 4, total_hint=int(slot.ssr_total_host[0]))
+        return False
 
     def geometry_moved(self) -> bool:
         """What the LAST completed update reported (valid once a later forward of the same stream has finished)."""
@@ -517,7 +538,10 @@ class WholeStepGraph:
         import diff_gaussian_rasterization as dgr
         sink = dgr._grad_sink or {}
         slabv = getattr(self.owner, "grad_slab", None) or {}
-        return (tuple((t.data_ptr(), tuple(t.shape)) for t in self._params(g)),
+        slot = self.cache.slot if self.cache is not None else None
+        slot_key = None if slot is None else tuple(None if t is None else t.data_ptr() for t in (
+            (slot.occlusion,) if self.mode == "record" else (slot.occlusion, slot.ssr_offsets, slot.ssr_entries)))
+        return (slot_key, tuple((t.data_ptr(), tuple(t.shape)) for t in self._params(g)),
                 tuple(sorted((k, v.data_ptr()) for k, v in sink.items())),
                 tuple(sorted((k, v.data_ptr()) for k, v in slabv.items())),
                 self.adam.key() if self.adam is not None else None)
@@ -710,7 +734,11 @@ class WholeStepGraph:
             raise ValueError("WholeStepGraph: image size / field of view differ from the captured ones")
         cache = self.cache
         for _ in range(4):
-            if cache is not None and self.mode == "replay":
+            if cache is not None and self.mode == "record":
+                cache.holds = None  # this forward overwrites the slot, whether or not its view ends up stored
+            if cache is not None and self.mode != "record":
+                if self.capacity <= 0:
+                    self.capacity = cache.capacity  # a fresh variant adopts the chunks' capacity
                 if cache.capacity != self.capacity or vkey not in cache.entries:
                     return None  # the recording variant re-sized the chunks / dropped the entry: record again
                 cache.load(vkey)  # the view's tile lists and occlusion plane into the slot (a no-op for the same view)
@@ -743,7 +771,7 @@ class WholeStepGraph:
                 if moved:
                     cache.flag_host.zero_()
                     cache.invalidate()
-                    if self.mode == "replay":
+                    if self.mode != "record":
                         cache.stats["repeated"] += 1
                         return None  # the replayed lists were stale: nothing of this step has been consumed, repeat it
                 if self.mode == "record":
@@ -751,6 +779,8 @@ class WholeStepGraph:
                         cache.store(vkey)
                         cache.recorded_R[vkey] = r
                 else:
+                    if self.mode == "replay_rec":
+                        cache.store_hits(vkey)
                     cache.stats["replayed"] += 1
                     r = cache.recorded_R.get(vkey, r)
             params = self._params(g)

@@ -331,7 +331,7 @@ def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_im
     if geometry_cache:
         # a training set that is revisited: eight views, every one recorded once during the warm-up
         n = min(n, 8)
-        warmup = max(warmup, n + 2)
+        warmup = max(warmup, 2 * n + 4)  # every view recorded, then replayed once with its hit list recorded: three captures
 
     def run(i):
         v = dp.view_for(i, rank, world, n)
@@ -344,9 +344,11 @@ def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_im
     if geometry_cache and tr.stepper.geom_cache is not None:
         c = tr.stepper.geom_cache
         extra["geometry_cache"] = dict(c.stats, views=n, bytes_per_view=int(sum(v.numel() * v.element_size() for v in next(iter(c.entries.values())).values())) if c.entries else 0,
-                                       what="per view: tile lists (ranges, tile order, point list) and the occlusion plane are reused "
-                                            "while the optimizer reports no change of a geometry bit (gigs_adam_step_watch); "
-                                            "preprocess, blend, shade, SSR, loss, backward and update run every iteration")
+                                       what="per view: tile lists (ranges, tile order, point list), the occlusion plane and the hit "
+                                            "list of the indirect-light march are reused while the optimizer reports no change of a "
+                                            "geometry bit (gigs_adam_step_watch): no binning, no SSAO march, SSR = a gather at the "
+                                            "recorded hits; preprocess, blend, normal derivation, shade, loss, backward and update "
+                                            "run every iteration")
     tr.close()
     with torch.no_grad():
         light.base.copy_(base0)  # bench.py's light is shared with the legs that follow

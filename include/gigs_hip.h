@@ -176,6 +176,25 @@ int gigs_ssr_ex(gigs_ctx* ctx, int width, int height, float focal_x, float focal
                 const float* pos, const float* rgb, const float* albedo, const float* roughness,
                 const float* metallic, const float* F0, float* color, float* abd, void* scratch, void* stream);
 
+/* The hit list of the indirect-light march (gigs-hip extension; frozen-geometry reuse).  WHICH pixel each ray of each pixel
+ * hits depends on normals and positions only (forward.cu:796-829), not on the radiance gathered there, so a view whose geometry
+ * does not change marches once and gathers afterwards.  gigs_ssr_hits is gigs_ssr_ex (same outputs) that additionally,
+ *   mode 1: writes counts[4 * pixel + w] = the number of hits of pixel's rays handled by wave w of its workgroup (u32 [4 N]);
+ *   mode 2: given offsets = the exclusive prefix of those counts (u32 [4 N + 1]), writes the hits in march order as
+ *           {hit pixel, ray index} pairs (2 x u32 each) at offsets[...]; pairs beyond `capacity` are dropped -- compare
+ *           offsets[4 N] with it.
+ * gigs_ssr_apply evaluates color / abd from such a list: per pixel the four sequences are summed in order, combined as the
+ * march combines its four waves, and the same tail applied -- the march's outputs bit for bit while normals / positions are the
+ * recorded ones.  Recorded by the default march only (gigs_options.gi_march = 4). */
+int gigs_ssr_hits(gigs_ctx* ctx, int width, int height, float focal_x, float focal_y, float radius, float bias, float thick,
+                  float delta, int step, int start, const float* normal_view, const float* pos, const float* rgb,
+                  const float* albedo, const float* roughness, const float* metallic, const float* F0, float* color, float* abd,
+                  int mode, unsigned* counts, const unsigned* offsets, void* entries, unsigned capacity, void* scratch,
+                  void* stream);
+int gigs_ssr_apply(int width, int height, float delta, const unsigned* offsets, const void* entries, const float* normal_view,
+                   const float* pos, const float* rgb, const float* albedo, const float* metallic, const float* F0,
+                   float* color, float* abd, void* stream);
+
 /* kornia.filters.median_blur(x[None], (3,3))[0] as called at
  * R/diff_gaussian_rasterization/__init__.py:478, 504 (zero padding, NaN-propagating). */
 int gigs_median3x3(int channels, int height, int width, const float* in, float* out, void* stream);
