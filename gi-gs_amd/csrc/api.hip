@@ -114,6 +114,7 @@ gigs::Options options_from_env() {
   const char* ll = getenv("GIGS_LONG_LISTS");
   o.long_lists = (ll && ll[0]) ? (ll[0] == '1' ? 1 : 0) : -1;
   o.bucket_target = std::max(256, env_int("GIGS_BUCKET_TARGET", 1536));
+  o.bin_bands = std::max(0, env_int("GIGS_BIN_BANDS", 0));
   o.blend_cull = env_int("GIGS_BLEND_CULL", 1) != 0;
   o.pre_bwd_sh_skip = env_int("GIGS_PRE_BWD_SH_SKIP", 1) != 0;
   o.gi_march = 4;
@@ -256,7 +257,7 @@ int gigs_ctx_get_options(const gigs_ctx* ctx, gigs_options* out) {
   const gigs::Options& o = ctx_of(ctx).opt;
   out->struct_bytes = (int)sizeof(gigs_options);
   out->binning_legacy = o.binning_legacy; out->bucket_max_mean = o.bucket_max_mean; out->long_lists = o.long_lists;
-  out->bucket_target = o.bucket_target; out->blend_cull = o.blend_cull; out->pre_bwd_sh_skip = o.pre_bwd_sh_skip;
+  out->bucket_target = o.bucket_target; out->bin_bands = o.bin_bands; out->blend_cull = o.blend_cull; out->pre_bwd_sh_skip = o.pre_bwd_sh_skip;
   out->gi_march = o.gi_march; out->gi_cert = o.gi_cert; out->gi_interleave = o.gi_interleave;
   out->gi_tile_log2w = o.gi_tile_log2w; out->gi_zero_rays = o.gi_zero_rays; out->spec_max8 = o.spec_max8;
   out->spec_max16 = o.spec_max16; out->shade_lds_floats = o.shade_lds_floats; out->shade_bwd_blocks = o.shade_bwd_blocks;
@@ -268,12 +269,13 @@ int gigs_ctx_set_options(gigs_ctx* ctx, const gigs_options* in) {
   if (in->gi_march < 0 || in->gi_march > 4) return fail(GIGS_ERR_INVALID, "gi_march must be 0..4");
   if (in->gi_tile_log2w < 0 || in->gi_tile_log2w > 6) return fail(GIGS_ERR_INVALID, "gi_tile_log2w must be 0..6");
   if (in->long_lists < -1 || in->long_lists > 1) return fail(GIGS_ERR_INVALID, "long_lists must be -1, 0 or 1");
-  if (in->bucket_target < 256 || in->bucket_max_mean < 0) return fail(GIGS_ERR_INVALID, "bucket_target >= 256, bucket_max_mean >= 0");
+  if (in->bucket_target < 256 || in->bucket_max_mean < 0 || in->bin_bands < 0 || in->bin_bands > 64)
+    return fail(GIGS_ERR_INVALID, "bucket_target >= 256, bucket_max_mean >= 0, 0 <= bin_bands <= 64");
   if (in->spec_max8 < 0 || in->spec_max16 < in->spec_max8) return fail(GIGS_ERR_INVALID, "0 <= spec_max8 <= spec_max16");
   if (in->shade_lds_floats < 0 || in->shade_bwd_blocks < 0) return fail(GIGS_ERR_INVALID, "shade_lds_floats, shade_bwd_blocks >= 0");
   gigs::Options& o = reinterpret_cast<gigs::Ctx*>(ctx)->opt;
   o.binning_legacy = in->binning_legacy != 0; o.bucket_max_mean = in->bucket_max_mean; o.long_lists = in->long_lists;
-  o.bucket_target = in->bucket_target; o.blend_cull = in->blend_cull != 0; o.pre_bwd_sh_skip = in->pre_bwd_sh_skip != 0;
+  o.bucket_target = in->bucket_target; o.bin_bands = in->bin_bands; o.blend_cull = in->blend_cull != 0; o.pre_bwd_sh_skip = in->pre_bwd_sh_skip != 0;
   o.gi_march = in->gi_march; o.gi_cert = in->gi_cert != 0; o.gi_interleave = in->gi_interleave != 0;
   o.gi_tile_log2w = in->gi_tile_log2w; o.gi_zero_rays = in->gi_zero_rays != 0; o.spec_max8 = in->spec_max8;
   o.spec_max16 = in->spec_max16; o.shade_lds_floats = in->shade_lds_floats; o.shade_bwd_blocks = in->shade_bwd_blocks;
@@ -457,7 +459,9 @@ int gigs_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_user, g
     }
     {
       StageScope sc(kSort, s);
-      gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, geom, bin, img, s);
+      // dense scenes scatter in bands of tile rows (binning.hip::bin_scatter_kernel); options.bin_bands overrides
+      const unsigned bands = opt.bin_bands > 0 ? (unsigned)opt.bin_bands : (dense ? 4u : 1u);
+      gigs::launch_bin_scatter(P, radii, a.gx, a.gy, (unsigned)num_rendered, bands, geom, bin, img, s);
       if (gigs::launch_bin_sort((int)T, P, dense && num_rendered > 0, (unsigned)opt.bucket_target, (unsigned)num_rendered, bin, img, s) != 0)
         return fail(GIGS_ERR_HIP, "bin_sort: cannot fork the sort streams");
     }

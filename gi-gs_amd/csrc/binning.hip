@@ -158,8 +158,10 @@ void launch_tile_ranges(int R, const BinningState& b, uint2* ranges, hipStream_t
 // No host read-back anywhere: with a caller-given capacity (gigs_set_async_binning) the forward never synchronises and
 // can be captured into a hipGraph; R and an overflow flag stay in device memory.  Instances beyond the capacity are
 // dropped (ranges are clamped, the flag is raised): memory-safe, and the caller replays the step with a larger capacity.
+// [row0, row1): the tile rows this pass of the walk emits (bin_scatter's bands; everything for the other walks)
 __device__ __forceinline__ bool bin_rect(int idx, int end, const int* __restrict__ radii, const float* __restrict__ means2D,
-                                         unsigned gx, unsigned gy, unsigned& minx, unsigned& miny, unsigned& w, unsigned& n) {
+                                         unsigned gx, unsigned gy, unsigned& minx, unsigned& miny, unsigned& w, unsigned& n,
+                                         unsigned row0 = 0u, unsigned row1 = 0xffffffffu) {
   minx = miny = w = n = 0;
   if (idx >= end) return false;
   const int r = radii[idx];
@@ -167,6 +169,9 @@ __device__ __forceinline__ bool bin_rect(int idx, int end, const int* __restrict
   const float2 xy = reinterpret_cast<const float2*>(means2D)[idx];
   unsigned maxx, maxy;
   tile_rect(xy.x, xy.y, r, gx, gy, minx, miny, maxx, maxy);
+  miny = max(miny, row0);
+  maxy = min(maxy, row1);
+  if (maxy <= miny) return false;
   w = maxx - minx;
   n = w * (maxy - miny);
   return n > 0;
@@ -178,7 +183,7 @@ constexpr unsigned kBinWaveExpand = 12;  // footprints with more tiles than this
 // payload = pay(idx) evaluated once per Gaussian (the split path's depth bucket; the plain path passes nothing).
 template <typename Pay, typename F>
 __device__ __forceinline__ void bin_walk(int P, const int* __restrict__ radii, const float* __restrict__ means2D, unsigned gx,
-                                         unsigned gy, Pay pay, F f) {
+                                         unsigned gy, Pay pay, F f, unsigned row0 = 0u, unsigned row1 = 0xffffffffu) {
   const int groups = min((int)kBinGroups, (P + 255) / 256);
   const int chunk = (P + groups - 1) / groups;
   const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
@@ -186,7 +191,7 @@ __device__ __forceinline__ void bin_walk(int P, const int* __restrict__ radii, c
   for (int base = begin; base < end; base += blockDim.x) {
     const int idx = base + threadIdx.x;
     unsigned minx, miny, w, n;
-    const bool any = bin_rect(idx, end, radii, means2D, gx, gy, minx, miny, w, n);
+    const bool any = bin_rect(idx, end, radii, means2D, gx, gy, minx, miny, w, n, row0, row1);
     const unsigned payload = any ? pay(idx) : 0u;
     const bool big = any && n > kBinWaveExpand;
     if (any && !big) {
@@ -294,15 +299,22 @@ __global__ void __launch_bounds__(kLanes)
 bin_scatter_kernel(int P, int T, const int* __restrict__ radii, const float* __restrict__ means2D,
                    const float* __restrict__ depths, unsigned gx, unsigned gy, unsigned capacity, unsigned idx_bits,
                    const uint32_t* __restrict__ bin_hist, const uint32_t* __restrict__ tile_start,
-                   uint64_t* __restrict__ keys) {
+                   uint64_t* __restrict__ keys, unsigned bands) {
   extern __shared__ uint32_t s_cur[];
   const uint32_t* row = bin_hist + (size_t)blockIdx.x * T;
   for (int t = threadIdx.x; t < T; t += kLanes) s_cur[t] = tile_start[t] + row[t];
   __syncthreads();
-  bin_walk(P, radii, means2D, gx, gy, NoPay(), [&](int idx, unsigned tile, unsigned) {
-    const uint32_t slot = atomicAdd(&s_cur[tile], 1u);
-    if (slot < capacity) keys[slot] = ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint32_t)idx;
-  });
+  // bands > 1 (gigs_options.bin_bands): the chunk is walked once per band of tile rows and emits only that band's instances,
+  // so that at any time the grid's 8-byte key stores go to 1 / bands of the (chunk, tile) sub-ranges -- the lines they fill
+  // stay cache-resident until they are full (a dense scene's 512 chunks x 4 056 tiles x 128-byte lines are 266 MB of open
+  // lines against 256 MB of Infinity Cache: 3.65 x write amplification, profiles/r03/pmc_summary_r03_c4).  Same slots, same
+  // keys: the order inside a (chunk, tile) sub-range is arbitrary anyway (the per-tile sort follows).
+  const unsigned rows = (gy + bands - 1) / bands;
+  for (unsigned b = 0; b < bands; b++)
+    bin_walk(P, radii, means2D, gx, gy, NoPay(), [&](int idx, unsigned tile, unsigned) {
+      const uint32_t slot = atomicAdd(&s_cur[tile], 1u);
+      if (slot < capacity) keys[slot] = ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint32_t)idx;
+    }, b * rows, min(gy, (b + 1) * rows));
 }
 
 // Bitonic network with every compare-exchange ascending (first substage of a merge mirrors the upper half), so an
@@ -779,16 +791,17 @@ void launch_bin_prefix(int P, int T, unsigned capacity, const ImageState& img, u
                      img.bin_counters, user_counters);
 }
 
-void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, const GeomState& g,
+void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, unsigned bands, const GeomState& g,
                         const BinningState& b, const ImageState& img, hipStream_t s) {
   const int T = (int)(gx * gy);
   const uint32_t* tile_start = img.bin_hist + (size_t)(kBinGroups + 1) * T;
+  bands = std::max(1u, std::min(bands, gy));
   if (P >= kWideWalk)
     hipLaunchKernelGGL(bin_scatter_kernel<1024>, dim3(bin_groups(P)), dim3(1024), (size_t)T * sizeof(uint32_t), s, P, T, radii,
-                       g.means2D, g.depths, gx, gy, capacity, bin_index_bits(P), img.bin_hist, tile_start, b.keys_unsorted);
+                       g.means2D, g.depths, gx, gy, capacity, bin_index_bits(P), img.bin_hist, tile_start, b.keys_unsorted, bands);
   else
     hipLaunchKernelGGL(bin_scatter_kernel<256>, dim3(bin_groups(P)), dim3(256), (size_t)T * sizeof(uint32_t), s, P, T, radii,
-                       g.means2D, g.depths, gx, gy, capacity, bin_index_bits(P), img.bin_hist, tile_start, b.keys_unsorted);
+                       g.means2D, g.depths, gx, gy, capacity, bin_index_bits(P), img.bin_hist, tile_start, b.keys_unsorted, bands);
 }
 
 // ---- dense scenes: the long lists' partition + bucket sorts (tables in the binning chunk's sort_space, which the

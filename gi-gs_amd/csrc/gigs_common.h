@@ -238,6 +238,7 @@ struct Options {
   int bucket_max_mean;   // GIGS_BUCKET_MAX_MEAN
   int long_lists;        // GIGS_LONG_LISTS: -1 auto, 0 never, 1 always
   int bucket_target;     // GIGS_BUCKET_TARGET
+  int bin_bands;         // GIGS_BIN_BANDS: passes of the by-tile scatter over bands of tile rows (0 = by density: 1 / 4)
   int blend_cull;        // GIGS_BLEND_CULL
   int pre_bwd_sh_skip;   // GIGS_PRE_BWD_SH_SKIP
   int gi_march;          // GIGS_GI_MARCH: 0 exact, 1 hoist, 2 hoist_fma, 3 proj_nr, 4 proj
@@ -275,7 +276,7 @@ void launch_zero_words(uint32_t* p, size_t n, hipStream_t s);
 // tile-bucketed binning: count -> prefix (ranges, R) -> scatter -> per-tile sort
 void launch_bin_count(int P, const int* radii, unsigned gx, unsigned gy, const GeomState& g, const ImageState& img, hipStream_t s);
 void launch_bin_prefix(int P, int T, unsigned capacity, const ImageState& img, unsigned* user_counters, hipStream_t s);
-void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, const GeomState& g,
+void launch_bin_scatter(int P, const int* radii, unsigned gx, unsigned gy, unsigned capacity, unsigned bands, const GeomState& g,
                         const BinningState& b, const ImageState& img, hipStream_t s);
 // long_lists: tiles above 8192 keys are partitioned by sampled splitters and sorted bucket by bucket (dense scenes)
 int launch_bin_sort(int T, int P, bool long_lists, unsigned bucket_target, unsigned capacity, const BinningState& b, const ImageState& img,

@@ -149,7 +149,7 @@ class ShadeExt(C.Structure):
 class Options(C.Structure):
     """gigs_options of include/gigs_hip.h."""
     _fields_ = [(n, C.c_int) for n in (
-        "struct_bytes", "binning_legacy", "bucket_max_mean", "long_lists", "bucket_target", "blend_cull",
+        "struct_bytes", "binning_legacy", "bucket_max_mean", "long_lists", "bucket_target", "bin_bands", "blend_cull",
         "pre_bwd_sh_skip", "gi_march", "gi_cert", "gi_interleave", "gi_tile_log2w", "gi_zero_rays", "spec_max8",
         "spec_max16", "shade_lds_floats", "shade_bwd_blocks")]
 

@@ -64,6 +64,8 @@ typedef struct gigs_options {
   int bucket_max_mean;  /* mean instances per tile above which a scene counts as dense (2500). env GIGS_BUCKET_MAX_MEAN */
   int long_lists;       /* -1 (default) by density, 0 / 1 forbid / force the long-list partition.  env GIGS_LONG_LISTS */
   int bucket_target;    /* keys per bucket of that partition (1536).                            env GIGS_BUCKET_TARGET */
+  int bin_bands;        /* passes of the by-tile scatter over bands of tile rows: 0 (default) = 4 for dense scenes, else 1;
+                           same keys, point_list, ranges.                                          env GIGS_BIN_BANDS */
   int blend_cull;       /* 1 (default); 0 = blend forward without the quadrant cull (same bits). env GIGS_BLEND_CULL */
   int pre_bwd_sh_skip;  /* 1 (default); 0 = the preprocess backward evaluates every chain.   env GIGS_PRE_BWD_SH_SKIP */
   int gi_march;         /* SSAO / SSR march: 0 exact (the oracle's pixel choices bit for bit), 1 hoist, 2 hoist_fma,
