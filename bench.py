@@ -776,6 +776,10 @@ def secondary_steps(args, g, light, brdf_lut, gi, cams_t, view_dirs, gt_image, n
                     chain runs, which the stage-2 pattern of the headline step skips); no shade / SSR
     iteration       a COMPLETE stage-2 training iteration of train.py:247-523: activations of the raw parameter groups,
                     the headline step, BRDF TV + lamb + envmap TV, backward, Adam on Gaussians and light, clamp
+    iteration_cached_geometry  the same iteration over eight revisited views with pipeline.GeometryCache: tile lists,
+                    occlusion plane and the indirect-light hit list are reused per view while the optimizer reports no
+                    change of a geometry bit (stage 2 updates materials and light only); same updates, fewer kernels.
+                    A secondary figure: `value`, `drop_in_step` and `iteration` run everything
     iteration_stage1  a complete stage-1 iteration (train.py:266-331): L1 + D-SSIM + normal losses, full backward, Adam
     """
     out = {}
