@@ -9,6 +9,7 @@ forward and one backward (gigs_activate_fwd / _bwd) instead of eight getters' wo
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict
 
 import torch
@@ -23,7 +24,11 @@ _OUT_OF = dict(opacities="opacity", normal="normal", albedo="albedo", roughness=
                scales="scaling", rotations="rotation")
 
 
-_sink = None
+class _Scope(threading.local):
+    sink = None
+
+
+_st = _Scope()  # per thread, like the scopes of diff_gaussian_rasterization
 
 
 class grad_sink:
@@ -36,13 +41,11 @@ class grad_sink:
         self.tensors = dict(tensors)
 
     def __enter__(self):
-        global _sink
-        self._prev, _sink = _sink, self.tensors
+        self._prev, _st.sink = _st.sink, self.tensors
         return self
 
     def __exit__(self, *exc):
-        global _sink
-        _sink = self._prev
+        _st.sink = self._prev
         return False
 
 
@@ -75,7 +78,7 @@ class _Activate(torch.autograd.Function):
         raw = ctx.saved_tensors
         dev = raw[0].device
         g = [None if t is None else t.contiguous().float() for t in g_out]
-        sink = _sink or {}
+        sink = _st.sink or {}
         d = []
         for name, t in zip(RAW, raw):
             v = sink.get(name)

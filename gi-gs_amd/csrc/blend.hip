@@ -249,7 +249,7 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ brec,
                  const float* __restrict__ viewmatrix, const float* __restrict__ bg_color,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, BlendOut o,
-                 int argmax_depth, int inference, uint8_t* __restrict__ hit_mask, int cull,
+                 int argmax_depth, int inference, uint8_t* __restrict__ hit_mask, size_t hit_stride, int cull,
                  const uint32_t* __restrict__ tile_order) {
   // Each wave walks the tile's list on its own (no workgroup barrier anywhere): the time of a tile is the
   // time of its busiest quadrant, not the sum over batches of the slowest quadrant of each batch, and a wave
@@ -274,7 +274,10 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   // the kernel ends when its longest tile does: waves of long tiles get the issue priority on their SIMD
   if (n > kLongTile) __builtin_amdgcn_s_setprio(3);
   float4* sw = s_rec[wave];
-  uint8_t* hit = hit_mask + 4 * (size_t)range.x + wave;  // this quadrant's byte of instance i: hit[4 * i]
+  // this quadrant's byte of instance i of the list: hit[i].  One plane of R bytes per quadrant ([4][R]): a wave's 64 bytes per
+  // chunk are one contiguous run (interleaved [R][4] they were a 256-byte span of partial 32-byte writes: 16 B of L2 -> fabric
+  // write traffic per instance at C4, 460 MB per forward; the backward read them with the same stride)
+  uint8_t* hit = hit_mask + (size_t)wave * hit_stride + range.x;
 
   float T = 1.0f;
   uint32_t last_contributor = 0;
@@ -373,10 +376,10 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
     // serial path of the long walks, at most one chunk of cheap non-blending evaluations more for the others
     wave_done = ballot64(!done) == 0ull;
     __builtin_amdgcn_wave_barrier();  // the walk's LDS reads precede the next chunk's staging stores
-    if (valid) hit[4 * (size_t)(base + lane)] = (uint8_t)((hits >> lane) & 1ull);
+    if (valid) hit[base + lane] = (uint8_t)((hits >> lane) & 1ull);
   }
   // instances of chunks that were never fetched (every pixel of the quadrant saturated) blend nowhere here
-  for (int i = base + lane; i < n; i += 64) hit[4 * (size_t)i] = 0;
+  for (int i = base + lane; i < n; i += 64) hit[i] = 0;
 
   const float C0 = C01.x, C1 = C01.y, C2 = C2P0.x, P0 = C2P0.y, N0 = N01.x, N1 = N01.y, N2 = N2P1.x, P1 = N2P1.y;
   const float A0 = A01.x, A1 = A01.y, A2 = A2P2.x, P2 = A2P2.y, Rr = RM.x, Mm = RM.y;
@@ -413,13 +416,14 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
 void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& b,
                       const ImageState& im, float* out_color, float* out_opacity,
                       float* out_depth, float* out_normal, float* out_normal_view, float* out_pos,
-                      float* out_albedo, float* out_roughness, float* out_metallic, int cull, hipStream_t s) {
+                      float* out_albedo, float* out_roughness, float* out_metallic, int cull, size_t hit_stride,
+                      hipStream_t s) {
   BlendOut o{out_color, out_opacity, out_depth, out_normal, out_normal_view,
              out_pos, out_albedo, out_roughness, out_metallic};
   // cull = 0 (gigs_options.blend_cull) disables the quadrant cull (diagnostic: the outputs must not change by a bit)
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(a.gx * a.gy), dim3(GIGS_TILE), 0, s, a.W, a.H, a.gx,
                      im.ranges, b.point_list, g.brec, a.viewmatrix, a.background, im.n_contrib,
-                     im.final_T, o, a.argmax_depth, a.inference, b.hit_mask, cull, im.tile_order);
+                     im.final_T, o, a.argmax_depth, a.inference, b.hit_mask, hit_stride, cull, im.tile_order);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -432,7 +436,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ brec,
                  const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
                  const uint32_t* __restrict__ n_contrib, BlendGradIn gi, float* __restrict__ grec,
-                 const uint8_t* __restrict__ hit_mask, const uint32_t* __restrict__ tile_order) {
+                 const uint8_t* __restrict__ hit_mask, size_t hit_stride, const uint32_t* __restrict__ tile_order) {
   // Wave-autonomous like the forward: each wave walks the tile's list back to front in chunks of 64 instances
   // (lane l of chunk c <-> instance n-1-(64c+l)), fetching only the instances its quadrant blended (the
   // forward's hit byte), two-deep pipelined, no workgroup barrier.  The 19 per-Gaussian sums of a wave are
@@ -456,7 +460,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   if (n > kLongTile) __builtin_amdgcn_s_setprio(3);
   float4* sw = s_rec[wave];
   float* ssum = s_sum[wave];
-  const uint8_t* hit = hit_mask + 4 * (size_t)range.x + wave;
+  const uint8_t* hit = hit_mask + (size_t)wave * hit_stride + range.x;
 
   const float T_final = inside ? final_Ts[pix_id] : 0;
   float T = T_final;
@@ -494,7 +498,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   // pipeline prologue (chunk 0 = the last 64 instances): ids + hit bytes of chunks 0 and 1, records of chunk 0
   auto fetch_id = [&](int base, uint32_t& id, bool& h) {
     const int idx = n - 1 - (base + lane);
-    h = idx >= 0 && hit[4 * (size_t)idx] != 0;
+    h = idx >= 0 && hit[idx] != 0;
     id = h ? point_list[range.x + idx] : 0u;
   };
   uint32_t id_cur, id_next;
@@ -629,7 +633,7 @@ void launch_blend_bwd(const BwdArgs& a, const GeomState& g, const BinningState& 
                  a.dL_dpix_albedo, a.dL_dpix_roughness, a.dL_dpix_metallic};
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.gx * a.gy), dim3(GIGS_TILE), 0, s, a.W, a.H, a.gx,
                      im.ranges, b.point_list, g.brec, a.background, im.final_T,
-                     im.n_contrib, gi, g.grec, b.hit_mask, im.tile_order);
+                     im.n_contrib, gi, g.grec, b.hit_mask, (size_t)a.R, im.tile_order);
 }
 
 }  // namespace gigs

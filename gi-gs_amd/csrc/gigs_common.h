@@ -206,7 +206,7 @@ struct BinningState {
   uint32_t* values_unsorted;
   uint64_t* keys;
   uint32_t* point_list;
-  uint8_t* hit_mask;  // [R][4]: byte w of instance i is 1 iff quadrant (wave) w of its tile had a pixel that blended it
+  uint8_t* hit_mask;  // [4][R]: byte i of plane w is 1 iff quadrant (wave) w of instance i's tile had a pixel that blended it
   char* sort_space;
   size_t sort_size;
   static BinningState fromChunk(char*& chunk, size_t R, size_t sort_size) {
@@ -295,7 +295,8 @@ void launch_tile_order(int T, const uint2* ranges, uint32_t* tile_order, hipStre
 void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& b,
                       const ImageState& im, float* out_color, float* out_opacity,
                       float* out_depth, float* out_normal, float* out_normal_view, float* out_pos,
-                      float* out_albedo, float* out_roughness, float* out_metallic, int cull, hipStream_t s);
+                      float* out_albedo, float* out_roughness, float* out_metallic, int cull, size_t hit_stride,
+                      hipStream_t s);  // hit_stride = the R the binning chunk was carved for
 
 struct BwdArgs {
   int P, D, M, R, W, H;

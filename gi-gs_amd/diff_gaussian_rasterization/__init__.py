@@ -21,6 +21,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
+import threading
 from types import SimpleNamespace
 from typing import NamedTuple, Optional, Tuple
 
@@ -73,6 +74,19 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Scopes(threading.local):
+    """The dynamic scopes of this module (`with OutputPool / after_blend / grad_sink / AsyncBinning / view_cache`), per
+    THREAD like the library contexts of gigs_lib: two Python threads driving two streams do not see each other's."""
+    pool = None         # OutputPool
+    after_blend = None  # callable
+    grad_sink = None    # {name: tensor}
+    async_ = None       # AsyncBinning
+    view = None         # (ViewSlot, "record" | "replay" | "replay_rec") while a frozen-geometry view cache is active
+
+
+_st = _Scopes()
+
+
 class OutputPool:
     """Optional reuse of the operator's output planes across calls (gigs-hip extension, off by default).
 
@@ -85,14 +99,12 @@ class OutputPool:
         self.buffers, self.counts = {}, {}
 
     def __enter__(self):
-        global _pool
         self.counts = {}
-        self._prev, _pool = _pool, self
+        self._prev, _st.pool = _st.pool, self
         return self
 
     def __exit__(self, *exc):
-        global _pool
-        _pool = self._prev
+        _st.pool = self._prev
         return False
 
     def get(self, tag, shape, dtype, device):
@@ -105,8 +117,6 @@ class OutputPool:
         return t
 
 
-_pool: Optional[OutputPool] = None
-_after_blend = None
 
 
 class after_blend:
@@ -117,19 +127,14 @@ class after_blend:
         self.fn = fn
 
     def __enter__(self):
-        global _after_blend
-        self._prev, _after_blend = _after_blend, self.fn
+        self._prev, _st.after_blend = _st.after_blend, self.fn
         return self
 
     def __exit__(self, *exc):
-        global _after_blend
-        _after_blend = self._prev
+        _st.after_blend = self._prev
         return False
 
 
-_grad_sink = None
-_async = None
-_view = None  # (ViewSlot, "record" | "replay") while a frozen-geometry view cache is active
 
 
 class ViewSlot:
@@ -206,13 +211,11 @@ class view_cache:
         self.pair = (slot, mode)
 
     def __enter__(self):
-        global _view
-        self._prev, _view = _view, self.pair
+        self._prev, _st.view = _st.view, self.pair
         return self
 
     def __exit__(self, *exc):
-        global _view
-        _view = self._prev
+        _st.view = self._prev
         return False
 
 
@@ -245,16 +248,14 @@ class AsyncBinning:
         self._snap = False
 
     def __enter__(self):
-        global _async
-        self._prev, _async = _async, self
+        self._prev, _st.async_ = _st.async_, self
         self._use = gigs_lib.use(gigs_lib.current().derive(async_binning=(self.capacity, self.counters)))
         self._use.__enter__()
         return self
 
     def __exit__(self, *exc):
-        global _async
         self._use.__exit__(*exc)
-        _async = self._prev
+        _st.async_ = self._prev
         return False
 
     def snapshot(self) -> None:
@@ -285,20 +286,18 @@ class grad_sink:
         self.tensors = dict(tensors)
 
     def __enter__(self):
-        global _grad_sink
-        self._prev, _grad_sink = _grad_sink, self.tensors
+        self._prev, _st.grad_sink = _st.grad_sink, self.tensors
         return self
 
     def __exit__(self, *exc):
-        global _grad_sink
-        _grad_sink = self._prev
+        _st.grad_sink = self._prev
         return False
 
 
 def _new(tag: str, shape, device, dtype=torch.float32) -> torch.Tensor:
     """Uninitialised output tensor (every element is written by the kernel that receives it)."""
-    if _pool is not None:
-        return _pool.get(tag, shape, dtype, device)
+    if _st.pool is not None:
+        return _st.pool.get(tag, shape, dtype, device)
     return torch.empty(tuple(shape), dtype=dtype, device=device)
 
 
@@ -363,13 +362,13 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
     out_opacity, out_depth, out_roughness, out_metallic = slab[15:16], slab[16:17], slab[17:18], slab[18:19]
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     ctx_ptr = gigs_lib.ctx_ptr()
-    if _view is not None and P != 0:
+    if _st.view is not None and P != 0:
         # frozen-geometry view cache: bin into (record) / blend from (replay) the slot's fixed chunks
-        slot, mode = _view
-        if _async is None:
+        slot, mode = _st.view
+        if _st.async_ is None:
             raise RuntimeError("view_cache needs asynchronous binning (AsyncBinning): the slot's chunks have its capacity")
         binning, img = slot.binning, slot.img
-        slot.meta = (P, W, H, _async.capacity)
+        slot.meta = (P, W, H, _st.async_.capacity)
         if mode != "record":
             ctx_ptr = gigs_lib.current().derive(reuse_binning=True).ptr
     rendered = 0
@@ -421,7 +420,7 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
     # every element of every gradient tensor is written by the backward kernels when P > 0
     # (the reference zero-fills 14 tensors first, rasterize_points.cu:299-312)
     _mk = torch.empty if P != 0 else torch.zeros
-    sink = _grad_sink or {}
+    sink = _st.grad_sink or {}
 
     def z(name, *shape):
         t = sink.get(name)
@@ -497,8 +496,8 @@ def _depth_to_normal(width, height, focal_x, focal_y, viewmatrix, depthMap):
 def _SSAO(width, height, focal_x, focal_y, radius, bias, thick, delta, step, start, out_normal, out_pos):
     _need_gpu(out_normal, "out_normal")
     dev = out_normal.device
-    if _view is not None:
-        slot, mode = _view
+    if _st.view is not None:
+        slot, mode = _st.view
         if slot.occlusion is None or tuple(slot.occlusion.shape) != (1, height, width):
             if mode != "record":
                 raise RuntimeError("view_cache('replay'): the slot holds no occlusion plane of this size")
@@ -542,21 +541,21 @@ def _SSR(width, height, focal_x, focal_y, radius, bias, thick, delta, step, star
     sp = None if scratch is None else scratch.data_ptr()
     W, H = int(width), int(height)
     a = (W, H, float(focal_x), float(focal_y), float(radius), float(bias), float(thick), float(delta), int(step), int(start))
-    hit_list = (_view is not None and gigs_lib.current().option("gi_march") == 4 and int(start) < int(step)
+    hit_list = (_st.view is not None and gigs_lib.current().option("gi_march") == 4 and int(start) < int(step)
                 and os.environ.get("GIGS_SSR_HIT_LIST", "1") == "1")
     with torch.cuda.device(dev):
-        if hit_list and _view[1] == "replay" and _view[0].ssr_loaded:
+        if hit_list and _st.view[1] == "replay" and _st.view[0].ssr_loaded:
             # frozen geometry: gather the radiance at the recorded hits instead of marching (gigs_ssr_apply)
-            slot = _view[0]
+            slot = _st.view[0]
             normal_p, pos_p, rgb_p, albedo_p, _rough_p, metallic_p, F0_p = ptrs
             gigs_lib.check(_lib.gigs_ssr_apply(W, H, float(delta), slot.ssr_offsets.data_ptr(), slot.ssr_entries.data_ptr(),
                                                normal_p, pos_p, rgb_p, albedo_p, metallic_p, F0_p, color.data_ptr(),
                                                abd.data_ptr(), _stream()), "SSR (gather)")
-        elif hit_list and _view[1] == "replay_rec":
+        elif hit_list and _st.view[1] == "replay_rec":
             # record the hit list beside the normal outputs: count per (pixel, wave), prefix, fill.  Outside a capture (the
             # recording step's eager warm-up) the buffers are sized from the count; inside, an overflow is noticed by the
             # caller (ViewSlot.ssr_ok) after the forward and the view is simply not cached with its hit list
-            slot = _view[0]
+            slot = _st.view[0]
             capturing = torch.cuda.is_current_stream_capturing()
             if not capturing:
                 slot.ssr_prepare(W * H)
@@ -811,10 +810,10 @@ class GaussianRasterizer(nn.Module):
          out_normal_view, _) = _RasterizeGaussians.apply(
             means3D, means2D, opacities, normal, albedo, roughness, metallic, shs, colors_precomp, scales,
             rotations, cov3D_precomp, raster_settings)
-        if _after_blend is not None:
+        if _st.after_blend is not None:
             # gigs-hip extension: the blend kernel is queued, the VALU-bound SSAO march is next -- the point at
             # which a caller can start independent memory-bound work on another stream (see after_blend)
-            _after_blend()
+            _st.after_blend()
 
         focal_x = raster_settings.image_width / (2.0 * raster_settings.tanfovx)
         focal_y = raster_settings.image_height / (2.0 * raster_settings.tanfovy)

@@ -536,7 +536,7 @@ class WholeStepGraph:
 
     def _key(self, g):
         import diff_gaussian_rasterization as dgr
-        sink = dgr._grad_sink or {}
+        sink = dgr._st.grad_sink or {}
         slabv = getattr(self.owner, "grad_slab", None) or {}
         slot = self.cache.slot if self.cache is not None else None
         slot_key = None if slot is None else tuple(None if t is None else t.data_ptr() for t in (

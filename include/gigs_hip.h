@@ -523,8 +523,8 @@ int gigs_dist2(int P, const float* points, float* mean_dists, void* scratch, siz
  * start, or -1).  `which`: geometry 0 depths f32[P], 1 pos_view f32[3P], 2 means2D f32[2P],
  * 3 cov3D f32[6P], 4 conic_opacity f32[4P], 5 rgb f32[3P], 6 clamped u8[3P],
  * 7 tiles_touched u32[P], 8 point_offsets u32[P];  binning 0 keys_unsorted u64[R],
- * 1 values_unsorted u32[R], 2 keys u64[R], 3 point_list u32[R], 4 hit_mask u8[4R] (byte w of instance i: quadrant
- * w of its tile blended it);  image 0 final_T f32[N],
+ * 1 values_unsorted u32[R], 2 keys u64[R], 3 point_list u32[R], 4 hit_mask u8[4][R] (byte i of plane w: quadrant
+ * w of instance i's tile blended it);  image 0 final_T f32[N],
  * 1 n_contrib u32[N], 2 ranges u32[2T], 3 tile_order u32[T] (the blend kernels' workgroup -> tile map, longest lists first). */
 long long gigs_geom_offset(int P, int which);
 long long gigs_binning_offset(int num_rendered, int which);
