@@ -71,6 +71,7 @@ class _Activate(torch.autograd.Function):
                                                   torch.cuda.current_stream().cuda_stream), "activate_fwd")
         ctx.save_for_backward(*raw)
         ctx.P, ctx.K = P, K
+        ctx.sink = _st.sink  # backward() runs on autograd's device thread: the sink of THIS call travels with the node
         return tuple(out[n] for n in OUT)
 
     @staticmethod
@@ -78,7 +79,7 @@ class _Activate(torch.autograd.Function):
         raw = ctx.saved_tensors
         dev = raw[0].device
         g = [None if t is None else t.contiguous().float() for t in g_out]
-        sink = _st.sink or {}
+        sink = ctx.sink or _st.sink or {}
         d = []
         for name, t in zip(RAW, raw):
             v = sink.get(name)

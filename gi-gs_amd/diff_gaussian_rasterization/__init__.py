@@ -723,6 +723,10 @@ class _RasterizeGaussians(torch.autograd.Function):
          out_normal_view, out_pos, albedo_map, roughness_map, metallic_map) = res
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        # autograd runs backward() on its own device thread: the library context and the gradient sink of THIS call travel
+        # with the node (gigs_lib.with_forward_context; the per-thread scopes of this module are the caller's)
+        ctx.lib_ctx = gigs_lib.current()
+        ctx.grad_sink = _st.grad_sink
         ctx.save_for_backward(colors_precomp, normal, albedo, roughness, metallic, means3D, scales, rotations,
                               cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -730,6 +734,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 out_normal_view, out_pos)
 
     @staticmethod
+    @gigs_lib.with_forward_context
     def backward(ctx, grad_out_color, gard_radii=None, grad_out_opacity=None, grad_depth=None,
                  grad_out_normal=None, grad_out_albedo=None, grad_out_roughness=None, grad_out_metallic=None,
                  grad_out_normal_view=None, grad_out_pos=None):
@@ -752,17 +757,21 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_out_normal, grad_out_albedo, grad_out_roughness, grad_out_metallic, geomBuffer, binningBuffer,
             imgBuffer, num_rendered, raster_settings.debug,
         )
-        if raster_settings.debug:
-            cpu_args = cpu_deep_copy_tuple(args)
-            try:
-                res = _C.rasterize_gaussians_backward(*args)
-            except Exception as ex:
-                torch.save(cpu_args, "snapshot_bw.dump")
-                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
-                raise ex
-        else:
-            res = _rasterize_gaussians_backward(*args, image_size=(raster_settings.image_height,
-                                                                   raster_settings.image_width))
+        prev_sink, _st.grad_sink = _st.grad_sink, (ctx.grad_sink if ctx.grad_sink is not None else _st.grad_sink)
+        try:
+            if raster_settings.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    res = _C.rasterize_gaussians_backward(*args)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise ex
+            else:
+                res = _rasterize_gaussians_backward(*args, image_size=(raster_settings.image_height,
+                                                                       raster_settings.image_width))
+        finally:
+            _st.grad_sink = prev_sink
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_normal, grad_albedo, grad_roughness,
          grad_metallic, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations) = res
         return (grad_means3D, grad_means2D, grad_opacities, grad_normal, grad_albedo, grad_roughness,

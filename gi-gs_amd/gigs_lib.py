@@ -7,6 +7,7 @@ oracle/ is test infrastructure and is never imported from here.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 import threading
 
@@ -364,3 +365,18 @@ def set_options(**kw) -> Context:
     """The same, for good (scripts and tools): replaces this thread's current context by the derived one."""
     _tls.ctx = current().derive(**kw)
     return _tls.ctx
+
+
+def with_forward_context(backward):
+    """Decorator for `torch.autograd.Function.backward` (below `@staticmethod`).  autograd runs backward nodes on its own
+    device thread, where this module's per-thread current context is not the caller's: a forward stores
+    `ctx.lib_ctx = gigs_lib.current()` and the decorated backward runs under `use(ctx.lib_ctx)` -- the backward belongs to the
+    library context its forward ran with, whichever thread executes it."""
+    @functools.wraps(backward)
+    def wrapper(ctx, *grads):
+        lc = getattr(ctx, "lib_ctx", None)
+        if lc is None:
+            return backward(ctx, *grads)
+        with use(lc):
+            return backward(ctx, *grads)
+    return wrapper

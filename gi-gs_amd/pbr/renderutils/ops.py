@@ -74,10 +74,12 @@ class _specular_cubemap(torch.autograd.Function):
                                "specular_cubemap_fwd_w")
         ctx.save_for_backward(bounds)
         ctx.tables = tables
+        ctx.lib_ctx = gigs_lib.current()  # for the backward, which autograd runs on its own thread
         ctx.res, ctx.roughness, ctx.theta_cutoff = res, roughness, costheta_cutoff
         return out
 
     @staticmethod
+    @gigs_lib.with_forward_context
     def backward(ctx, dout):
         (bounds,) = ctx.saved_tensors
         d = _gpu(dout, "dout")
@@ -145,9 +147,11 @@ class _specular_cubemap_normalized(torch.autograd.Function):
                            "specular_cubemap_fwd_w")
         ctx.save_for_backward(bounds, wsum)
         ctx.tables, ctx.res = tables, res
+        ctx.lib_ctx = gigs_lib.current()
         return out
 
     @staticmethod
+    @gigs_lib.with_forward_context
     def backward(ctx, dout):
         bounds, wsum = ctx.saved_tensors
         if len(ctx.tables) > 3 and ctx.tables[3] is not None:
@@ -190,10 +194,12 @@ class _specular_levels(torch.autograd.Function):
             gigs_lib.check(_lib.gigs_specular_cubemap_multi_w(gigs_lib.ctx_ptr(), len(cs), C.cast(arr, C.c_void_p), 0, _stream()),
                            "specular_cubemap_multi_w")
         ctx.meta = meta
+        ctx.lib_ctx = gigs_lib.current()
         ctx.shapes = [c.shape[1] for c in cs]
         return tuple(outs)
 
     @staticmethod
+    @gigs_lib.with_forward_context
     def backward(ctx, *douts):
         import ctypes as C
         dev = next(d for d in douts if d is not None).device

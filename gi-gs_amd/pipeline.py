@@ -1236,6 +1236,8 @@ def _close_stepper(self):
         w.close()
     if getattr(self, "whole", None) is not None:
         self.whole.close()
+    if getattr(self, "geom_cache", None) is not None:
+        self.geom_cache.invalidate()  # the per-view entries (tile lists, occlusion planes, hit lists): device memory
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     if getattr(self, "_captured", False):  # piecewise path: the two graphed callables

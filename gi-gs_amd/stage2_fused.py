@@ -89,12 +89,14 @@ class _Stage2Fused(torch.autograd.Function):
                               metallic_map if use_metallic else None, lut, diffuse, d_direct_u, d_irr_u, abd,
                               acc4, *specular)
         ctx.cfg = cfg
+        ctx.lib_ctx = gigs_lib.current()
         ctx.need_light = (ctx.needs_input_grad[12], [ctx.needs_input_grad[13 + i] for i in range(len(specular))])
         loss = loss.reshape(())
         ctx.mark_non_differentiable(render_rgb, render_direct, IRR)
         return loss, render_rgb, render_direct, IRR
 
     @staticmethod
+    @gigs_lib.with_forward_context
     def backward(ctx, g_loss, *_unused):
         (normals_view, view_dirs, albedo_map, roughness_map, mask_u8, mask_f, occlusion, metallic_map, lut, diffuse,
          d_direct_u, d_irr_u, abd, acc4, *specular) = ctx.saved_tensors

@@ -923,3 +923,36 @@ def test_long_runs_of_identical_depths_sort_in_bounded_time(orc, mode, monkeypat
     cam = scenes.orbit_camera(1, 6, 160, 128)
     _, _, res, _ = check_forward(orc, sc, cam, tag="identical depths " + mode + " ")
     assert res[0] > 4500
+
+
+def test_backward_runs_with_the_context_and_sink_of_its_forward(monkeypatch):
+    """autograd executes backward nodes on its own device thread, where the per-thread current library context and the
+    per-thread scopes of the operator module are not the caller's.  The node carries both from its forward
+    (gigs_lib.with_forward_context): gigs_backward receives the context the forward ran with -- even when backward() is
+    called after the `with` block has ended -- and writes into the gradient sink that was active at the forward."""
+    dgr = _dgr()
+    lib = gigs_lib.lib()
+    sc, cam = small_scene(P=1500, sh_degree=1, W=96, H=64, scale_mu=0.06)
+    seen = []
+    real = lib.gigs_backward
+
+    def spy(ctx_ptr, *a):
+        seen.append(ctx_ptr)
+        return real(ctx_ptr, *a)
+    monkeypatch.setattr(lib, "gigs_backward", spy)
+    ctx = gigs_lib.current().derive(pre_bwd_sh_skip=0, gi_march="exact")
+    assert ctx.ptr != gigs_lib.current().ptr
+    t = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+    sink = {"means3D": torch.empty_like(t["means3D"]), "albedo": torch.empty_like(t["albedo"])}
+    st = settings(dgr, cam, 1)
+    with gigs_lib.use(ctx), dgr.grad_sink(sink):
+        out = dgr.GaussianRasterizer(st)(t["means3D"], torch.zeros_like(t["means3D"], requires_grad=True), t["opacities"], t["normal"],
+                                         t["albedo"], t["roughness"], t["metallic"], shs=t["shs"], scales=t["scales"],
+                                         rotations=t["rotations"])
+    assert gigs_lib.current().ptr != ctx.ptr
+    (out[0].sum() + out[7].sum()).backward()   # outside both scopes, on autograd's thread
+    torch.cuda.synchronize()
+    assert seen == [ctx.ptr], (seen, ctx.ptr)
+    # AccumulateGrad may clone a gradient that something else references: compare values with the sink's
+    assert torch.equal(t["means3D"].grad, sink["means3D"]) and torch.equal(t["albedo"].grad, sink["albedo"])
+    assert float(sink["albedo"].abs().sum()) > 0
