@@ -51,8 +51,9 @@ const char* gigs_build_arch(void);
  * caller owns, so that two rasterizer instances (or two streams) of one process do not see each other:
  * every entry point that reads such state takes a `gigs_ctx*` first.  NULL = the default context: the
  * options below as the environment gave them when the library was first used (parsed ONCE, immutable
- * afterwards), no asynchronous binning, no event.  A context may be used by one thread at a time;
- * different contexts are independent (what the library itself caches process-wide -- ray tables, texel
+ * afterwards), no asynchronous binning, no event.  Calls only READ their context, so any number of threads
+ * and streams may use one concurrently; the gigs_ctx_set_* functions must not race with calls that use it.
+ * Different contexts are independent (what the library itself caches process-wide -- ray tables, texel
  * tables, temp-storage sizes -- is keyed by its inputs and never modified once built).
  * The in-library profile session (gigs_profile_begin/end, a bench.py diagnostic) is the one process-wide
  * facility left. */
