@@ -694,10 +694,11 @@ def run(args):
                                      "bound": "valu", "achieved": round(valu_frac * 1024 * 2.4, 1), "peak": round(1024 * 2.4, 1),
                                      "unit": "G VALU-active SIMD cycles/s", "frac": round(valu_frac, 4)})
             if dom in ("ssao", "ssr"):
-                roofline["note"] = ("dominant kernel by time; contract fields are its HBM roofline (algorithmic bytes / duration), "
-                                    "which does not bind it: its z-plane lookups are served by L2/L1 (the plane is 2.5 MB) and most "
-                                    "are skipped by the certification table in LDS, so the march is bound by fp32 VALU issue "
-                                    "(`limiter`; DESIGN.md section 5)")
+                roofline["note"] = ("dominant kernel by time; bound / achieved / peak / frac are the roof that binds it, fp32 VALU "
+                                    "issue (VALU-active SIMD cycles of its instruction stream, from the committed PMC pass, over this "
+                                    "run's live duration, against 1024 SIMDs x 2.4 GHz); its HBM roofline (algorithmic bytes / duration: "
+                                    "hbm_*) does not: the z-plane lookups are served by L2 / L1 (the plane is 2.5 MB) and most are "
+                                    "skipped by the certification table in LDS (DESIGN.md section 5)")
         cpu = parity_rep = None
         vi0 = args.warmup % n_views
         if not args.no_cpu_baseline and world == 1:
