@@ -956,3 +956,90 @@ def test_backward_runs_with_the_context_and_sink_of_its_forward(monkeypatch):
     # AccumulateGrad may clone a gradient that something else references: compare values with the sink's
     assert torch.equal(t["means3D"].grad, sink["means3D"]) and torch.equal(t["albedo"].grad, sink["albedo"])
     assert float(sink["albedo"].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("case", ["default", "ragged_delta", "nan_radiance"])
+def test_ssr_hit_list_gather_equals_the_march(case):
+    """gigs_ssr_hits / gigs_ssr_apply (frozen-geometry reuse): the hit list recorded by the march -- count per (pixel, wave),
+    exclusive prefix, fill -- and the gather over it reproduce gigs_ssr_ex bit for bit, also for other radiance than the one
+    the list was recorded with (the hits depend on normals and positions only: forward.cu:796-829), on ragged images, other
+    ray sets, with NaN / Inf radiance, and with a capacity that is too small (entries beyond it dropped, total reported)."""
+    import ctypes as C
+
+    import pipeline
+    dgr = _dgr()
+    lib = gigs_lib.lib()
+    if case == "ragged_delta":
+        sc, cam = scenes.surface_scene(P=30_000, sh_degree=1, seed=7, scale_mu=0.02), scenes.orbit_camera(2, 9, 333, 251, radius=3.3)
+        gi = dict(scenes.GI_DEFAULTS, delta=0.125, start=4, radius=1.2)
+    else:
+        sc, cam = scenes.surface_scene(P=40_000, sh_degree=1, seed=11, scale_mu=0.02), scenes.orbit_camera(1, 7, 320, 240, radius=3.4)
+        gi = scenes.GI_DEFAULTS
+    g = {k: tt(sc[k]) for k in GAUSS_KEYS}
+    camt = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    W, H = cam["image_width"], cam["image_height"]
+    N = W * H
+    fx, fy = focal(cam)
+    with torch.no_grad():
+        res = pipeline.render(camt, g, 1, torch.zeros(3, device=DEV), dict(scenes.GI_DEFAULTS, start=16))
+        out, _, _ = pipeline.rasterize(camt, g, 1, torch.zeros(3, device=DEV), dict(scenes.GI_DEFAULTS, start=16))
+    nrm, posf = res["out_normal_view"].contiguous(), out[11].contiguous()
+    alb, rough, metal = res["albedo_map"].contiguous(), res["roughness_map"].contiguous(), res["metallic_map"].contiguous()
+    F0 = torch.full((3, H, W), 0.04, device=DEV)
+    rgb1 = alb.clamp(0, 1).clone()
+    if case == "nan_radiance":
+        rgb1[0, H // 2 - 5:H // 2 + 5, :] = float("inf")
+        rgb1[2, :, W // 2 - 4:W // 2 + 4] = float("nan")
+    torch.manual_seed(3)
+    rgb2 = torch.rand(3, H, W, device=DEV)
+    a = (W, H, float(fx), float(fy), float(gi["radius"]), float(gi["bias"]), float(gi["thick"]), float(gi["delta"]), int(gi["step"]), int(gi["start"]))
+    s = torch.cuda.current_stream().cuda_stream
+    scratch = torch.empty(int(lib.gigs_gi_scratch_bytes(W, H)) or 1, dtype=torch.uint8, device=DEV)
+    new3 = lambda: torch.empty(3, H, W, device=DEV)  # noqa: E731
+
+    def march(rgb):
+        col, abd = new3(), new3()
+        gigs_lib.check(lib.gigs_ssr_ex(None, *a, nrm.data_ptr(), posf.data_ptr(), rgb.data_ptr(), alb.data_ptr(), rough.data_ptr(),
+                                       metal.data_ptr(), F0.data_ptr(), col.data_ptr(), abd.data_ptr(), scratch.data_ptr(), s), "ssr_ex")
+        return col, abd
+
+    counts = torch.zeros(4 * N, dtype=torch.int32, device=DEV)
+    offsets = torch.zeros(4 * N + 1, dtype=torch.int32, device=DEV)
+    c1, a1 = new3(), new3()
+    gigs_lib.check(lib.gigs_ssr_hits(None, *a, nrm.data_ptr(), posf.data_ptr(), rgb1.data_ptr(), alb.data_ptr(), rough.data_ptr(),
+                                     metal.data_ptr(), F0.data_ptr(), c1.data_ptr(), a1.data_ptr(), 1, counts.data_ptr(), None, None, 0,
+                                     scratch.data_ptr(), s), "ssr_hits count")
+    torch.cumsum(counts, 0, dtype=torch.int32, out=offsets[1:])
+    total = int(offsets[-1])
+    assert total > 1000, "no ray of the test view hits anything"
+    entries = torch.full((total, 2), -1, dtype=torch.int32, device=DEV)
+    c2, a2 = new3(), new3()
+    gigs_lib.check(lib.gigs_ssr_hits(None, *a, nrm.data_ptr(), posf.data_ptr(), rgb1.data_ptr(), alb.data_ptr(), rough.data_ptr(),
+                                     metal.data_ptr(), F0.data_ptr(), c2.data_ptr(), a2.data_ptr(), 2, None, offsets.data_ptr(),
+                                     entries.data_ptr(), total, scratch.data_ptr(), s), "ssr_hits fill")
+    assert int((entries < 0).sum()) == 0 and int(entries[:, 0].max()) < N  # every slot written, hit pixels inside the image
+    ref1 = march(rgb1)
+    for x, y in ((c1, ref1[0]), (a1, ref1[1]), (c2, ref1[0]), (a2, ref1[1])):  # the recording passes give the march's outputs
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    for rgb in (rgb1, rgb2):
+        col, abd = new3(), new3()
+        gigs_lib.check(lib.gigs_ssr_apply(W, H, float(gi["delta"]), offsets.data_ptr(), entries.data_ptr(), nrm.data_ptr(), posf.data_ptr(),
+                                          rgb.data_ptr(), alb.data_ptr(), metal.data_ptr(), F0.data_ptr(), col.data_ptr(), abd.data_ptr(), s),
+                       "ssr_apply")
+        want = march(rgb)
+        assert torch.equal(col.view(torch.int32), want[0].view(torch.int32)) and torch.equal(abd.view(torch.int32), want[1].view(torch.int32))
+    if case == "nan_radiance":
+        assert int(torch.isnan(ref1[0]).sum()) > 0
+    # too small a buffer: nothing is written beyond it
+    cap = total // 3
+    guard = torch.full((total, 2), -7, dtype=torch.int32, device=DEV)
+    gigs_lib.check(lib.gigs_ssr_hits(None, *a, nrm.data_ptr(), posf.data_ptr(), rgb1.data_ptr(), alb.data_ptr(), rough.data_ptr(),
+                                     metal.data_ptr(), F0.data_ptr(), c2.data_ptr(), a2.data_ptr(), 2, None, offsets.data_ptr(),
+                                     guard.data_ptr(), cap, scratch.data_ptr(), s), "ssr_hits fill (small)")
+    torch.cuda.synchronize()
+    assert int((guard[cap:] != -7).sum()) == 0 and torch.equal(guard[:cap], entries[:cap])
+    # recorded by the default march only
+    with gigs_lib.options(gi_march="exact") as cx:
+        rc = lib.gigs_ssr_hits(cx.ptr, *a, nrm.data_ptr(), posf.data_ptr(), rgb1.data_ptr(), alb.data_ptr(), rough.data_ptr(), metal.data_ptr(),
+                               F0.data_ptr(), c2.data_ptr(), a2.data_ptr(), 1, counts.data_ptr(), None, None, 0, scratch.data_ptr(), s)
+    assert rc < 0 and b"default march" in lib.gigs_last_error()
