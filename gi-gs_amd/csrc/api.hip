@@ -509,7 +509,7 @@ int gigs_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_user, g
     StageScope sc(kBlendFwd, s);
     gigs::launch_blend_fwd(a, geom, bin, img, out_color, out_opacity, out_depth, out_normal,
                            out_normal_view, out_pos, out_albedo, out_roughness, out_metallic, opt.blend_cull,
-                           (size_t)num_rendered, s);
+                           (size_t)num_rendered, s, cx.reuse_binning != 0);
   }
   STAGE_CHECK("render");
   return num_rendered;

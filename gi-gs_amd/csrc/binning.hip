@@ -262,7 +262,7 @@ bin_prefix_groups_kernel(int groups, int T, uint32_t* __restrict__ bin_hist, uin
 
 // exclusive scan of the tile totals -> ranges (clamped to the capacity), R and the overflow flag.  One workgroup.
 __global__ void __launch_bounds__(1024)
-bin_prefix_tiles_kernel(int T, unsigned capacity, const uint32_t* __restrict__ totals, uint2* __restrict__ ranges,
+bin_prefix_tiles_kernel(int T, unsigned capacity, unsigned P, const uint32_t* __restrict__ totals, uint2* __restrict__ ranges,
                         uint32_t* __restrict__ tile_start, uint32_t* __restrict__ counters,
                         uint32_t* __restrict__ user_counters) {
   __shared__ uint32_t s_sum[1024];
@@ -290,6 +290,10 @@ bin_prefix_tiles_kernel(int T, unsigned capacity, const uint32_t* __restrict__ t
     const uint32_t R = s_sum[1023];
     counters[0] = R;
     counters[1] = R > capacity ? R : 0u;
+    // what these lists were made for: a later forward that REUSES them (gigs_ctx_set_reuse_binning) blends them only if its
+    // own Gaussian count and capacity are these (blend.hip: otherwise every tile is treated as empty -- no index can be out of range)
+    counters[2] = P;
+    counters[3] = capacity;
     if (user_counters) { user_counters[0] = R; user_counters[1] = R > capacity ? R : 0u; }
   }
 }
@@ -787,7 +791,7 @@ void launch_bin_prefix(int P, int T, unsigned capacity, const ImageState& img, u
   uint32_t* totals = img.bin_hist + (size_t)(kBinGroups) * T;       // carved with two extra rows (ImageState)
   uint32_t* tile_start = img.bin_hist + (size_t)(kBinGroups + 1) * T;
   hipLaunchKernelGGL(bin_prefix_groups_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, bin_groups(P), T, img.bin_hist, totals);
-  hipLaunchKernelGGL(bin_prefix_tiles_kernel, dim3(1), dim3(1024), 0, s, T, capacity, totals, img.ranges, tile_start,
+  hipLaunchKernelGGL(bin_prefix_tiles_kernel, dim3(1), dim3(1024), 0, s, T, capacity, (unsigned)P, totals, img.ranges, tile_start,
                      img.bin_counters, user_counters);
 }
 

@@ -250,7 +250,7 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
                  const float* __restrict__ viewmatrix, const float* __restrict__ bg_color,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, BlendOut o,
                  int argmax_depth, int inference, uint8_t* __restrict__ hit_mask, size_t hit_stride, int cull,
-                 const uint32_t* __restrict__ tile_order) {
+                 const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ reuse_guard, uint2 reuse_expect) {
   // Each wave walks the tile's list on its own (no workgroup barrier anywhere): the time of a tile is the
   // time of its busiest quadrant, not the sum over batches of the slowest quadrant of each batch, and a wave
   // whose 64 pixels are saturated leaves at once.  The list is consumed in chunks of 64 instances, one per
@@ -269,7 +269,12 @@ blend_fwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   asm volatile("" : "+v"(pixfx), "+v"(pixfy));  // not to be rematerialised (2 v_cvt per survivor) inside the walk
   bool done = !inside;
 
-  const uint2 range = ranges[tile];
+  uint2 range = ranges[tile];
+  // reused lists (gigs_ctx_set_reuse_binning): blended only if they were made for this Gaussian count and capacity --
+  // otherwise the tile is empty (background), and no stale index is ever dereferenced
+  if (reuse_guard && (reuse_guard[2] != reuse_expect.x || reuse_guard[3] != reuse_expect.y || range.y > reuse_expect.y ||
+                      range.x > range.y))
+    range = make_uint2(0u, 0u);
   const int n = (int)(range.y - range.x);
   // the kernel ends when its longest tile does: waves of long tiles get the issue priority on their SIMD
   if (n > kLongTile) __builtin_amdgcn_s_setprio(3);
@@ -417,13 +422,15 @@ void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& 
                       const ImageState& im, float* out_color, float* out_opacity,
                       float* out_depth, float* out_normal, float* out_normal_view, float* out_pos,
                       float* out_albedo, float* out_roughness, float* out_metallic, int cull, size_t hit_stride,
-                      hipStream_t s) {
+                      hipStream_t s, bool reused_lists) {
   BlendOut o{out_color, out_opacity, out_depth, out_normal, out_normal_view,
              out_pos, out_albedo, out_roughness, out_metallic};
   // cull = 0 (gigs_options.blend_cull) disables the quadrant cull (diagnostic: the outputs must not change by a bit)
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(a.gx * a.gy), dim3(GIGS_TILE), 0, s, a.W, a.H, a.gx,
                      im.ranges, b.point_list, g.brec, a.viewmatrix, a.background, im.n_contrib,
-                     im.final_T, o, a.argmax_depth, a.inference, b.hit_mask, hit_stride, cull, im.tile_order);
+                     im.final_T, o, a.argmax_depth, a.inference, b.hit_mask, hit_stride, cull, im.tile_order,
+                     reused_lists ? (const uint32_t*)im.bin_counters : (const uint32_t*)nullptr,
+                     make_uint2((unsigned)a.P, (unsigned)hit_stride));
 }
 
 // ------------------------------------------------------------------------------------------

@@ -296,7 +296,7 @@ void launch_blend_fwd(const FwdArgs& a, const GeomState& g, const BinningState& 
                       const ImageState& im, float* out_color, float* out_opacity,
                       float* out_depth, float* out_normal, float* out_normal_view, float* out_pos,
                       float* out_albedo, float* out_roughness, float* out_metallic, int cull, size_t hit_stride,
-                      hipStream_t s);  // hit_stride = the R the binning chunk was carved for
+                      hipStream_t s, bool reused_lists = false);  // hit_stride = the R the binning chunk was carved for
 
 struct BwdArgs {
   int P, D, M, R, W, H;

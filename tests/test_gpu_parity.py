@@ -1043,3 +1043,40 @@ def test_ssr_hit_list_gather_equals_the_march(case):
         rc = lib.gigs_ssr_hits(cx.ptr, *a, nrm.data_ptr(), posf.data_ptr(), rgb1.data_ptr(), alb.data_ptr(), rough.data_ptr(), metal.data_ptr(),
                                F0.data_ptr(), c2.data_ptr(), a2.data_ptr(), 1, counts.data_ptr(), None, None, 0, scratch.data_ptr(), s)
     assert rc < 0 and b"default march" in lib.gigs_last_error()
+
+
+def test_reused_tile_lists_equal_a_full_forward_and_are_guarded(orc):
+    """gigs_ctx_set_reuse_binning (dgr.view_cache): a forward that reuses the tile lists of an earlier forward of the same
+    view and geometry -- preprocess + blend only -- gives that forward's planes bit for bit, with other material attributes
+    the planes of a complete forward of THOSE; and lists made for another Gaussian count are not blended at all (every tile
+    empty: background), instead of dereferencing stale indices."""
+    dgr = _dgr()
+    sc = scenes.surface_scene(P=20_000, sh_degree=1, seed=13, scale_mu=0.025)
+    cam = scenes.orbit_camera(1, 5, 251, 203, radius=3.4)
+    bg = (0.2, 0.4, 0.1)
+    full = hip_raw_forward(dgr, sc, cam, bg=bg)
+    R = full[0]
+    slot = dgr.ViewSlot(DEV)
+    with dgr.AsyncBinning(int(1.5 * R), DEV):
+        with dgr.view_cache(slot, "record"):
+            rec = hip_raw_forward(dgr, sc, cam, bg=bg)
+        with dgr.view_cache(slot, "replay"):
+            rep = hip_raw_forward(dgr, sc, cam, bg=bg)
+        sc2 = dict(sc, albedo=np.ascontiguousarray(1.0 - sc["albedo"]), roughness=np.ascontiguousarray(sc["roughness"] * 0.5))
+        with dgr.view_cache(slot, "replay"):
+            rep2 = hip_raw_forward(dgr, sc2, cam, bg=bg)
+        # another cloud (fewer Gaussians) against the same lists: guarded
+        sc3 = scenes.surface_scene(P=12_000, sh_degree=1, seed=14, scale_mu=0.025)
+        with dgr.view_cache(slot, "replay"):
+            bad = hip_raw_forward(dgr, sc3, cam, bg=bg)
+    want2 = hip_planes(hip_raw_forward(dgr, sc2, cam, bg=bg))
+    for name, a, b in (("record", hip_planes(full), hip_planes(rec)), ("replay", hip_planes(full), hip_planes(rep)),
+                       ("replay, other materials", want2, hip_planes(rep2))):
+        for k in PLANES + ["radii"]:
+            x, y = a[k], b[k]
+            np.testing.assert_array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                          y.view(np.uint32) if y.dtype == np.float32 else y, err_msg=name + " " + k)
+    hb = hip_planes(bad)
+    assert np.all(hb["opacity"] == 0.0) and np.all(hb["albedo"] == 0.0)
+    for c in range(3):
+        assert np.all(hb["color"][c] == np.float32(bg[c]))
