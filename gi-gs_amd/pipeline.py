@@ -370,12 +370,14 @@ class GeometryCache:
     and the light only, so once Adam's residual momentum has died out positions, covariances, opacities and normals stop
     changing bit for bit -- and with them, per view, the tile lists (`ranges`, `point_list`: the whole binning), the
     operator's occlusion plane (the SSAO march) and the indirect-light hit list.  288 GB of HBM hold them for a whole
-    training set (~18 MB per 800 x 800 view without the hit list).
+    training set (~18 MB per 800 x 800 view, ~113 MB with the hit list of the C2 scene).
 
     Protocol.  The optimizer step reports whether it moved a bit of a geometry group (gigs_adam_step_watch -> `flag_dev`,
     copied to pinned memory by a node of the update graph).  A view is RECORDED by a complete step (dgr.view_cache: the
-    forward bins into the slot's chunks, SSAO writes the slot's plane; `store` copies the parts to the view's entry) and
-    REPLAYED from its entry afterwards (`load` -> slot; preprocess + blend only, no binning, no SSAO march).  The host
+    forward bins into the slot's chunks, SSAO writes the slot's plane; `store` copies the parts to the view's entry),
+    REPLAYED from its entry afterwards (`load` -> slot; preprocess + blend only, no binning, no SSAO march) -- the first
+    replay still marches the indirect light and records its hit list ("replay_rec": a drifting phase, whose recordings are
+    never kept, pays nothing for hit lists), later ones gather at the recorded hits ("replay").  The host
     learns about update k only while step k + 1 runs, so a replay is optimistic: if the flag read after the forward says
     the previous update moved geometry, every entry is dropped and the step is repeated as a recording before anything of
     it is consumed (the update graph has not been replayed yet) -- the same repeat protocol as a binning overflow.
@@ -397,9 +399,8 @@ class GeometryCache:
         self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.stats = dict(recorded=0, replayed=0, repeated=0, invalidated=0, hit_lists=0)
         self.recorded_R: Dict = {}
-        import gigs_lib as _gl
         # the hit list of the indirect-light march is recorded by the default march only (gigs_ssr_hits)
-        self.hit_lists = os.environ.get("GIGS_SSR_HIT_LIST", "1") == "1" and _gl.current().option("gi_march") == 4
+        self.hit_lists = os.environ.get("GIGS_SSR_HIT_LIST", "1") == "1" and gigs_lib.current().option("gi_march") == 4
 
     @staticmethod
     def view_key(cam: Dict):
@@ -488,7 +489,7 @@ class WholeStepGraph:
 
     def __init__(self, owner: "Stage2Step", cam: Dict, g: Dict[str, torch.Tensor], cache: Optional["GeometryCache"] = None,
                  mode: Optional[str] = None):
-        self.cache, self.mode = cache, mode  # frozen-geometry variant: "record" / "replay" under dgr.view_cache(cache.slot, mode)
+        self.cache, self.mode = cache, mode  # frozen-geometry variant: "record" / "replay_rec" / "replay" (dgr.view_cache)
         # a weak reference: the stepper owns its WholeStepGraphs, not the other way round -- no reference cycle, so the
         # graph execs die where the code says (close(), or the owner's last reference going away), never "whenever the
         # cyclic collector happens to run" (the round-3 host segfault in hip::Graph::UpdateStreams: DESIGN.md section 5)
