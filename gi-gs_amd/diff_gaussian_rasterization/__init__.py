@@ -19,6 +19,7 @@ live on a HIP device and the shared library must be present.
 from __future__ import annotations
 
 import ctypes as C
+import contextlib
 import os
 import sys
 import threading
@@ -79,6 +80,7 @@ class _Scopes(threading.local):
     THREAD like the library contexts of gigs_lib: two Python threads driving two streams do not see each other's."""
     pool = None         # OutputPool
     after_blend = None  # callable
+    prefetch_events = None  # (step begin, blend begin) events of the drop-in light prefetch
     grad_sink = None    # {name: tensor}
     async_ = None       # AsyncBinning
     view = None         # (ViewSlot, "record" | "replay" | "replay_rec") while a frozen-geometry view cache is active
@@ -815,10 +817,27 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = torch.Tensor([])
 
-        (color, radii, opacity_map, depth, out_normal, albedo_map, roughness_map, metallic_map,
-         out_normal_view, _) = _RasterizeGaussians.apply(
-            means3D, means2D, opacities, normal, albedo, roughness, metallic, shs, colors_precomp, scales,
-            rotations, cov3D_precomp, raster_settings)
+        # drop-in overlap: a light whose pre-filter the caller will ask for next (pbr.light.CubemapLight.build_mips, train.py:340)
+        # starts it on its side stream when this forward's blend kernel starts -- unless a stepper of this package drives the
+        # light itself (after_blend) or the call is being captured into a graph
+        pre = ()
+        if _st.after_blend is None and gigs_lib.prefetchers and means3D.is_cuda and not torch.cuda.is_current_stream_capturing():
+            pre = [x for x in list(gigs_lib.prefetchers) if x.wants_prefetch()]
+        if pre:
+            if _st.prefetch_events is None:
+                _st.prefetch_events = (torch.cuda.Event(), torch.cuda.Event())
+            step_ev, blend_ev = _st.prefetch_events
+            step_ev.record()
+            lib_scope = gigs_lib.use(gigs_lib.current().derive(blend_event=blend_ev))
+        else:
+            lib_scope = contextlib.nullcontext()
+        with lib_scope:
+            (color, radii, opacity_map, depth, out_normal, albedo_map, roughness_map, metallic_map,
+             out_normal_view, _) = _RasterizeGaussians.apply(
+                means3D, means2D, opacities, normal, albedo, roughness, metallic, shs, colors_precomp, scales,
+                rotations, cov3D_precomp, raster_settings)
+        for x in pre:
+            x.prefetch(step_ev, blend_ev)
         if _st.after_blend is not None:
             # gigs-hip extension: the blend kernel is queued, the VALU-bound SSAO march is next -- the point at
             # which a caller can start independent memory-bound work on another stream (see after_blend)

@@ -316,6 +316,13 @@ class Context:
 _default_opts = None
 _tls = threading.local()
 
+# Objects with independent work the rasterizer's forward may start beside its blend kernel (pbr.light.CubemapLight registers
+# itself: its pre-filter is prefetched on a side stream, see CubemapLight.prefetch).  The protocol: `wants_prefetch()` ->
+# bool, `prefetch(step_event, blend_event)`.
+import weakref  # noqa: E402
+
+prefetchers = weakref.WeakSet()
+
 
 def default_options() -> tuple:
     """The library's default options: the GIGS_* environment as it was when the library first read it."""

@@ -105,6 +105,9 @@ class CubemapLight(nn.Module):
         base = torch.rand(6, base_res, base_res, 3, dtype=torch.float32, device=device) * scale + bias
         self.base = nn.Parameter(base)
         self.register_parameter("env_base", self.base)
+        self._pre, self._wanted, self._prefetch_ok, self._side, self._ready = None, False, True, None, None
+        self.prefetch_stats = dict(started=0, adopted=0, discarded=0)
+        gigs_lib.prefetchers.add(self)
 
     def xfm(self, mtx) -> None:
         self.mtx = mtx
@@ -122,7 +125,77 @@ class CubemapLight(nn.Module):
         )
 
     def build_mips(self, cutoff: float = 0.99) -> None:
-        self.specular = [self.base]
+        pre, self._pre = self._pre, None
+        if not self.base.is_cuda or torch.cuda.is_current_stream_capturing():
+            self.specular, self.diffuse = self._build(cutoff)  # inside a graph capture: on the capturing stream
+            return
+        self._wanted = True  # the caller filters every iteration: the next rasterizer forward may start the next one early
+        main = torch.cuda.current_stream()
+        if pre is not None:
+            main.wait_event(pre["ready"])  # also when it is thrown away: the filter tables it may have built are complete
+            if pre["key"] != self._prefetch_key(cutoff):
+                # the base changed between the rasterizer's forward and this call (or the grad mode / cutoff did): this
+                # caller's order of calls does not suit the prefetch -- stop guessing
+                self.prefetch_stats["discarded"] += 1
+                self._prefetch_ok = False
+                pre = None
+            else:
+                self.prefetch_stats["adopted"] += 1
+        if pre is None:
+            # not prefetched: the same launches on the light's stream, in the caller's order (the stream waits for the
+            # caller's, the caller's for the result).  Every graph over `base` is built there, so `base`'s gradient
+            # accumulator belongs to that stream too: see prefetch()
+            side = self._side_stream()
+            side.wait_stream(main)
+            pre = self._build_on_side(cutoff)
+            main.wait_event(pre["ready"])
+        for t in [pre["diffuse"], *pre["specular"]]:
+            t.record_stream(main)
+        self.specular, self.diffuse = pre["specular"], pre["diffuse"]
+
+    # ---- drop-in overlap (gigs-hip extension; GIGS_LIGHT_PREFETCH=0 switches it off) ------------------------------------
+    # train.py:330-345 calls render() (the rasterizer, with its SSAO march) and THEN cubemap.build_mips(): op by op, the
+    # 0.3 ms GGX pre-filter and its 0.3 ms backward sit on the step's critical path.  They depend on `base` alone, which only
+    # the optimizer step changes, so the rasterizer's forward starts the filter the caller is about to ask for on this light's
+    # side stream, at the moment its own blend kernel starts (diff_gaussian_rasterization.GaussianRasterizer.forward); the
+    # build_mips() call that follows adopts the result if `base` is still the same tensor at the same version, under the same
+    # grad mode and cutoff, and waits for it on the caller's stream.  autograd runs a node's backward on the stream of its
+    # forward, so the filter's backward overlaps the rasterizer's backward the same way -- provided `base`'s gradient
+    # accumulator lives on the light's stream as well: it runs as soon as the filter's backward is queued, BEFORE the
+    # rasterizer's backward node, and one that lived on the caller's stream would make that stream wait for the filter's
+    # backward right there.  A light is prefetched only when its build_mips() was called since the previous rasterizer
+    # forward, and never again after a prefetch had to be thrown away: a caller with another order of calls pays for one
+    # wasted filter, not for one per iteration.
+    def _prefetch_key(self, cutoff):
+        return (id(self.base), self.base._version, float(cutoff), bool(torch.is_grad_enabled() and self.base.requires_grad))
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.base.device)
+            self._ready = torch.cuda.Event()
+        return self._side
+
+    def _build_on_side(self, cutoff):
+        key = self._prefetch_key(cutoff)
+        with torch.cuda.stream(self._side):
+            specular, diffuse = self._build(cutoff)
+            self._ready.record()
+        return dict(key=key, specular=specular, diffuse=diffuse, ready=self._ready)
+
+    def wants_prefetch(self) -> bool:
+        return (self._wanted and self._prefetch_ok and self._pre is None and self.base.is_cuda
+                and os.environ.get("GIGS_LIGHT_PREFETCH", "1") == "1")
+
+    def prefetch(self, step_event, blend_event, cutoff: float = 0.99) -> None:
+        self._wanted = False
+        side = self._side_stream()
+        side.wait_event(step_event)   # everything that wrote `base` (the optimizer step, clamp_) is in front of this event
+        side.wait_event(blend_event)  # start with the blend kernel: beside the sort passes the filter only slows them down
+        self._pre = self._build_on_side(cutoff)
+        self.prefetch_stats["started"] += 1
+
+    def _build(self, cutoff: float = 0.99):
+        specular = [self.base]
         diffuse_in = None
         if os.environ.get("GIGS_MIP_CHAIN", "1") == "1" and self.base.shape[3] == 3:
             n_levels, r = 0, self.base.shape[1]
@@ -130,28 +203,29 @@ class CubemapLight(nn.Module):
                 n_levels, r = n_levels + 1, r // 2
             if n_levels:
                 chain = _mip_chain.apply(self.base, n_levels)
-                self.specular = list(chain[:-1])  # the base as the node's output: its GGX gradient enters the chain's last step
+                specular = list(chain[:-1])  # the base as the node's output: its GGX gradient enters the chain's last step
                 diffuse_in = chain[-1]
         else:
-            while self.specular[-1].shape[1] > self.LIGHT_MIN_RES:
-                self.specular += [cubemap_mip.apply(self.specular[-1])]
-        n = len(self.specular)
+            while specular[-1].shape[1] > self.LIGHT_MIN_RES:
+                specular += [cubemap_mip.apply(specular[-1])]
+        n = len(specular)
         rough = [(idx / (n - 2)) * (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) + self.MIN_ROUGHNESS for idx in range(n - 1)] + [1.0]
-        coarsest = diffuse_in if diffuse_in is not None else self.specular[-1]
+        coarsest = diffuse_in if diffuse_in is not None else specular[-1]
         diffuse_first = os.environ.get("GIGS_LIGHT_DIFFUSE_LAST", "1") != "1"
+        diffuse = None
         if diffuse_first:
-            self.diffuse = diffuse_cubemap(coarsest)
+            diffuse = diffuse_cubemap(coarsest)
         # the levels are independent: one launch filters them all (and one launch back-propagates them all)
-        merged = specular_cubemap_levels(self.specular, rough, cutoff)
+        merged = specular_cubemap_levels(specular, rough, cutoff)
         if merged is not None:
-            self.specular = merged
             if not diffuse_first:
                 # created after the GGX node, the diffuse filter's backward runs BEFORE the GGX backward (autograd walks
                 # the later node first): 0.02 ms of short workgroups in front of the launch that floods every CU
-                self.diffuse = diffuse_cubemap(coarsest)
-            return
+                diffuse = diffuse_cubemap(coarsest)
+            return merged, diffuse
         if not diffuse_first:
-            self.diffuse = diffuse_cubemap(coarsest)
+            diffuse = diffuse_cubemap(coarsest)
         for idx in range(n - 1):
-            self.specular[idx] = specular_cubemap(self.specular[idx], rough[idx], cutoff)
-        self.specular[-1] = specular_cubemap(self.specular[-1], 1.0, cutoff)
+            specular[idx] = specular_cubemap(specular[idx], rough[idx], cutoff)
+        specular[-1] = specular_cubemap(specular[-1], 1.0, cutoff)
+        return specular, diffuse

@@ -775,3 +775,71 @@ def test_hipgraph_lifetime_is_deterministic(monkeypatch):
     assert np.isfinite(l1) and abs(float(o2["loss"]) - l1) <= 1e-6 * max(1.0, abs(l1))
     new.close()
     step.close()
+
+
+def test_drop_in_light_prefetch_is_adopted_and_changes_nothing(monkeypatch):
+    """The op-by-op caller of train.py:330-402 (render -> cubemap.build_mips() -> pbr_shading -> Gaussian_SSR -> loss):
+    from the second iteration on the rasterizer's forward starts the light's pre-filter on the light's side stream and
+    build_mips() adopts it (pbr/light.py::CubemapLight.prefetch) -- same loss, image and gradients as with
+    GIGS_LIGHT_PREFETCH=0, over optimizer steps that change the light between iterations; a caller that changes the light
+    between the rasterizer and build_mips() gets a correct, freshly built filter and no further prefetches."""
+    import pbr
+    import pipeline
+    sc = scenes.surface_scene(P=10_000, sh_degree=2, seed=9, scale_mu=0.025)
+    gi = scenes.GI_DEFAULTS
+    H, W = 176, 224
+    cams = [scenes.orbit_camera(i, 6, W, H, radius=3.5) for i in (1, 4)]
+    camts = [{k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    torch.manual_seed(1)
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    rays = pipeline.canonical_rays(cams[0], DEV)
+    vds = [pipeline.view_dirs_for(c, rays, DEV) for c in camts]
+
+    def run(prefetch):
+        monkeypatch.setenv("GIGS_LIGHT_PREFETCH", "1" if prefetch else "0")
+        torch.manual_seed(2)
+        light = pbr.CubemapLight(base_res=64, device=DEV)
+        g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        opt = torch.optim.SGD([light.base, g["albedo"]], lr=0.05)
+        step = pipeline.Stage2Step(light, lut, gi, 2, metallic=True, fused=False, graphs=False)
+        outs = []
+        for it in range(5):
+            opt.zero_grad(set_to_none=True)
+            o = step(camts[it % 2], g, gt, vds[it % 2])
+            torch.cuda.synchronize()
+            outs.append((float(o["loss"]), light.base.grad.clone(), g["albedo"].grad.clone(), o["render_rgb"].clone()))
+            opt.step()
+            with torch.no_grad():
+                light.clamp_(min=0.0)
+        return outs, light
+
+    ref, _ = run(False)
+    got, light = run(True)
+    assert light.prefetch_stats == dict(started=4, adopted=4, discarded=0), light.prefetch_stats
+    for (lr_, br, ar, rr), (lg, bg, ag, rg) in zip(ref, got):
+        assert abs(lr_ - lg) <= 2e-6 * max(1.0, abs(lr_))
+        torch.testing.assert_close(rg, rr, rtol=0, atol=2e-6)
+        assert rel_peak(bg.cpu().numpy(), br.cpu().numpy()) < 2e-3  # float-atomic sums: rounding differs from run to run
+        assert rel_peak(ag.cpu().numpy(), ar.cpu().numpy()) < 2e-3
+    assert abs(ref[0][0] - ref[2][0]) > 1e-7  # the optimizer did change the light / albedo between iterations
+
+    # a caller that touches the light between the rasterizer's forward and build_mips(): the stale prefetch is dropped
+    monkeypatch.setenv("GIGS_LIGHT_PREFETCH", "1")
+    torch.manual_seed(2)
+    light = pbr.CubemapLight(base_res=64, device=DEV)
+    g = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+    means2D = torch.zeros_like(g["means3D"], requires_grad=True)
+    light.build_mips()  # inline (nothing to adopt): the light now expects to be asked again
+    want = [t.detach().clone() for t in [light.diffuse, *light.specular]]
+    pipeline.rasterize(camts[0], g, 2, torch.zeros(3, device=DEV), gi, means2D=means2D)
+    assert light.prefetch_stats["started"] == 1
+    with torch.no_grad():
+        light.base.mul_(0.5)
+    light.build_mips()
+    assert light.prefetch_stats == dict(started=1, adopted=0, discarded=1)
+    for a, b in zip([light.diffuse, *light.specular], want):
+        torch.testing.assert_close(a, 0.5 * b, rtol=1e-5, atol=1e-7)  # the filter is linear in the base
+    pipeline.rasterize(camts[0], g, 2, torch.zeros(3, device=DEV), gi, means2D=means2D)
+    assert light.prefetch_stats["started"] == 1  # no further guesses for this light
+    torch.cuda.synchronize()
