@@ -843,3 +843,77 @@ def test_drop_in_light_prefetch_is_adopted_and_changes_nothing(monkeypatch):
     pipeline.rasterize(camts[0], g, 2, torch.zeros(3, device=DEV), gi, means2D=means2D)
     assert light.prefetch_stats["started"] == 1  # no further guesses for this light
     torch.cuda.synchronize()
+
+
+def test_two_steppers_on_two_host_threads_match_serial_runs():
+    """Two whole-step-graph steppers in one process, each driven by its own host thread on its own stream (own light, own
+    parameter tensors): the scopes of diff_gaussian_rasterization / activations are per thread and the library state per
+    context, so the concurrent runs reproduce the serial ones -- losses, images and gradients ('re-entrant per
+    stream').  Captures happen one thread at a time (capture mode thread_local), replays concurrently."""
+    import threading
+    import pbr
+    import pipeline
+    sc = scenes.surface_scene(P=10_000, sh_degree=2, seed=9, scale_mu=0.025)
+    gi = scenes.GI_DEFAULTS
+    H, W = 176, 224
+    cams = [scenes.orbit_camera(i, 6, W, H, radius=3.5) for i in (1, 4, 2)]
+    camts = [{k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    torch.manual_seed(1)
+    gt = torch.rand(3, H, W, device=DEV) * 0.5
+    lut = pbr.get_brdf_lut().to(DEV)
+    rays = pipeline.canonical_rays(cams[0], DEV)
+    vds = [pipeline.view_dirs_for(c, rays, DEV) for c in camts]
+    n_steps = 6
+
+    class Worker:
+        def __init__(self, k):
+            self.k, self.stream, self.out, self.err = k, torch.cuda.Stream(), [], None
+            torch.manual_seed(20 + k)
+            self.light = pbr.CubemapLight(base_res=64, device=DEV)
+            self.g = {key: tt(sc[key], grad=True) for key in GAUSS_KEYS}
+            with torch.cuda.stream(self.stream):
+                self.step = pipeline.Stage2Step(self.light, lut, gi, 2, metallic=True, fused=True, graphs=True)
+                self.one(0)  # capture
+                torch.cuda.synchronize()
+
+        def one(self, i):
+            for p in list(self.g.values()) + [self.light.base]:
+                p.grad = None
+            vi = (i + self.k) % len(camts)
+            o = self.step(camts[vi], self.g, gt, vds[vi])
+            self.stream.synchronize()
+            return (float(o["loss"]), self.g["albedo"].grad.clone(), self.light.base.grad.clone(), o["render_rgb"].clone())
+
+        def run(self, barrier=None):
+            try:
+                with torch.cuda.stream(self.stream):
+                    if barrier is not None:
+                        barrier.wait()
+                    self.out = [self.one(i) for i in range(n_steps)]
+            except BaseException as ex:  # noqa: BLE001 -- reported by the asserting thread
+                self.err = ex
+                if barrier is not None:
+                    barrier.abort()
+
+    workers = [Worker(0), Worker(1)]
+    for w in workers:  # serial reference runs
+        w.run()
+        assert w.err is None, w.err
+    serial = [w.out for w in workers]
+    barrier = threading.Barrier(2)
+    threads = [threading.Thread(target=w.run, args=(barrier,)) for w in workers]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for w, ref in zip(workers, serial):
+        assert w.err is None, w.err
+        for (ls, as_, bs, rs), (lc, ac, bc, rc) in zip(ref, w.out):
+            assert abs(ls - lc) <= 2e-6 * max(1.0, abs(ls))
+            torch.testing.assert_close(rc, rs, rtol=0, atol=2e-6)
+            assert rel_peak(ac.cpu().numpy(), as_.cpu().numpy()) < 2e-3
+            assert rel_peak(bc.cpu().numpy(), bs.cpu().numpy()) < 2e-3
+    assert abs(serial[0][0][0] - serial[1][0][0]) > 1e-7  # the two workers do render different things
+    for w in workers:
+        w.step.close()
