@@ -80,7 +80,7 @@ class _Scopes(threading.local):
     THREAD like the library contexts of gigs_lib: two Python threads driving two streams do not see each other's."""
     pool = None         # OutputPool
     after_blend = None  # callable
-    prefetch_events = None  # (step begin, blend begin) events of the drop-in light prefetch
+    prefetch_events = None  # {device: (step begin, blend begin)} events of the drop-in light prefetch
     grad_sink = None    # {name: tensor}
     async_ = None       # AsyncBinning
     view = None         # (ViewSlot, "record" | "replay" | "replay_rec") while a frozen-geometry view cache is active
@@ -824,10 +824,14 @@ class GaussianRasterizer(nn.Module):
         if _st.after_blend is None and gigs_lib.prefetchers and means3D.is_cuda and not torch.cuda.is_current_stream_capturing():
             pre = [x for x in list(gigs_lib.prefetchers) if x.wants_prefetch()]
         if pre:
+            pre = [x for x in pre if x.base.device == means3D.device]
+        if pre:
             if _st.prefetch_events is None:
-                _st.prefetch_events = (torch.cuda.Event(), torch.cuda.Event())
-            step_ev, blend_ev = _st.prefetch_events
-            step_ev.record()
+                _st.prefetch_events = {}
+            if means3D.device not in _st.prefetch_events:  # an event belongs to the device it is first recorded on
+                _st.prefetch_events[means3D.device] = (torch.cuda.Event(), torch.cuda.Event())
+            step_ev, blend_ev = _st.prefetch_events[means3D.device]
+            step_ev.record(torch.cuda.current_stream(means3D.device))
             lib_scope = gigs_lib.use(gigs_lib.current().derive(blend_event=blend_ev))
         else:
             lib_scope = contextlib.nullcontext()
