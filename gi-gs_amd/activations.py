@@ -22,6 +22,8 @@ RAW = ("f_dc", "f_rest", "opacity", "normal", "albedo", "roughness", "metallic",
 OUT = ("shs", "opacities", "normal", "albedo", "roughness", "metallic", "scales", "rotations")
 _OUT_OF = dict(opacities="opacity", normal="normal", albedo="albedo", roughness="roughness", metallic="metallic",
                scales="scaling", rotations="rotation")
+_UPSTREAM_OF = dict(f_dc="shs", f_rest="shs", opacity="opacities", normal="normal", albedo="albedo", roughness="roughness",
+                    metallic="metallic", scaling="scales", rotation="rotations")  # raw parameter -> the getter it feeds
 
 
 class _Scope(threading.local):
@@ -72,6 +74,11 @@ class _Activate(torch.autograd.Function):
         ctx.save_for_backward(*raw)
         ctx.P, ctx.K = P, K
         ctx.sink = _st.sink  # backward() runs on autograd's device thread: the sink of THIS call travels with the node
+        # Declared stage-2 gradient set (gigs_lib.Context.materials_only): the rasterizer's backward hands back None for the
+        # gradients that are exact zeros; so does this node (no tensor, nothing written) -- the captured Adam launch then
+        # updates those groups with g = 0.  Without the declaration an absent gradient is written as zeros, as before.
+        ctx.absent_is_none = gigs_lib.current().materials_only is not None
+        ctx.set_materialize_grads(False)
         return tuple(out[n] for n in OUT)
 
     @staticmethod
@@ -80,14 +87,20 @@ class _Activate(torch.autograd.Function):
         dev = raw[0].device
         g = [None if t is None else t.contiguous().float() for t in g_out]
         sink = ctx.sink or _st.sink or {}
+        upstream = dict(zip(OUT, g))
         d = []
         for name, t in zip(RAW, raw):
+            if ctx.absent_is_none and upstream[_UPSTREAM_OF[name]] is None:
+                d.append(None)
+                continue
             v = sink.get(name)
             ok = v is not None and v.shape == t.shape and v.dtype == t.dtype and v.device == t.device and v.is_contiguous()
             d.append(v if ok else torch.empty_like(t))
+        if all(t is None for t in d):
+            return tuple(d)
         a = gigs_lib.ActivationRaw(*[t.data_ptr() for t in raw])
         b = gigs_lib.ActivationOut(*[None if t is None else t.data_ptr() for t in g])
-        c = gigs_lib.ActivationRaw(*[t.data_ptr() for t in d])
+        c = gigs_lib.ActivationRaw(*[None if t is None else t.data_ptr() for t in d])
         with torch.cuda.device(dev):
             gigs_lib.check(_lib.gigs_activate_bwd(ctx.P, ctx.K, C.addressof(a), C.addressof(b), C.addressof(c),
                                                   torch.cuda.current_stream().cuda_stream), "activate_bwd")

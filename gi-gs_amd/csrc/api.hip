@@ -183,7 +183,7 @@ const Options& default_options() {
   return o;
 }
 const Ctx& default_ctx() {
-  static const Ctx c = {default_options(), 0u, nullptr, nullptr, 0};
+  static const Ctx c = {default_options(), 0u, nullptr, nullptr, 0, nullptr};
   return c;
 }
 }  // namespace gigs
@@ -284,6 +284,11 @@ int gigs_ctx_set_options(gigs_ctx* ctx, const gigs_options* in) {
 int gigs_ctx_set_reuse_binning(gigs_ctx* ctx, int on) {
   if (!ctx) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_reuse_binning: the default context is immutable, create one");
   reinterpret_cast<gigs::Ctx*>(ctx)->reuse_binning = on != 0;
+  return 0;
+}
+int gigs_ctx_set_materials_only(gigs_ctx* ctx, void* violations) {
+  if (!ctx) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_materials_only: the default context is immutable, create one");
+  reinterpret_cast<gigs::Ctx*>(ctx)->materials_only = reinterpret_cast<unsigned*>(violations);
   return 0;
 }
 int gigs_ctx_set_blend_begin_event(gigs_ctx* ctx, void* hip_event) {
@@ -575,9 +580,12 @@ int gigs_backward(gigs_ctx* ctx, int P, int D, int M, int R, const float* backgr
   if (P == 0) return 0;
   if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(GIGS_ERR_INVALID, "bad sizes");
   if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GIGS_ERR_INVALID, "null scratch buffer");
-  if (!dL_dmean2D || !dL_dopacity || !dL_dnormal || !dL_dalbedo ||
-      !dL_droughness || !dL_dmetallic || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
-      (shs && !dL_dsh))
+  // gigs_ctx_set_materials_only: the declared stage-2 gradient set -- only these four outputs are written
+  unsigned* const materials_only = ctx_of(ctx).materials_only;
+  if (!dL_dmean2D || !dL_dalbedo || !dL_droughness || !dL_dmetallic)
+    return fail(GIGS_ERR_INVALID, "null gradient output");
+  if (!materials_only && (!dL_dopacity || !dL_dnormal || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
+                          (shs && !dL_dsh)))
     return fail(GIGS_ERR_INVALID, "null gradient output");
 
   gigs::BwdArgs a;
@@ -617,7 +625,7 @@ int gigs_backward(gigs_ctx* ctx, int P, int D, int M, int R, const float* backgr
   STAGE_CHECK("render backward");
   {
     StageScope sc(kPreprocessBwd, s);
-    gigs::launch_preprocess_bwd(a, geom, ctx_of(ctx).opt.pre_bwd_sh_skip, s);
+    gigs::launch_preprocess_bwd(a, geom, ctx_of(ctx).opt.pre_bwd_sh_skip, s, materials_only);
   }
   STAGE_CHECK("preprocess backward");
   return 0;

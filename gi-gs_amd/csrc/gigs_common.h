@@ -256,6 +256,7 @@ struct Ctx {
   unsigned* async_counters;
   void* blend_begin_event;  // gigs_ctx_set_blend_begin_event
   int reuse_binning;        // gigs_ctx_set_reuse_binning
+  unsigned* materials_only;  // gigs_ctx_set_materials_only: violation counter of the declared stage-2 gradient set
 };
 const Options& default_options();  // api.hip
 const Ctx& default_ctx();          // options = default_options(), no async binning, no event
@@ -313,7 +314,7 @@ struct BwdArgs {
 };
 void launch_blend_bwd(const BwdArgs& a, const GeomState& g, const BinningState& b,
                       const ImageState& im, hipStream_t s);
-void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, int sh_skip, hipStream_t s);
+void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, int sh_skip, hipStream_t s, unsigned* materials_only = nullptr);
 
 void launch_depth_to_normal(int W, int H, float fx, float fy, const float* viewmatrix,
                             const float* depth, float* normal, float* depth_pos, hipStream_t s);

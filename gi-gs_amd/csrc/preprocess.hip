@@ -279,7 +279,7 @@ __device__ __forceinline__ v3 dnormvdv3(v3 v, v3 dv) {  // auxiliary.h:118-128
 }
 
 __global__ void __launch_bounds__(kPreBlock)
-preprocess_bwd_kernel(BwdArgs a, GeomState g, int sh_always) {
+preprocess_bwd_kernel(BwdArgs a, GeomState g, int sh_always, unsigned* __restrict__ materials_only) {
   extern __shared__ __align__(16) float sh_lds[];
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   const int P = a.P, M = a.M, D = a.D;
@@ -293,6 +293,28 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g, int sh_always) {
     g0 = gr[0]; g1 = gr[1]; g2 = gr[2]; g3 = gr[3]; g4 = gr[4];
     // consumed: zero again, so that another backward on the same forward state starts from zero (see preprocess_fwd)
     gr[0] = z4; gr[1] = z4; gr[2] = z4; gr[3] = z4; gr[4] = z4;
+  }
+
+  if (materials_only) {
+    // Declared stage-2 gradient set (gigs_ctx_set_materials_only): the loss reaches the material planes only, whose blend
+    // gradients do not feed dL/dalpha (backward.cu:580-590) -- every other slot of the record is an exact zero, and with
+    // it every other output of this kernel.  Those outputs are not written (the caller keeps no tensor for them); the
+    // premise is CHECKED: a live Gaussian with any other non-zero (or NaN) slot counts as a violation.
+    bool bad = false;
+    if (live) {
+      a.dL_dmean2D[3 * (size_t)idx + 0] = g0.x;
+      a.dL_dmean2D[3 * (size_t)idx + 1] = g0.y;
+      a.dL_dmean2D[3 * (size_t)idx + 2] = g0.z;
+      a.dL_dalbedo[3 * (size_t)idx + 0] = g3.y;
+      a.dL_dalbedo[3 * (size_t)idx + 1] = g3.z;
+      a.dL_dalbedo[3 * (size_t)idx + 2] = g3.w;
+      a.dL_droughness[idx] = g4.x;
+      a.dL_dmetallic[idx] = g4.y;
+      bad = g0.x != 0.0f || g0.y != 0.0f || g0.w != 0.0f || g1.x != 0.0f || g1.y != 0.0f || g1.z != 0.0f || g1.w != 0.0f ||
+            g2.x != 0.0f || g2.y != 0.0f || g2.z != 0.0f || g2.w != 0.0f || g3.x != 0.0f || g4.z != 0.0f;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(materials_only, 1u);
+    return;
   }
 
   // The SH coefficients (12*M bytes per Gaussian) matter only where a colour gradient arrived: with
@@ -544,13 +566,13 @@ preprocess_bwd_kernel(BwdArgs a, GeomState g, int sh_always) {
   }
 }
 
-void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, int sh_skip, hipStream_t s) {
+void launch_preprocess_bwd(const BwdArgs& a, const GeomState& g, int sh_skip, hipStream_t s, unsigned* materials_only) {
   const int blocks = (a.P + kPreBlock - 1) / kPreBlock;
   const size_t lds = a.shs ? (size_t)kPreBlock * sh_stride(a.M) * sizeof(float) : 0;
   // sh_skip = 0 (gigs_options.pre_bwd_sh_skip, diagnostic): evaluate every visible Gaussian and read the SH block of every
   // group, whatever the incoming gradients (as before round 3)
   const int sh_always = sh_skip ? 0 : 1;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(kPreBlock), lds, s, a, g, sh_always);
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(kPreBlock), materials_only ? 0 : lds, s, a, g, sh_always, materials_only);
 }
 
 }  // namespace gigs

@@ -412,6 +412,7 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
   float* __restrict__ V = G.exp_avg_sq[gi];
   const float ss = G.dyn ? G.dyn[2 * (G.dyn_base + gi)] : G.step_size[gi];
   const float bs = G.dyn ? G.dyn[2 * (G.dyn_base + gi) + 1] : G.bc2_sqrt[gi];
+  // Gr == NULL: the group's gradient is an exact zero the caller did not materialise -- the same arithmetic with g = 0
   const bool vec = ((((uintptr_t)P | (uintptr_t)Gr | (uintptr_t)M | (uintptr_t)V) & 15) == 0) && base + kAdamChunk <= n;
   const bool watched = (G.watch_mask >> gi) & 1u;
   bool moved = false;
@@ -421,7 +422,7 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
       const long long i = base + (long long)(r * 256 + threadIdx.x) * 4;
       float4 p = *reinterpret_cast<float4*>(P + i), m = *reinterpret_cast<float4*>(M + i);
       float4 v = *reinterpret_cast<float4*>(V + i);
-      const float4 g = *reinterpret_cast<const float4*>(Gr + i);
+      const float4 g = Gr ? *reinterpret_cast<const float4*>(Gr + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       const float4 p0 = p;
       adam_one(p.x, g.x, m.x, v.x, K, ss, bs);
       adam_one(p.y, g.y, m.y, v.y, K, ss, bs);
@@ -432,7 +433,7 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
       *reinterpret_cast<float4*>(P + i) = p;
       *reinterpret_cast<float4*>(M + i) = m;
       *reinterpret_cast<float4*>(V + i) = v;
-      if (zero_grad) *reinterpret_cast<float4*>(Gr + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (zero_grad && Gr) *reinterpret_cast<float4*>(Gr + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   } else {
     for (int r = 0; r < kAdamChunk / 256; r++) {
@@ -440,10 +441,10 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
       if (i >= n) break;
       float p = P[i], m = M[i], v = V[i];
       const float p0 = p;
-      adam_one(p, Gr[i], m, v, K, ss, bs);
+      adam_one(p, Gr ? Gr[i] : 0.0f, m, v, K, ss, bs);
       moved |= __float_as_uint(p) != __float_as_uint(p0);
       P[i] = p; M[i] = m; V[i] = v;
-      if (zero_grad) Gr[i] = 0.0f;
+      if (zero_grad && Gr) Gr[i] = 0.0f;
     }
   }
   // frozen geometry: no wave of a watched group sees a change, no atomic is issued
@@ -552,8 +553,8 @@ __device__ __forceinline__ void act_sh_tile_bwd(int P, int row_f, const ActPtrs&
   if (A.g_shs) act_tile_in(A.g_shs + (size_t)r0 * row_f, rows * row_f, row_f, tile, row_f, 0);
   else for (int e = threadIdx.x; e < rows * row_f; e += 256) tile[e] = 0.0f;
   __syncthreads();
-  act_tile_out(A.d_f_dc + 3 * (size_t)r0, rows * 3, 3, tile, row_f, 0);
-  if (row_f > 3) act_tile_out(A.d_f_rest + (size_t)r0 * (row_f - 3), rows * (row_f - 3), row_f - 3, tile, row_f, 3);
+  if (A.d_f_dc) act_tile_out(A.d_f_dc + 3 * (size_t)r0, rows * 3, 3, tile, row_f, 0);
+  if (row_f > 3 && A.d_f_rest) act_tile_out(A.d_f_rest + (size_t)r0 * (row_f - 3), rows * (row_f - 3), row_f - 3, tile, row_f, 3);
 }
 
 // grid: the SH tiles first, then one block per 256 Gaussians for the sixteen small attributes
@@ -587,23 +588,30 @@ activate_bwd_kernel(int P, int K, ActPtrs A, int sh_tiles) {
   }
   const int i = ((int)blockIdx.x - sh_tiles) * 256 + threadIdx.x;
   if (i >= P) return;
-  {
+  // a NULL output (gigs_activate_bwd: the caller keeps no tensor for a gradient it knows to be zero) is neither computed nor written
+  if (A.d_opacity) {
     const float s = sigmoidf(A.opacity[i]);
     A.d_opacity[i] = A.g_opacity ? A.g_opacity[i] * (s * (1.0f - s)) : 0.0f;
+  }
+  if (A.d_roughness) {
     const float r = sigmoidf(A.roughness[i]);
     A.d_roughness[i] = A.g_roughness ? A.g_roughness[i] * (r * (1.0f - r)) : 0.0f;
+  }
+  if (A.d_metallic) {
     const float m = sigmoidf(A.metallic[i]);
     A.d_metallic[i] = A.g_metallic ? A.g_metallic[i] * (m * (1.0f - m)) : 0.0f;
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const float a = sigmoidf(A.albedo[3 * i + k]);
-    A.d_albedo[3 * i + k] = A.g_albedo ? A.g_albedo[3 * i + k] * (a * (1.0f - a)) : 0.0f;
-    A.d_scaling[3 * i + k] = A.g_scales ? A.g_scales[3 * i + k] * expf(A.scaling[3 * i + k]) : 0.0f;
+    if (A.d_albedo) {
+      const float a = sigmoidf(A.albedo[3 * i + k]);
+      A.d_albedo[3 * i + k] = A.g_albedo ? A.g_albedo[3 * i + k] * (a * (1.0f - a)) : 0.0f;
+    }
+    if (A.d_scaling) A.d_scaling[3 * i + k] = A.g_scales ? A.g_scales[3 * i + k] * expf(A.scaling[3 * i + k]) : 0.0f;
   }
   const float z4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  normalize_bwd<3>(A.normal + 3 * i, A.g_normal ? A.g_normal + 3 * i : z4, A.d_normal + 3 * i);
-  normalize_bwd<4>(A.rotation + 4 * i, A.g_rotations ? A.g_rotations + 4 * i : z4, A.d_rotation + 4 * i);
+  if (A.d_normal) normalize_bwd<3>(A.normal + 3 * i, A.g_normal ? A.g_normal + 3 * i : z4, A.d_normal + 3 * i);
+  if (A.d_rotation) normalize_bwd<4>(A.rotation + 4 * i, A.g_rotations ? A.g_rotations + 4 * i : z4, A.d_rotation + 4 * i);
 }
 
 // ---- densification bookkeeping ----------------------------------------------------------
@@ -826,7 +834,7 @@ int gigs_adam_step_watch(int n_groups, const gigs_adam_group* groups, double bet
     int k = 0;
     for (; done < n_groups && k < gigs::kAdamMaxGroups; done++) {
       const gigs_adam_group& g = groups[done];
-      if (g.n < 0 || (!dyn && g.step < 1) || (g.n > 0 && (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq))) {
+      if (g.n < 0 || (!dyn && g.step < 1) || (g.n > 0 && (!g.param || !g.exp_avg || !g.exp_avg_sq))) {  // grad == NULL: an exact-zero gradient, not materialised
         gigs_internal_stage_end(tok);
         return gigs_internal_fail(GIGS_ERR_INVALID, "adam_step: bad group");
       }
@@ -959,10 +967,7 @@ int gigs_activate_fwd(int P, int K, const gigs_activation_raw* raw, const gigs_a
 
 int gigs_activate_bwd(int P, int K, const gigs_activation_raw* raw, const gigs_activation_out* grad_out,
                       const gigs_activation_raw_grad* grad_raw, void* stream) {
-  if (P < 0 || K < 1 || 3 * K > gigs::kActMaxRowF || (P > 0 && (!act_raw_ok(raw, K) || !grad_out || !grad_raw || !grad_raw->f_dc ||
-                                   (K > 1 && !grad_raw->f_rest) || !grad_raw->opacity || !grad_raw->normal ||
-                                   !grad_raw->albedo || !grad_raw->roughness || !grad_raw->metallic ||
-                                   !grad_raw->scaling || !grad_raw->rotation)))
+  if (P < 0 || K < 1 || 3 * K > gigs::kActMaxRowF || (P > 0 && (!act_raw_ok(raw, K) || !grad_out || !grad_raw)))
     return gigs_internal_fail(GIGS_ERR_INVALID, "activate_bwd: bad argument");
   if (P == 0) return 0;
   gigs::ActPtrs A;
@@ -975,7 +980,8 @@ int gigs_activate_bwd(int P, int K, const gigs_activation_raw* raw, const gigs_a
   A.d_albedo = grad_raw->albedo; A.d_roughness = grad_raw->roughness; A.d_metallic = grad_raw->metallic;
   A.d_scaling = grad_raw->scaling; A.d_rotation = grad_raw->rotation;
   void* tok; gigs_internal_stage_begin(31, stream, &tok);
-  const int sh_tiles = (P + gigs::kActRows - 1) / gigs::kActRows;
+  // no SH tile when neither SH gradient is wanted
+  const int sh_tiles = (A.d_f_dc || A.d_f_rest) ? (P + gigs::kActRows - 1) / gigs::kActRows : 0;
   hipLaunchKernelGGL(gigs::activate_bwd_kernel, dim3((unsigned)(sh_tiles + (P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K,
                      A, sh_tiles);
   gigs_internal_stage_end(tok);

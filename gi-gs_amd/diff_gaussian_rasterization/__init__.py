@@ -424,7 +424,13 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
     _mk = torch.empty if P != 0 else torch.zeros
     sink = _st.grad_sink or {}
 
+    # gigs_ctx_set_materials_only (the context of the forward travels with the node): the declared stage-2 gradient set --
+    # the other gradients are exact zeros the library neither writes nor is given a tensor for; they come back as None
+    materials_only = P != 0 and gigs_lib.current().materials_only is not None
+
     def z(name, *shape):
+        if materials_only and name not in ("means2D", "albedo", "roughness", "metallic"):
+            return None
         t = sink.get(name)
         if (t is not None and P != 0 and tuple(t.shape) == shape and t.dtype == torch.float32 and t.device == dev
                 and t.is_contiguous()):
@@ -447,6 +453,9 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
             keep.append(k)
             return ptr
 
+        def dp(t):
+            return None if t is None else t.data_ptr()
+
         with torch.cuda.device(dev):
             rc = _lib.gigs_backward(
                 gigs_lib.ctx_ptr(), P, int(sh_degree), M, int(num_rendered), p(bg, "bg"), W, H, p(means3D, "means3D"),
@@ -458,11 +467,11 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
                 imgBuffer.data_ptr(), p(grad_depth, "grad_depth"), p(grad_color, "grad_color"),
                 p(grad_opacity, "grad_opacity"), p(grad_normal, "grad_normal"), p(grad_albedo, "grad_albedo"),
                 p(grad_roughness, "grad_roughness"), p(grad_metallic, "grad_metallic"),
-                dL_dmeans2D.data_ptr(), None, None, dL_dopacity.data_ptr(),
-                dL_dnormal.data_ptr(), dL_dalbedo.data_ptr(), dL_droughness.data_ptr(),
-                dL_dmetallic.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
-                dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
-                dL_drotations.data_ptr(), int(debug), _stream())
+                dL_dmeans2D.data_ptr(), None, None, dp(dL_dopacity),
+                dp(dL_dnormal), dL_dalbedo.data_ptr(), dL_droughness.data_ptr(),
+                dL_dmetallic.data_ptr(), dp(dL_dcolors), dp(dL_dmeans3D),
+                dp(dL_dcov3D), dp(dL_dsh) if M else None, dp(dL_dscales),
+                dp(dL_drotations), int(debug), _stream())
         gigs_lib.check(rc, "rasterize_gaussians_backward")
     return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dnormal, dL_dalbedo, dL_droughness, dL_dmetallic,
             dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)

@@ -121,9 +121,14 @@ class CapturedAdam:
     Every listed parameter must have a gradient buffer (a parameter without one is simply not listed: its moments and
     step count stay untouched, as torch.optim.Adam leaves a parameter whose .grad is None)."""
 
-    def __init__(self, optimizers, params, grads):
+    def __init__(self, optimizers, params, grads, absent_is_zero: bool = False):
+        """absent_is_zero: a listed parameter whose gradient is None is NOT skipped but updated with g = 0 (gigs_adam_group
+        with grad == NULL) -- the declared stage-2 gradient set of pipeline.WholeStepGraph, where None stands for an exact
+        zero that nobody materialised (the reference hands Adam a tensor of zeros there: the moments decay, the parameter
+        follows its momentum)."""
         self.entries = []  # (optimizer, group, parameter, gradient buffer)
-        by_id = {id(p): g for p, g in zip(params, grads) if g is not None}
+        by_id = {id(p): g for p, g in zip(params, grads) if g is not None or absent_is_zero}
+        listed = {id(p) for p in params}
         self.buckets = {}
         dev = None
         for opt in optimizers:
@@ -133,10 +138,10 @@ class CapturedAdam:
                 key = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))
                 for p in group["params"]:
                     gr = by_id.get(id(p))
-                    if gr is None:
+                    if gr is None and not (absent_is_zero and id(p) in listed):
                         continue
-                    if (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or gr.dtype != torch.float32
-                            or not gr.is_contiguous() or gr.shape != p.shape):
+                    if (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or (gr is not None and (
+                            gr.dtype != torch.float32 or not gr.is_contiguous() or gr.shape != p.shape))):
                         raise RuntimeError("CapturedAdam: parameters and gradient buffers must be contiguous fp32 on the GPU")
                     dev = p.device if dev is None else dev
                     st = opt.state[p]
@@ -183,7 +188,7 @@ class CapturedAdam:
             st = o.state.get(p)
             if not st:  # the optimizer no longer holds this tensor (densification replaced it): the capture is stale
                 return ("stale", id(self))
-            out.append((p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
+            out.append((p.data_ptr(), 0 if gr is None else gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
         return tuple(out)
 
     def launch(self, watch=None, changed: Optional[torch.Tensor] = None) -> None:
@@ -197,7 +202,7 @@ class CapturedAdam:
                 for i in idx:
                     o, grp, p, gr = self.entries[i]
                     st = o.state[p]
-                    groups.append(gigs_lib.AdamGroup(p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(),
+                    groups.append(gigs_lib.AdamGroup(p.data_ptr(), None if gr is None else gr.data_ptr(), st["exp_avg"].data_ptr(),
                                                      st["exp_avg_sq"].data_ptr(), p.numel(), 0.0, 0))
                     flags.append(1 if (watch is not None and grp.get("name") in watch) else 0)
                 arr = (gigs_lib.AdamGroup * len(groups))(*groups)

@@ -503,6 +503,7 @@ class WholeStepGraph:
         self.recaptures = 0
         self.fwd_done = torch.cuda.Event()
         self._packs = {}
+        self.viol_dev = self.viol_host = None  # declared stage-2 gradient set: violation counter (device) and its pinned copy
 
     CAM_TENSORS = ("viewmatrix", "projmatrix", "campos")
 
@@ -524,6 +525,7 @@ class WholeStepGraph:
         self.inner = self.bin = None
         self._packs.clear()
         self._src = {}
+        self.check_declared()  # the device is idle: the last update's count has arrived
 
     def __del__(self):
         try:
@@ -563,7 +565,23 @@ class WholeStepGraph:
             stack.enter_context(activations.grad_sink({k: v for k, v in slabv.items() if k in activations.RAW}))
             if "xyz" in slabv:
                 stack.enter_context(dgr.grad_sink({"means3D": slabv["xyz"]}))
+        if self.viol_dev is not None:
+            # the declared stage-2 gradient set: the forward's library context carries the violation counter, the backward
+            # nodes (rasterizer, activations) then produce the material gradients only
+            stack.enter_context(gigs_lib.use(gigs_lib.current().derive(materials_only=self.viol_dev)))
         return stack
+
+    def check_declared(self) -> None:
+        """The declared stage-2 gradient set (Stage2Step.materials_only) is checked on the device by every backward; the
+        count reaches pinned memory behind every update.  Non-zero: a gradient that was taken for zero was not."""
+        if self.viol_host is not None and int(self.viol_host[0]) != 0:
+            n = int(self.viol_host[0])
+            self.viol_host.zero_()
+            raise RuntimeError(
+                "WholeStepGraph: %d wave(s) of the rasterizer's backward found a gradient outside the declared stage-2 set "
+                "(albedo / roughness / metallic / light) -- the loss reaches colour, opacity, depth, normal or geometry, so "
+                "the updates since the last check used zeros that were not zeros.  Build the stepper / trainer with "
+                "materials_only=False (GIGS_MATERIALS_ONLY=0)." % n)
 
     def _into_slab(self, g, grads):
         """Inside the backward capture: every gradient ends up in its slab view (most were born there; the light's is
@@ -606,6 +624,12 @@ class WholeStepGraph:
                 self.cache.invalidate()  # entries are carved for the old capacity
             self.cache.capacity = self.capacity
         self.bin = AsyncBinning(self.capacity, self.dev)
+        # Declared stage-2 gradient set (complete iterations only: the gradients are consumed inside the step, by an Adam
+        # launch that takes an absent gradient as g = 0)
+        self.viol_dev = self.viol_host = None
+        if o.optimizers and getattr(o, "materials_only", False) and os.environ.get("GIGS_MATERIALS_ONLY", "1") == "1":
+            self.viol_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.viol_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.inner = o._make_inner()  # the eager step that is captured: returns its attached loss instead of differentiating
         self.inner._defer_backward = True
         self.inner._static_bg = bg
@@ -685,7 +709,7 @@ class WholeStepGraph:
                 # the update as a third graph (train.py:517-522): it is replayed only once the host has seen that the
                 # forward's binning did not overflow, and -- multi-GPU -- after the gradient all-reduce
                 from optim import CapturedAdam
-                adam = CapturedAdam(o.optimizers, params, list(grads[:-1]))
+                adam = CapturedAdam(o.optimizers, params, list(grads[:-1]), absent_is_zero=self.viol_dev is not None)
                 go = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(go, pool=gf.pool(), stream=cap, capture_error_mode="thread_local"):
                     if self.cache is not None:
@@ -695,6 +719,8 @@ class WholeStepGraph:
                         self.cache.flag_dev.zero_()
                     else:
                         adam.launch()
+                    if self.viol_dev is not None:
+                        self.viol_host.copy_(self.viol_dev, non_blocking=True)  # cumulative: a violation stays visible
                     if o.post_update is not None:
                         with torch.no_grad():
                             o.post_update()
@@ -758,6 +784,7 @@ class WholeStepGraph:
             self.fwd_done.record()
             self.gb.replay()
             self.fwd_done.synchronize()
+            self.check_declared()  # this forward has ended, so every earlier update's count has arrived
             r, over = int(self.bin.host[0]), int(self.bin.host[1])
             if over:
                 self.capacity = -(-int(1.5 * over) // 65536) * 65536
@@ -878,7 +905,7 @@ class Stage2Step:
     def __init__(self, light, brdf_lut, gi: Dict, sh_degree: int, metallic: bool = True, indirect: bool = True,
                  gamma: bool = False, tone: bool = False, graphs: bool = False, fused: bool = False,
                  prepare=None, regularizer=None, optimizers=None, post_update=None, before_update=None,
-                 geometry_cache: bool = False):
+                 geometry_cache: bool = False, materials_only: bool = False):
         """The last five arguments turn the step into a COMPLETE training iteration (train_iteration.Stage2Trainer):
         `prepare(raw) -> g` maps the optimizer's tensors to the rasterizer's inputs (the GaussianModel getters;
         `__call__` then takes the raw dictionary), `regularizer(maps) -> scalar` adds the BRDF / envmap terms of
@@ -902,6 +929,7 @@ class Stage2Step:
         self.whole, self._wholes = None, {}
         # frozen-geometry reuse (GeometryCache; graph path only, off by default: the headline step never uses it)
         self.geometry_cache, self.geom_cache = bool(geometry_cache), None
+        self.materials_only = bool(materials_only)
 
     def _capture(self, front_args, loss_args):
         def clone(args):

@@ -81,9 +81,14 @@ class Stage2Trainer:
     def __init__(self, raw: Dict[str, torch.Tensor], light, brdf_lut: torch.Tensor, gi: Dict, sh_degree: int,
                  lrs: Optional[Dict[str, float]] = None, light_lr: float = 0.05, graphs: bool = True, glue: str = "hip",
                  brdf_tv_weight: float = 1.0, env_tv_weight: float = 0.01, before_update=None, metallic: bool = True,
-                 geometry_cache: bool = False):
+                 geometry_cache: bool = False, materials_only: bool = True):
         """geometry_cache: reuse, per view, what frozen geometry makes constant -- tile lists, occlusion plane (pipeline.
-        GeometryCache; graphs only).  Same updates as without it (tested); a secondary figure, never the headline metric."""
+        GeometryCache; graphs only).  Same updates as without it (tested); a secondary figure, never the headline metric.
+        materials_only (graphs only): a stage-2 iteration's loss reaches albedo / roughness / metallic and the light, every
+        other gradient is an exact zero -- DECLARED here, so those zeros are neither written by the rasterizer's backward,
+        nor pushed through the activations' backward, nor read by Adam (which updates the groups with g = 0: same
+        arithmetic), and CHECKED on the device by every backward (gigs_ctx_set_materials_only): a violation raises at
+        the next iteration.  Same updates as without it (tested)."""
         if glue not in ("hip", "torch"):
             raise ValueError("glue must be 'hip' or 'torch'")
         self.raw, self.light = raw, light
@@ -97,7 +102,8 @@ class Stage2Trainer:
             light, brdf_lut, gi, sh_degree, metallic=metallic, graphs=graphs and glue == "hip", fused=glue == "hip",
             prepare=activations.activate if glue == "hip" else activations.activate_torch, regularizer=self.regularizer,
             optimizers=[self.optimizer, self.light_optimizer], post_update=lambda: light.clamp_(min=0.0),
-            before_update=before_update, geometry_cache=geometry_cache and graphs and glue == "hip")
+            before_update=before_update, geometry_cache=geometry_cache and graphs and glue == "hip",
+            materials_only=materials_only and graphs and glue == "hip")
 
     def set_lr(self, name: str, lr: float) -> None:
         """update_learning_rate (scene/gaussian_model.py:349-355): takes effect at the next iteration, graphs included

@@ -432,7 +432,9 @@ int gigs_cube_texture_bwd_gather(int res, int n, int planar, const int* offsets,
  *   loss_count = {loss, number of mask pixels}; g_a / g_b may each be NULL (g_b = -g_a).
  * gigs_adam_step = torch.optim.Adam(eps=..., betas=...) without weight decay / amsgrad, as the reference configures it
  *   (scene/gaussian_model.py:325-346), for all parameter groups in one launch per 16 groups; `step` is the 1-based
- *   update count of the group's state, `lr` its current learning rate; zero_grad != 0 also clears the gradients. */
+ *   update count of the group's state, `lr` its current learning rate; zero_grad != 0 also clears the gradients.
+ *   grad == NULL: the group's gradient is an exact zero that was not materialised -- the update runs with g = 0 (the
+ *   moments decay, the parameter follows its momentum), which is NOT torch's "grad is None: skip the parameter". */
 typedef struct gigs_adam_group {
   float* param;
   float* grad;
@@ -476,8 +478,8 @@ int gigs_adam_step_watch(int n_groups, const gigs_adam_group* groups, double bet
 /* The parameter getters of GaussianModel (scene/gaussian_model.py:48-58, 178-263) as one pass each way:
  * shs = cat(f_dc [P,1,3], f_rest [P,K-1,3]) -> [P,K,3]; opacities / albedo / roughness / metallic = sigmoid(raw);
  * scales = exp(scaling); rotations = F.normalize(rotation), normal = F.normalize(normal) (dim -1, eps 1e-12).
- * gigs_activate_bwd: grad_out members may be NULL (= zero gradient); every grad_raw tensor is overwritten
- * (f_rest may be NULL when K == 1). */
+ * gigs_activate_bwd: grad_out members may be NULL (= zero gradient); every non-NULL grad_raw tensor is overwritten, a NULL
+ * one is neither computed nor written (a gradient the caller knows to be zero and keeps no tensor for). */
 typedef struct gigs_activation_raw {
   const float *f_dc, *f_rest, *opacity, *normal, *albedo, *roughness, *metallic, *scaling, *rotation;
 } gigs_activation_raw;
@@ -567,6 +569,19 @@ int gigs_ssr_backward(int width, int height, const float* grad_color, const floa
  * are then those of a complete forward bit for bit.  Whether the geometry is unchanged is the caller's knowledge
  * (gigs_adam_step_watch reports it from the optimizer step). */
 int gigs_ctx_set_reuse_binning(gigs_ctx* ctx, int on);
+
+/* Declared stage-2 gradient set (gigs-hip extension).  The loss of a stage-2 iteration reaches the material planes and
+ * the light only (train.py:330-420), and the material planes' blend gradients do not feed dL/dalpha (backward.cu:580-590):
+ * every gradient of gigs_backward other than dL_dalbedo / dL_droughness / dL_dmetallic (and the densification slot of
+ * dL_dmean2D) is an exact zero, 59 of 67 floats per Gaussian at SH degree 3 that the reference writes, activates and feeds
+ * to Adam all the same.  After gigs_ctx_set_materials_only(ctx, violations) -- `violations` a DEVICE uint32 the caller
+ * zeroes -- gigs_backward(ctx, ...) writes those four outputs only; every other gradient pointer may be NULL and is never
+ * written.  The premise is checked on the device: each wave that finds a live Gaussian whose blend-backward record holds a
+ * non-zero (or NaN) value in any other slot adds 1 to *violations; a caller that reads a non-zero count has used zeros that
+ * were not zeros and must not continue.  The consumers take the absent gradients as what they are: gigs_activate_bwd skips a
+ * NULL grad_raw member, a gigs_adam_group with grad == NULL is updated with g = 0 (same arithmetic, nothing read).
+ * violations == NULL restores the complete backward. */
+int gigs_ctx_set_materials_only(gigs_ctx* ctx, void* violations);
 
 /* Optional scheduling hook: a hipEvent_t (caller-owned, NULL = none) that gigs_forward records on its stream right
  * before it launches the alpha-blend kernel, so that a caller can start independent work on another stream next to

@@ -473,3 +473,83 @@ def test_frozen_geometry_cache_replays_the_tile_lists_and_follows_the_plain_trai
     assert cache.stats["repeated"] == r0 + 1 and cache.stats["invalidated"] >= 2, cache.stats
     plain.close()
     cached.close()
+
+
+def test_declared_stage2_gradient_set_gives_the_same_updates_and_is_checked_on_the_device():
+    """Stage2Trainer(materials_only=True), the default: the rasterizer's backward writes dL/d(albedo, roughness, metallic)
+    only (gigs_ctx_set_materials_only), the activations' backward and Adam never see the 59 other floats per Gaussian --
+    Adam updates those groups with g = 0.  (1) Same training as with every zero materialised: the zero-gradient groups --
+    started WITH momentum, so that they do move -- bit for bit, materials / light / losses to the rounding of the float-atomic
+    gradient sums.  (2) The premise is checked by every backward: a loss term that reaches the rasterized normals (outside
+    the declared set) raises at the next iteration instead of training on zeros that are not zeros."""
+    import pbr
+    import pipeline
+    import scenes
+    import train_iteration as ti
+    dev = torch.device("cuda:0")
+    H = W = 96
+    sc = scenes.surface_scene(P=5000, sh_degree=2, seed=8, scale_mu=0.035)
+    n_views = 4
+    cams = [scenes.orbit_camera(i, n_views, W, H, radius=3.5) for i in range(n_views)]
+    cams = [{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in c.items()} for c in cams]
+    gi = scenes.GI_DEFAULTS
+    lut = pbr.get_brdf_lut().to(dev)
+    rays = pipeline.canonical_rays(cams[0], dev)
+    vds = [pipeline.view_dirs_for(c, rays, dev) for c in cams]
+    torch.manual_seed(1)
+    gts = [torch.rand(3, H, W, device=dev) * 0.6 for _ in cams]
+    zero_groups = ("xyz", "f_dc", "f_rest", "opacity", "normal", "scaling", "rotation")
+
+    def make(declared):
+        torch.manual_seed(3)
+        raw = ti.raw_from_scene(sc, dev)
+        light = pbr.CubemapLight(base_res=64, device=dev)
+        tr = ti.Stage2Trainer(raw, light, lut, gi, 2, graphs=True, materials_only=declared)
+        gen = torch.Generator(device=dev).manual_seed(5)
+        for name in zero_groups:  # residual momentum of stage 1: these groups keep moving although their gradient is zero
+            p = raw[name]
+            tr.optimizer.state[p] = {"step": torch.tensor(200.0), "exp_avg": torch.randn(p.shape, device=dev, generator=gen) * 1e-3,
+                                     "exp_avg_sq": torch.full_like(p, 1e-6)}
+        return tr, raw, light
+
+    def run(tr, n):
+        return [float(tr.iteration(cams[i % n_views], gts[i % n_views], vds[i % n_views])["loss"]) for i in range(n)]
+
+    full, raw_f, light_f = make(False)
+    start = {k: raw_f[k].detach().clone() for k in zero_groups}
+    lf = run(full, 10)
+    decl, raw_d, light_d = make(True)
+    ld = run(decl, 10)
+    torch.cuda.synchronize()
+    w = decl.stepper.whole
+    assert w.viol_dev is not None and int(w.viol_dev.item()) == 0 and full.stepper.whole.viol_dev is None
+    assert sum(g is None for g in w.grads) == len(zero_groups)  # nothing materialised for them
+    for k in zero_groups:
+        assert not torch.equal(raw_f[k].detach(), start[k]), k       # momentum did move the group
+        assert torch.equal(raw_d[k].detach(), raw_f[k].detach()), k  # g = 0 either way: the same bits
+        for s in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(decl.optimizer.state[raw_d[k]][s], full.optimizer.state[raw_f[k]][s]), (k, s)
+        assert int(decl.optimizer.state[raw_d[k]]["step"]) == 210
+    for a, b in zip(lf, ld):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (lf, ld)
+    for k in ("albedo", "roughness", "metallic"):
+        torch.testing.assert_close(raw_d[k].detach(), raw_f[k].detach(), rtol=0, atol=2e-3)
+        assert not torch.equal(raw_d[k].detach(), ti.raw_from_scene(sc, dev)[k].detach())
+    torch.testing.assert_close(light_d.base.detach(), light_f.base.detach(), rtol=0, atol=2e-3)
+    full.close()
+    decl.close()
+
+    # (2) a regulariser outside the declared set
+    class Bad(ti.Stage2Regularizer):
+        def __call__(self, maps):
+            return super().__call__(maps) + 0.1 * maps["normal_map"].square().mean()
+
+    tr, raw, light = make(True)
+    tr.stepper.regularizer = Bad(light)
+    tr.stepper.close()  # nothing captured yet; the next iteration captures with the new regulariser
+    tr.iteration(cams[0], gts[0], vds[0])
+    with pytest.raises(RuntimeError, match="outside the declared stage-2 set"):
+        tr.iteration(cams[1], gts[1], vds[1])
+        tr.close()
+    tr.stepper.whole.viol_host.zero_()
+    tr.close()
