@@ -189,3 +189,46 @@ def test_gi_at_delta_0_03125(orc, march):
         assert d.mean() <= tol, f"{march} {name}: mean L1 {d.mean():.3e}"
         assert (d > 1e-5).mean() <= (1e-3 if march == "exact" else 2e-3), f"{march} {name}: {(d > 1e-5).mean():.2e} of the pixels moved"
     assert (occ_ref < 1.0).sum() > 100, "no occlusion in the test view"
+
+
+def test_materials_only_backward_writes_the_declared_set_and_counts_violations():
+    """gigs_ctx_set_materials_only (gigs-hip extension): with a loss that reaches the albedo / roughness / metallic planes only
+    -- whose blend gradients do not feed dL/dalpha (backward.cu:580-590) -- the declared backward returns those three
+    gradients as the complete backward computes them and nothing else (None: no tensor, nothing written), and its device-side
+    check stays at zero; a loss that also reaches the colour plane is counted as a violation."""
+    import gigs_lib
+    dgr = _dgr()
+    sc = scenes.surface_scene(P=6000, sh_degree=2, seed=4, scale_mu=0.04)
+    cam = scenes.orbit_camera(2, 6, 160, 128, radius=3.4)
+    st = settings(dgr, cam, 2)
+    torch.manual_seed(3)
+    w_alb, w_rm = torch.randn(3, 128, 160, device=DEV), torch.randn(2, 128, 160, device=DEV)
+
+    def run(counter, colour):
+        t = {k: tt(sc[k], grad=True) for k in GAUSS_KEYS}
+        m2d = torch.zeros_like(t["means3D"], requires_grad=True)
+        scope = gigs_lib.use(gigs_lib.current().derive(materials_only=counter)) if counter is not None else gigs_lib.use(gigs_lib.current())
+        with scope:
+            out = dgr.GaussianRasterizer(st)(t["means3D"], m2d, t["opacities"], t["normal"], t["albedo"], t["roughness"],
+                                             t["metallic"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        loss = (out[7] * w_alb).sum() + (out[8] * w_rm[:1]).sum() + (out[9] * w_rm[1:]).sum()
+        if colour:
+            loss = loss + out[0].sum()
+        loss.backward()  # the node carries the forward's context to autograd's thread
+        torch.cuda.synchronize()
+        return {k: (None if v.grad is None else v.grad.detach().cpu().numpy()) for k, v in t.items()}, m2d.grad
+
+    full, m2d_full = run(None, False)
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    got, m2d_got = run(counter, False)
+    assert int(counter.item()) == 0
+    for k in ("albedo", "roughness", "metallic"):
+        assert np.abs(full[k]).max() > 0
+        d = np.abs(got[k] - full[k]).max() / np.abs(full[k]).max()
+        assert d < 1e-5, (k, d)  # float-atomic sums: rounding differs from run to run
+    for k in ("means3D", "opacities", "normal", "shs", "scales", "rotations"):
+        assert got[k] is None, k
+        assert float(np.abs(full[k]).max()) == 0.0, k  # what was not materialised is an exact zero in the complete backward
+    assert torch.equal(m2d_got, m2d_full)  # zeros (and the densification slot)
+    run(counter, True)
+    assert int(counter.item()) > 0  # the colour plane's gradient reaches dL/dalpha, SH and geometry: counted
