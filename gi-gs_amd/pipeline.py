@@ -1162,7 +1162,10 @@ def _fused_begin(self, start_event=None):
         # the side stream: intended here (autograd inserts the event wait), so the advisory warning is switched off
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        self.side = torch.cuda.Stream()
+        # the light owns a stream (pbr/light.py: every graph over `base` is built there, so is its backward): that stream IS the
+        # side stream of this step -- the fused node's split backward (stage2_fused.py) relies on the filters' backward running
+        # behind what it issues there
+        self.side = self.light._side_stream() if hasattr(self.light, "_side_stream") else torch.cuda.Stream()
         self.mips = LightMips(self.light)
         self.dummy = torch.zeros(1, device=self.light.base.device)
         if self.graphs:
