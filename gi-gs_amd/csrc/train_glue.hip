@@ -400,6 +400,29 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p - step_size * (m / denom);          // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+// kStream: the three arrays a step reads and rewrites are touched once per step and are far larger than any cache: loads
+// and stores carry the non-temporal hint (they do not displace what the next kernels of the iteration will read)
+template <bool kStream>
+__device__ __forceinline__ float4 adam_ld4(const float* p) {
+  if constexpr (kStream) {
+    const adam_f4 v = __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+template <bool kStream>
+__device__ __forceinline__ void adam_st4(float* p, float4 v) {
+  if constexpr (kStream) {
+    adam_f4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<adam_f4*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
+
+template <bool kStream>
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
   int gi = 0;
@@ -420,8 +443,8 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const long long i = base + (long long)(r * 256 + threadIdx.x) * 4;
-      float4 p = *reinterpret_cast<float4*>(P + i), m = *reinterpret_cast<float4*>(M + i);
-      float4 v = *reinterpret_cast<float4*>(V + i);
+      float4 p = adam_ld4<kStream>(P + i), m = adam_ld4<kStream>(M + i);
+      float4 v = adam_ld4<kStream>(V + i);
       const float4 g = Gr ? *reinterpret_cast<const float4*>(Gr + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       const float4 p0 = p;
       adam_one(p.x, g.x, m.x, v.x, K, ss, bs);
@@ -430,9 +453,9 @@ adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
       adam_one(p.w, g.w, m.w, v.w, K, ss, bs);
       moved |= (__float_as_uint(p.x) != __float_as_uint(p0.x)) | (__float_as_uint(p.y) != __float_as_uint(p0.y)) |
                (__float_as_uint(p.z) != __float_as_uint(p0.z)) | (__float_as_uint(p.w) != __float_as_uint(p0.w));
-      *reinterpret_cast<float4*>(P + i) = p;
-      *reinterpret_cast<float4*>(M + i) = m;
-      *reinterpret_cast<float4*>(V + i) = v;
+      adam_st4<kStream>(P + i, p);
+      adam_st4<kStream>(M + i, m);
+      adam_st4<kStream>(V + i, v);
       if (zero_grad && Gr) *reinterpret_cast<float4*>(Gr + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   } else {
@@ -872,7 +895,9 @@ int gigs_adam_step_watch(int n_groups, const gigs_adam_group* groups, double bet
       continue;
     }
     const gigs::AdamConsts K = {(float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps};
-    hipLaunchKernelGGL(gigs::adam_kernel, dim3(chunks), dim3(256), 0, s, G, K, zero_grad);
+    // bit 8 of zero_grad (diagnostic, tools/adam_bw.py): the plain loads / stores instead of the streaming ones
+    if (zero_grad & 0x100) hipLaunchKernelGGL(gigs::adam_kernel<false>, dim3(chunks), dim3(256), 0, s, G, K, zero_grad & 0xff);
+    else hipLaunchKernelGGL(gigs::adam_kernel<true>, dim3(chunks), dim3(256), 0, s, G, K, zero_grad & 0xff);
   }
   gigs_internal_stage_end(tok);
   if (hipGetLastError() != hipSuccess) return gigs_internal_fail(GIGS_ERR_HIP, "adam_step: launch failed");
