@@ -1162,10 +1162,7 @@ def _fused_begin(self, start_event=None):
         # the side stream: intended here (autograd inserts the event wait), so the advisory warning is switched off
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        # the light owns a stream (pbr/light.py: every graph over `base` is built there, so is its backward): that stream IS the
-        # side stream of this step -- the fused node's split backward (stage2_fused.py) relies on the filters' backward running
-        # behind what it issues there
-        self.side = self.light._side_stream() if hasattr(self.light, "_side_stream") else torch.cuda.Stream()
+        self.side = torch.cuda.Stream()
         self.mips = LightMips(self.light)
         self.dummy = torch.zeros(1, device=self.light.base.device)
         if self.graphs:
@@ -1216,10 +1213,13 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
     args = (normal_map.detach(), out_normal_view.detach(), albedo_map, roughness_map, metallic_map,
             occlusion_map.detach(), depth_pos.detach(), st.viewmatrix, view_dirs, gt_image, *lights)
     if self.back is None:
-        # light_stream: the fused node's backward issues its light-texture gradient scatter there (stage2_fused.py); not
-        # under make_graphed_callables, whose per-callable capture cannot leave a forked stream unjoined
+        # light_stream: the fused node's backward issues its light-texture gradient scatter there (stage2_fused.py) -- the
+        # stream on which the light's filters were built, hence on which autograd runs their backward, behind that scatter:
+        # the light's own stream (pbr/light.py builds every filter there outside captures).  Not under
+        # make_graphed_callables, whose per-callable capture cannot leave a forked stream unjoined
+        own = self.light._side_stream() if hasattr(self.light, "_side_stream") else self.side
         cfg = dict(H=H, W=W, gi=self.gi, focal_x=W / (2.0 * cam["tanfovx"]), focal_y=H / (2.0 * cam["tanfovy"]),
-                   light_stream=None if self.graphs else self.side, **self.flags)
+                   light_stream=None if self.graphs else own, **self.flags)
         self.back = Stage2FusedBack(self.brdf_lut, cfg)
         if self.graphs:
             # pooled rasterizer planes (fixed addresses) become the graph's static inputs themselves: no staging copies
