@@ -3,6 +3,7 @@ pre-filter run in libgigs_hip.so.  Image I/O (cv2) parts of the reference class 
 from __future__ import annotations
 
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -14,6 +15,26 @@ from .renderutils import diffuse_cubemap, specular_cubemap
 from .renderutils.ops import specular_cubemap_levels
 
 _lib = gigs_lib.lib()
+
+
+class _Tls(threading.local):
+    build_here = False
+
+
+_tls = _Tls()
+
+
+class build_on_current_stream:
+    """`with build_on_current_stream():` -- CubemapLight.build_mips() runs its launches on the caller's current stream instead
+    of the light's own one (a stepper that schedules the light itself: pipeline._fused_begin)."""
+
+    def __enter__(self):
+        self._prev, _tls.build_here = _tls.build_here, True
+        return self
+
+    def __exit__(self, *exc):
+        _tls.build_here = self._prev
+        return False
 
 
 class cubemap_mip(torch.autograd.Function):
@@ -126,8 +147,9 @@ class CubemapLight(nn.Module):
 
     def build_mips(self, cutoff: float = 0.99) -> None:
         pre, self._pre = self._pre, None
-        if not self.base.is_cuda or torch.cuda.is_current_stream_capturing():
-            self.specular, self.diffuse = self._build(cutoff)  # inside a graph capture: on the capturing stream
+        if not self.base.is_cuda or _tls.build_here or torch.cuda.is_current_stream_capturing():
+            # inside a graph capture, or for a stepper that schedules the light itself: on the current stream
+            self.specular, self.diffuse = self._build(cutoff)
             return
         self._wanted = True  # the caller filters every iteration: the next rasterizer forward may start the next one early
         main = torch.cuda.current_stream()

@@ -1179,7 +1179,10 @@ def _fused_begin(self, start_event=None):
         self.side.wait_event(self.step_begin)
     else:
         self.side.wait_event(self.blend_begin)
-    with torch.cuda.stream(self.side):
+    import pbr.light as pbr_light
+    # this stepper schedules the light itself: the filters are built HERE, on its side stream (not on the light's own
+    # stream, which serves the op-by-op caller: pbr/light.py), so that their backward runs there too
+    with torch.cuda.stream(self.side), pbr_light.build_on_current_stream():
         out = self.mips(self.dummy)
         # what the shade waits for: an event of its own, so that work queued on this stream later (the regularisers,
         # _fused_step) is not waited for with it
@@ -1214,12 +1217,10 @@ def _fused_step(self, cam, gt_image, view_dirs, st, radii, screenspace_points, n
             occlusion_map.detach(), depth_pos.detach(), st.viewmatrix, view_dirs, gt_image, *lights)
     if self.back is None:
         # light_stream: the fused node's backward issues its light-texture gradient scatter there (stage2_fused.py) -- the
-        # stream on which the light's filters were built, hence on which autograd runs their backward, behind that scatter:
-        # the light's own stream (pbr/light.py builds every filter there outside captures).  Not under
-        # make_graphed_callables, whose per-callable capture cannot leave a forked stream unjoined
-        own = self.light._side_stream() if hasattr(self.light, "_side_stream") else self.side
+        # stream on which _fused_begin built the light's filters, hence on which autograd runs their backward, behind that
+        # scatter.  Not under make_graphed_callables, whose per-callable capture cannot leave a forked stream unjoined
         cfg = dict(H=H, W=W, gi=self.gi, focal_x=W / (2.0 * cam["tanfovx"]), focal_y=H / (2.0 * cam["tanfovy"]),
-                   light_stream=None if self.graphs else own, **self.flags)
+                   light_stream=None if self.graphs else self.side, **self.flags)
         self.back = Stage2FusedBack(self.brdf_lut, cfg)
         if self.graphs:
             # pooled rasterizer planes (fixed addresses) become the graph's static inputs themselves: no staging copies
