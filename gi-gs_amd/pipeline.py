@@ -597,6 +597,11 @@ class WholeStepGraph:
                 if v is None:
                     continue
                 if out[i] is None:
+                    # the declared stage-2 gradient set: an absent gradient outside the collective's stretch stays absent
+                    # (Adam takes it as g = 0); inside it the slab must hold the zeros the other ranks add to
+                    reduced = getattr(self.owner, "grad_slab_reduced", None)
+                    if self.viol_dev is not None and reduced is not None and name not in reduced:
+                        continue
                     v.zero_()
                 elif out[i].data_ptr() != v.data_ptr():
                     v.copy_(out[i])

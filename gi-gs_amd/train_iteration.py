@@ -190,6 +190,7 @@ def _attach_slab(trainer, group, names, average, force, light=None):
     trainer._dp_args = (group, tuple(names), average, force)
     stepper = trainer.stepper
     stepper.grad_slab = {k: v for k, v in zip(order, slab.views)}
+    stepper.grad_slab_reduced = set(names)  # what the collective covers (pipeline.WholeStepGraph._into_slab)
 
     def hook():
         wsg = stepper.whole
