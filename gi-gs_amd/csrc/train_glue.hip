@@ -388,6 +388,8 @@ struct AdamGroups {
   // gigs_adam_step_watch: bit k set = group k of this launch is watched; *changed |= 1 when one of its parameters changes
   unsigned watch_mask;
   unsigned* changed;
+  // gigs_adam_step_guarded: the launch is a no-op while *guard != 0 (a violated gradient declaration: gigs_ctx_set_materials_only)
+  const unsigned* guard;
 };
 
 struct AdamConsts { float b2, omb1, omb2, eps; };  // beta2, 1 - beta1, 1 - beta2 (rounded from double as torch does), eps
@@ -425,6 +427,7 @@ __device__ __forceinline__ void adam_st4(float* p, float4 v) {
 template <bool kStream>
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamGroups G, AdamConsts K, int zero_grad) {
+  if (G.guard && *G.guard != 0u) return;  // uniform: nothing of this update is computed from gradients that were declared wrongly
   int gi = 0;
   while (gi + 1 < G.count && blockIdx.x >= G.first_chunk[gi + 1]) gi++;
   const long long n = G.n[gi];
@@ -846,6 +849,11 @@ int gigs_adam_step_dyn(int n_groups, const gigs_adam_group* groups, double beta1
 
 int gigs_adam_step_watch(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
                          const float* dyn, const unsigned char* watch, unsigned* changed, void* stream) {
+  return gigs_adam_step_guarded(n_groups, groups, beta1, beta2, eps, zero_grad, dyn, watch, changed, nullptr, stream);
+}
+
+int gigs_adam_step_guarded(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
+                           const float* dyn, const unsigned char* watch, unsigned* changed, const unsigned* guard, void* stream) {
   if (n_groups < 0 || (n_groups > 0 && !groups)) return gigs_internal_fail(GIGS_ERR_INVALID, "adam_step: bad argument");
   hipStream_t s = (hipStream_t)stream;
   void* tok; gigs_internal_stage_begin(26, stream, &tok);
@@ -886,6 +894,7 @@ int gigs_adam_step_watch(int n_groups, const gigs_adam_group* groups, double bet
     G.count = k;
     G.dyn = dyn;
     G.changed = changed;
+    G.guard = guard;
     G.first_chunk[k] = chunks;
     if (k == 0 || chunks == 0) {
       if (k == 0 && done < n_groups) {  // a single group too large for one grid

@@ -114,6 +114,7 @@ SIGNATURES = {
     "gigs_adam_step_dyn": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, _f, C.c_void_p]),
     "gigs_adam_scalars": (None, [C.c_double, _i, C.c_double, C.c_double, C.POINTER(C.c_float)]),
     "gigs_adam_step_watch": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, _f, C.c_char_p, _f, C.c_void_p]),
+    "gigs_adam_step_guarded": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, _f, C.c_char_p, _f, _f, C.c_void_p]),
     "gigs_ctx_set_reuse_binning": (_i, [C.c_void_p, _i]),
     "gigs_ctx_set_materials_only": (_i, [C.c_void_p, C.c_void_p]),
     "gigs_activate_fwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -191,9 +191,11 @@ class CapturedAdam:
             out.append((p.data_ptr(), 0 if gr is None else gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
         return tuple(out)
 
-    def launch(self, watch=None, changed: Optional[torch.Tensor] = None) -> None:
+    def launch(self, watch=None, changed: Optional[torch.Tensor] = None, guard: Optional[torch.Tensor] = None) -> None:
         """`watch` (group names) + `changed` (device int32[1]): gigs_adam_step_watch ORs 1 into `changed` when the update
-        moves a bit of a watched group (pipeline.GeometryCache: the geometry groups of a stage-2 iteration)."""
+        moves a bit of a watched group (pipeline.GeometryCache: the geometry groups of a stage-2 iteration).  `guard` (device
+        int32[1]): while it is non-zero the launch changes nothing (gigs_adam_step_guarded: the violation counter of a
+        declared gradient set)."""
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             row = 0
@@ -206,7 +208,13 @@ class CapturedAdam:
                                                      st["exp_avg_sq"].data_ptr(), p.numel(), 0.0, 0))
                     flags.append(1 if (watch is not None and grp.get("name") in watch) else 0)
                 arr = (gigs_lib.AdamGroup * len(groups))(*groups)
-                if changed is not None and any(flags):
+                if guard is not None:
+                    use_watch = changed is not None and any(flags)
+                    gigs_lib.check(_lib.gigs_adam_step_guarded(len(groups), C.cast(arr, C.c_void_p), b1, b2, eps, 0,
+                                                               self.table[row:].data_ptr(), bytes(flags) if use_watch else None,
+                                                               changed.data_ptr() if use_watch else None, guard.data_ptr(),
+                                                               stream), "adam_step_guarded")
+                elif changed is not None and any(flags):
                     gigs_lib.check(_lib.gigs_adam_step_watch(len(groups), C.cast(arr, C.c_void_p), b1, b2, eps, 0,
                                                              self.table[row:].data_ptr(), bytes(flags), changed.data_ptr(),
                                                              stream), "adam_step_watch")

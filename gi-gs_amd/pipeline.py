@@ -579,9 +579,9 @@ class WholeStepGraph:
             self.viol_host.zero_()
             raise RuntimeError(
                 "WholeStepGraph: %d wave(s) of the rasterizer's backward found a gradient outside the declared stage-2 set "
-                "(albedo / roughness / metallic / light) -- the loss reaches colour, opacity, depth, normal or geometry, so "
-                "the updates since the last check used zeros that were not zeros.  Build the stepper / trainer with "
-                "materials_only=False (GIGS_MATERIALS_ONLY=0)." % n)
+                "(albedo / roughness / metallic / light) -- the loss reaches colour, opacity, depth, normal or geometry.  "
+                "The updates since then were withheld on the device (gigs_adam_step_guarded), the parameters are those of "
+                "the last valid step.  Build the stepper / trainer with materials_only=False (GIGS_MATERIALS_ONLY=0)." % n)
 
     def _into_slab(self, g, grads):
         """Inside the backward capture: every gradient ends up in its slab view (most were born there; the light's is
@@ -719,11 +719,11 @@ class WholeStepGraph:
                 with torch.cuda.graph(go, pool=gf.pool(), stream=cap, capture_error_mode="thread_local"):
                     if self.cache is not None:
                         # the update reports whether it moved a geometry bit; the word travels to pinned memory and is cleared
-                        adam.launch(watch=GeometryCache.WATCH, changed=self.cache.flag_dev)
+                        adam.launch(watch=GeometryCache.WATCH, changed=self.cache.flag_dev, guard=self.viol_dev)
                         self.cache.flag_host.copy_(self.cache.flag_dev, non_blocking=True)
                         self.cache.flag_dev.zero_()
                     else:
-                        adam.launch()
+                        adam.launch(guard=self.viol_dev)
                     if self.viol_dev is not None:
                         self.viol_host.copy_(self.viol_dev, non_blocking=True)  # cumulative: a violation stays visible
                     if o.post_update is not None:

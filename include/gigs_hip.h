@@ -474,6 +474,11 @@ void gigs_adam_scalars(double lr, int step, double beta1, double beta2, float* o
  * (gigs_ctx_set_reuse_binning). */
 int gigs_adam_step_watch(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
                          const float* dyn, const unsigned char* watch, unsigned* changed, void* stream);
+/* gigs_adam_step_watch behind a guard: `guard` is a DEVICE word (NULL = none); while it is non-zero the launch changes nothing
+ * -- parameters, moments and gradients stay as they are.  With the violation counter of gigs_ctx_set_materials_only as the
+ * guard, an update is never computed from gradients that were taken for zero and were not. */
+int gigs_adam_step_guarded(int n_groups, const gigs_adam_group* groups, double beta1, double beta2, double eps, int zero_grad,
+                           const float* dyn, const unsigned char* watch, unsigned* changed, const unsigned* guard, void* stream);
 
 /* The parameter getters of GaussianModel (scene/gaussian_model.py:48-58, 178-263) as one pass each way:
  * shs = cat(f_dc [P,1,3], f_rest [P,K-1,3]) -> [P,K,3]; opacities / albedo / roughness / metallic = sigmoid(raw);

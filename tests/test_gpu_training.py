@@ -547,7 +547,12 @@ def test_declared_stage2_gradient_set_gives_the_same_updates_and_is_checked_on_t
     tr, raw, light = make(True)
     tr.stepper.regularizer = Bad(light)
     tr.stepper.close()  # nothing captured yet; the next iteration captures with the new regulariser
+    before = {k: v.detach().clone() for k, v in raw.items()}
+    light_before = light.base.detach().clone()
     tr.iteration(cams[0], gts[0], vds[0])
+    torch.cuda.synchronize()
+    # the violating step's update is guarded on the device (gigs_adam_step_guarded): nothing was changed by it
+    assert all(torch.equal(raw[k].detach(), before[k]) for k in raw) and torch.equal(light.base.detach(), light_before)
     with pytest.raises(RuntimeError, match="outside the declared stage-2 set"):
         tr.iteration(cams[1], gts[1], vds[1])
         tr.close()
