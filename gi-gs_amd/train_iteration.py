@@ -356,6 +356,25 @@ def bench_iteration(sc, light, brdf_lut, gi, sh_degree, cams_t, view_dirs, gt_im
                                             "geometry bit (gigs_adam_step_watch): no binning, no SSAO march, SSR = a gather at the "
                                             "recorded hits; preprocess, blend, normal derivation, shade, loss, backward and update "
                                             "run every iteration")
+    wsg = tr.stepper.whole
+    if wsg is not None and wsg.go is not None and wsg.adam is not None and not geometry_cache and not data_parallel:
+        # the update graph alone (Adam on the ten Gaussian groups and the light, clamp): an HBM-streaming launch -- parameter and
+        # both moments read and rewritten, the gradient read where one exists -- against the 8 TB/s peak
+        nbytes = sum(p.numel() * 4 * (6 + (1 if gr is not None else 0)) for _, _, p, gr in wsg.adam.entries)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            wsg.go.replay()
+        a.record()
+        for _ in range(10):
+            wsg.go.replay()
+        b.record()
+        b.synchronize()
+        ms = a.elapsed_time(b) / 10
+        extra["update"] = dict(ms=round(ms, 4), adam_bytes=int(nbytes), achieved_GBs=round(nbytes / ms / 1e6, 1), hbm_peak_GBs=8000.0,
+                               hbm_frac=round(nbytes / ms / 1e6 / 8000.0, 4),
+                               groups_without_gradient_tensor=sum(1 for e in wsg.adam.entries if e[3] is None),
+                               what="the third hipGraph replayed alone: gigs_adam_step_guarded on every group (a group whose "
+                                    "gradient is a declared zero has no gradient tensor: g = 0) + clamp of the light")
     tr.close()
     with torch.no_grad():
         light.base.copy_(base0)  # bench.py's light is shared with the legs that follow
