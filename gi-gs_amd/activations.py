@@ -63,11 +63,15 @@ class _Activate(torch.autograd.Function):
         if r["f_dc"].shape != (P, 1, 3) or r["f_rest"].shape != (P, K - 1, 3) or r["rotation"].shape != (P, 4):
             raise ValueError("activate: unexpected parameter shapes")
         dev = raw[0].device
-        out = {"shs": torch.empty((P, K, 3), dtype=torch.float32, device=dev)}
+        # gigs_ctx_set_split_sh (the context's sh_rest IS this call's f_rest tensor): the rasterizer reads f_dc and f_rest as they
+        # are, nothing is concatenated; the node's "shs" output is then an empty placeholder (activate() hands out f_dc instead)
+        rest = gigs_lib.current().sh_rest
+        split = rest is not None and K > 1 and rest.data_ptr() == r["f_rest"].data_ptr()
+        out = {"shs": torch.empty((0,) if split else (P, K, 3), dtype=torch.float32, device=dev)}
         for o, src in _OUT_OF.items():
             out[o] = torch.empty_like(r[src])
         a = gigs_lib.ActivationRaw(*[r[n].data_ptr() for n in RAW])
-        b = gigs_lib.ActivationOut(*[out[n].data_ptr() for n in OUT])
+        b = gigs_lib.ActivationOut(*[None if (split and n == "shs") else out[n].data_ptr() for n in OUT])
         with torch.cuda.device(dev):
             gigs_lib.check(_lib.gigs_activate_fwd(P, K, C.addressof(a), C.addressof(b),
                                                   torch.cuda.current_stream().cuda_stream), "activate_fwd")
@@ -110,6 +114,8 @@ class _Activate(torch.autograd.Function):
 def activate(raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     out = _Activate.apply(*[raw[n] for n in RAW])
     g = dict(zip(OUT, out))
+    if g["shs"].numel() == 0 and raw["f_dc"].numel() != 0:
+        g["shs"] = raw["f_dc"]  # split SH (gigs_ctx_set_split_sh): the rasterizer takes the degree-0 tensor, f_rest via its context
     g["means3D"] = raw["xyz"]
     return g
 

@@ -183,7 +183,7 @@ const Options& default_options() {
   return o;
 }
 const Ctx& default_ctx() {
-  static const Ctx c = {default_options(), 0u, nullptr, nullptr, 0, nullptr};
+  static const Ctx c = {default_options(), 0u, nullptr, nullptr, 0, nullptr, nullptr};
   return c;
 }
 }  // namespace gigs
@@ -284,6 +284,11 @@ int gigs_ctx_set_options(gigs_ctx* ctx, const gigs_options* in) {
 int gigs_ctx_set_reuse_binning(gigs_ctx* ctx, int on) {
   if (!ctx) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_reuse_binning: the default context is immutable, create one");
   reinterpret_cast<gigs::Ctx*>(ctx)->reuse_binning = on != 0;
+  return 0;
+}
+int gigs_ctx_set_split_sh(gigs_ctx* ctx, const float* sh_rest) {
+  if (!ctx) return fail(GIGS_ERR_INVALID, "gigs_ctx_set_split_sh: the default context is immutable, create one");
+  reinterpret_cast<gigs::Ctx*>(ctx)->sh_rest = sh_rest;
   return 0;
 }
 int gigs_ctx_set_materials_only(gigs_ctx* ctx, void* violations) {
@@ -388,6 +393,7 @@ int gigs_forward(gigs_ctx* ctx, gigs_alloc_fn geometryBuffer, void* geom_user, g
   a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
   a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos; a.background = background;
   a.argmax_depth = argmax_depth; a.inference = inference;
+  a.shs_rest = (shs && !colors_precomp && M > 1) ? cx.sh_rest : nullptr;  // gigs_ctx_set_split_sh
 
   const size_t scan_sz = scan_size_cached(P);
   const size_t geom_bytes = gigs::required_bytes<gigs::GeomState>((size_t)P, scan_sz);
@@ -582,6 +588,8 @@ int gigs_backward(gigs_ctx* ctx, int P, int D, int M, int R, const float* backgr
   if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GIGS_ERR_INVALID, "null scratch buffer");
   // gigs_ctx_set_materials_only: the declared stage-2 gradient set -- only these four outputs are written
   unsigned* const materials_only = ctx_of(ctx).materials_only;
+  if (ctx_of(ctx).sh_rest && shs && M > 1 && !materials_only)
+    return fail(GIGS_ERR_INVALID, "a split-SH forward (gigs_ctx_set_split_sh) has a materials-only backward only");
   if (!dL_dmean2D || !dL_dalbedo || !dL_droughness || !dL_dmetallic)
     return fail(GIGS_ERR_INVALID, "null gradient output");
   if (!materials_only && (!dL_dopacity || !dL_dnormal || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||

@@ -257,6 +257,7 @@ struct Ctx {
   void* blend_begin_event;  // gigs_ctx_set_blend_begin_event
   int reuse_binning;        // gigs_ctx_set_reuse_binning
   unsigned* materials_only;  // gigs_ctx_set_materials_only: violation counter of the declared stage-2 gradient set
+  const float* sh_rest;      // gigs_ctx_set_split_sh
 };
 const Options& default_options();  // api.hip
 const Ctx& default_ctx();          // options = default_options(), no async binning, no event
@@ -270,6 +271,7 @@ struct FwdArgs {
       *metallic, *scales, *rotations, *cov3D_precomp, *viewmatrix, *projmatrix, *cam_pos,
       *background;
   int argmax_depth, inference;
+  const float* shs_rest;  // gigs_ctx_set_split_sh: `shs` = coefficient 0 [P,1,3], coefficients 1..M-1 here [P,M-1,3]
 };
 
 void launch_preprocess_fwd(const FwdArgs& a, const GeomState& g, int* radii, hipStream_t s);

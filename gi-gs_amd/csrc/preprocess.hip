@@ -68,6 +68,37 @@ __device__ __forceinline__ void stage_sh(const float* __restrict__ shs, float* s
   }
 }
 
+// The same LDS rows from the optimizer's two tensors (gigs_ctx_set_split_sh): coefficient 0 from `dc` [nG][3], coefficients
+// 1..M-1 from `rest` [nG][3(M-1)] -- no concatenated copy of the SH block exists anywhere.
+__device__ __forceinline__ void stage_sh_split(const float* __restrict__ dc, const float* __restrict__ rest, float* sh_lds,
+                                               size_t first, int nG, int M) {
+  const int n3 = 3 * M, r = n3 - 3, stride = sh_stride(M);
+  const float* d = dc + first * 3;
+  for (int e = threadIdx.x; e < nG * 3; e += kPreBlock) {
+    const int lane = e / 3;
+    sh_lds[lane * stride + (e - lane * 3)] = d[e];
+  }
+  const float* src = rest + first * (size_t)r;
+  const int nfloat = nG * r;
+  const int nvec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 ? nfloat >> 2 : 0;
+  const float4* src4 = reinterpret_cast<const float4*>(src);
+  for (int i = threadIdx.x; i < nvec; i += kPreBlock) {
+    const float4 v = src4[i];
+    const int e = i << 2;
+    int lane = e / r, j = e - lane * r;
+    const float c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      sh_lds[lane * stride + 3 + j] = c[k];
+      if (++j == r) { j = 0; ++lane; }
+    }
+  }
+  for (int e = (nvec << 2) + threadIdx.x; e < nfloat; e += kPreBlock) {
+    const int lane = e / r;
+    sh_lds[lane * stride + 3 + (e - lane * r)] = src[e];
+  }
+}
+
 __device__ __forceinline__ v3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
 struct Cov2D {
@@ -113,7 +144,8 @@ preprocess_fwd_kernel(FwdArgs a, GeomState g, int* __restrict__ radii) {
   if (use_sh) {
     const size_t first = (size_t)blockIdx.x * kPreBlock;
     const int nG = min(kPreBlock, P - (int)first);
-    stage_sh(a.shs, sh_lds, first, nG, a.M);
+    if (a.shs_rest) stage_sh_split(a.shs, a.shs_rest, sh_lds, first, nG, a.M);
+    else stage_sh(a.shs, sh_lds, first, nG, a.M);
     __syncthreads();
   }
   if (idx >= P) return;

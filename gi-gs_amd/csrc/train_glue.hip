@@ -981,7 +981,7 @@ static void act_fill_raw(gigs::ActPtrs& A, const gigs_activation_raw* r) {
 }
 
 int gigs_activate_fwd(int P, int K, const gigs_activation_raw* raw, const gigs_activation_out* out, void* stream) {
-  if (P < 0 || K < 1 || 3 * K > gigs::kActMaxRowF || (P > 0 && (!act_raw_ok(raw, K) || !out || !out->shs || !out->opacities || !out->normal ||
+  if (P < 0 || K < 1 || 3 * K > gigs::kActMaxRowF || (P > 0 && (!act_raw_ok(raw, K) || !out || !out->opacities || !out->normal ||
                                    !out->albedo || !out->roughness || !out->metallic || !out->scales || !out->rotations)))
     return gigs_internal_fail(GIGS_ERR_INVALID, "activate_fwd: bad argument");
   if (P == 0) return 0;
@@ -991,7 +991,7 @@ int gigs_activate_fwd(int P, int K, const gigs_activation_raw* raw, const gigs_a
   A.shs = out->shs; A.o_opacity = out->opacities; A.o_normal = out->normal; A.o_albedo = out->albedo;
   A.o_roughness = out->roughness; A.o_metallic = out->metallic; A.o_scales = out->scales; A.o_rotations = out->rotations;
   void* tok; gigs_internal_stage_begin(30, stream, &tok);
-  const int sh_tiles = (P + gigs::kActRows - 1) / gigs::kActRows;
+  const int sh_tiles = A.shs ? (P + gigs::kActRows - 1) / gigs::kActRows : 0;  // no concatenation without an output for it
   hipLaunchKernelGGL(gigs::activate_fwd_kernel, dim3((unsigned)(sh_tiles + (P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K,
                      A, sh_tiles);
   gigs_internal_stage_end(tok);

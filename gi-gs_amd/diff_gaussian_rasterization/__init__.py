@@ -376,6 +376,12 @@ def _rasterize_gaussians(bg, means3D, colors_precomp, opacities, normal, albedo,
     rendered = 0
     if P != 0:
         M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
+        rest = gigs_lib.current().sh_rest  # gigs_ctx_set_split_sh: `sh` is the degree-0 tensor, the others live in `rest`
+        if rest is not None and M:
+            if M != 1 or int(rest.shape[0]) != P or rest.dim() != 3 or not rest.is_contiguous() or rest.device != dev:
+                raise RuntimeError("split SH: shs must be the [P,1,3] degree-0 tensor and the context's sh_rest a contiguous "
+                                   "[P,M-1,3] tensor on the same device")
+            M = 1 + int(rest.shape[1])
         keep = []
 
         def p(t, name):
@@ -419,6 +425,8 @@ def _rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, normal, al
     else:
         raise RuntimeError("rasterize_gaussians_backward: grad_color is None and no image_size was given")
     M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
+    if M and gigs_lib.current().sh_rest is not None:  # split SH (the forward's context): M counts both tensors
+        M = 1 + int(gigs_lib.current().sh_rest.shape[1])
     # every element of every gradient tensor is written by the backward kernels when P > 0
     # (the reference zero-fills 14 tensors first, rasterize_points.cu:299-312)
     _mk = torch.empty if P != 0 else torch.zeros

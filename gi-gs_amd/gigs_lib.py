@@ -117,6 +117,7 @@ SIGNATURES = {
     "gigs_adam_step_guarded": (_i, [_i, C.c_void_p, C.c_double, C.c_double, C.c_double, _i, _f, C.c_char_p, _f, _f, C.c_void_p]),
     "gigs_ctx_set_reuse_binning": (_i, [C.c_void_p, _i]),
     "gigs_ctx_set_materials_only": (_i, [C.c_void_p, C.c_void_p]),
+    "gigs_ctx_set_split_sh": (_i, [C.c_void_p, C.c_void_p]),
     "gigs_activate_fwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gigs_activate_bwd": (_i, [_i, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gigs_densify_stats": (_i, [_i, _f, _f, _f, _f, _f, _f, _f, C.c_void_p]),
@@ -252,12 +253,13 @@ class Context:
     _lock = threading.Lock()
 
     def __init__(self, opts: tuple, async_capacity: int, async_counters, blend_event, reuse_binning: bool = False,
-                 materials_only=None):
+                 materials_only=None, sh_rest=None):
         l = lib()
         self.opts, self.async_capacity = tuple(opts), int(async_capacity)
         self.async_counters, self.blend_event = async_counters, blend_event  # kept alive with the context
         self.reuse_binning = bool(reuse_binning)
         self.materials_only = materials_only  # device int32[1] violation counter (gigs_ctx_set_materials_only), kept alive
+        self.sh_rest = sh_rest  # the optimizer's _features_rest tensor [P, M-1, 3] (gigs_ctx_set_split_sh), kept alive
         self.ptr = l.gigs_ctx_create()
         if not self.ptr:
             raise GigsError("gigs_ctx_create failed")
@@ -276,6 +278,8 @@ class Context:
             check(l.gigs_ctx_set_reuse_binning(self.ptr, 1), "gigs_ctx_set_reuse_binning")
         if materials_only is not None:
             check(l.gigs_ctx_set_materials_only(self.ptr, materials_only.data_ptr()), "gigs_ctx_set_materials_only")
+        if sh_rest is not None:
+            check(l.gigs_ctx_set_split_sh(self.ptr, sh_rest.data_ptr()), "gigs_ctx_set_split_sh")
 
     def __del__(self):
         try:
@@ -287,23 +291,25 @@ class Context:
 
     @classmethod
     def get(cls, opts: tuple, async_capacity: int = 0, async_counters=None, blend_event=None, reuse_binning=False,
-            materials_only=None) -> "Context":
+            materials_only=None, sh_rest=None) -> "Context":
         key = (tuple(int(v) for v in opts), int(async_capacity),
                None if async_counters is None else async_counters.data_ptr(), None if blend_event is None else id(blend_event),
-               bool(reuse_binning), None if materials_only is None else materials_only.data_ptr())
+               bool(reuse_binning), None if materials_only is None else materials_only.data_ptr(),
+               None if sh_rest is None else (sh_rest.data_ptr(), tuple(sh_rest.shape)))
         with cls._lock:
             c = cls._cache.get(key)
             if c is None:
                 if len(cls._cache) > 512:  # contexts of long-gone buffers: start over (live ones are re-created on demand)
                     cls._cache.clear()
-                c = cls._cache[key] = cls(key[0], async_capacity, async_counters, blend_event, reuse_binning, materials_only)
+                c = cls._cache[key] = cls(key[0], async_capacity, async_counters, blend_event, reuse_binning, materials_only, sh_rest)
         return c
 
-    def derive(self, async_binning=None, blend_event="keep", reuse_binning=None, materials_only="keep", **options) -> "Context":
+    def derive(self, async_binning=None, blend_event="keep", reuse_binning=None, materials_only="keep", sh_rest="keep",
+               **options) -> "Context":
         """The context with some settings changed: option names of gigs_options (gi_march also by name), `async_binning` =
         (capacity, counters tensor) or False to switch it off, `blend_event` = a torch.cuda.Event or None, `reuse_binning`
         = True / False (gigs_ctx_set_reuse_binning), `materials_only` = a device int32[1] violation counter or None
-        (gigs_ctx_set_materials_only)."""
+        (gigs_ctx_set_materials_only), `sh_rest` = the optimizer's _features_rest tensor or None (gigs_ctx_set_split_sh)."""
         opts = list(self.opts)
         for k, v in options.items():
             if k == "gi_march" and isinstance(v, str):
@@ -316,7 +322,8 @@ class Context:
             cap, cnt = async_binning
         ev = self.blend_event if isinstance(blend_event, str) else blend_event
         mo = self.materials_only if isinstance(materials_only, str) else materials_only
-        return Context.get(tuple(opts), cap, cnt, ev, self.reuse_binning if reuse_binning is None else reuse_binning, mo)
+        rest = self.sh_rest if isinstance(sh_rest, str) else sh_rest
+        return Context.get(tuple(opts), cap, cnt, ev, self.reuse_binning if reuse_binning is None else reuse_binning, mo, rest)
 
     def option(self, name: str) -> int:
         return self.opts[OPTION_NAMES.index(name)]

@@ -504,6 +504,7 @@ class WholeStepGraph:
         self.fwd_done = torch.cuda.Event()
         self._packs = {}
         self.viol_dev = self.viol_host = None  # declared stage-2 gradient set: violation counter (device) and its pinned copy
+        self.split_rest = None                 # ... and the optimizer's f_rest tensor the rasterizer then reads directly
 
     CAM_TENSORS = ("viewmatrix", "projmatrix", "campos")
 
@@ -568,7 +569,7 @@ class WholeStepGraph:
         if self.viol_dev is not None:
             # the declared stage-2 gradient set: the forward's library context carries the violation counter, the backward
             # nodes (rasterizer, activations) then produce the material gradients only
-            stack.enter_context(gigs_lib.use(gigs_lib.current().derive(materials_only=self.viol_dev)))
+            stack.enter_context(gigs_lib.use(gigs_lib.current().derive(materials_only=self.viol_dev, sh_rest=self.split_rest)))
         return stack
 
     def check_declared(self) -> None:
@@ -631,10 +632,16 @@ class WholeStepGraph:
         self.bin = AsyncBinning(self.capacity, self.dev)
         # Declared stage-2 gradient set (complete iterations only: the gradients are consumed inside the step, by an Adam
         # launch that takes an absent gradient as g = 0)
-        self.viol_dev = self.viol_host = None
+        self.viol_dev = self.viol_host = self.split_rest = None
         if o.optimizers and getattr(o, "materials_only", False) and os.environ.get("GIGS_MATERIALS_ONLY", "1") == "1":
             self.viol_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
             self.viol_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            # with it, the SH block is never concatenated: the rasterizer reads the optimizer's two tensors (gigs_ctx_set_split_sh;
+            # its materials-only backward does not touch SH)
+            rest = g.get("f_rest") if o.prepare is not None else None
+            if (rest is not None and rest.dim() == 3 and rest.shape[1] > 0 and rest.is_contiguous()
+                    and os.environ.get("GIGS_SPLIT_SH", "1") == "1"):
+                self.split_rest = rest
         self.inner = o._make_inner()  # the eager step that is captured: returns its attached loss instead of differentiating
         self.inner._defer_backward = True
         self.inner._static_bg = bg

@@ -483,6 +483,8 @@ int gigs_adam_step_guarded(int n_groups, const gigs_adam_group* groups, double b
 /* The parameter getters of GaussianModel (scene/gaussian_model.py:48-58, 178-263) as one pass each way:
  * shs = cat(f_dc [P,1,3], f_rest [P,K-1,3]) -> [P,K,3]; opacities / albedo / roughness / metallic = sigmoid(raw);
  * scales = exp(scaling); rotations = F.normalize(rotation), normal = F.normalize(normal) (dim -1, eps 1e-12).
+ * gigs_activate_fwd: out->shs may be NULL (the caller hands the two SH tensors to the rasterizer as they are:
+ * gigs_ctx_set_split_sh) -- no concatenation then.
  * gigs_activate_bwd: grad_out members may be NULL (= zero gradient); every non-NULL grad_raw tensor is overwritten, a NULL
  * one is neither computed nor written (a gradient the caller knows to be zero and keeps no tensor for). */
 typedef struct gigs_activation_raw {
@@ -587,6 +589,14 @@ int gigs_ctx_set_reuse_binning(gigs_ctx* ctx, int on);
  * NULL grad_raw member, a gigs_adam_group with grad == NULL is updated with g = 0 (same arithmetic, nothing read).
  * violations == NULL restores the complete backward. */
 int gigs_ctx_set_materials_only(gigs_ctx* ctx, void* violations);
+
+/* Split SH input (gigs-hip extension).  The optimizer keeps the SH coefficients as two tensors -- _features_dc [P,1,3] and
+ * _features_rest [P,M-1,3] (scene/gaussian_model.py:48-58) -- and get_features concatenates them for every render: a pure copy
+ * of 12 M bytes per Gaussian each way.  After gigs_ctx_set_split_sh(ctx, sh_rest), gigs_forward(ctx, ...) takes `shs` as the
+ * degree-0 tensor and reads coefficients 1..M-1 from sh_rest (M is still the total count): same colours bit for bit, no
+ * concatenated copy.  The backward of such a forward is the materials-only one (gigs_ctx_set_materials_only, which does not
+ * touch SH); gigs_backward refuses anything else.  sh_rest == NULL restores the single tensor. */
+int gigs_ctx_set_split_sh(gigs_ctx* ctx, const float* sh_rest);
 
 /* Optional scheduling hook: a hipEvent_t (caller-owned, NULL = none) that gigs_forward records on its stream right
  * before it launches the alpha-blend kernel, so that a caller can start independent work on another stream next to

@@ -232,3 +232,40 @@ def test_materials_only_backward_writes_the_declared_set_and_counts_violations()
     assert torch.equal(m2d_got, m2d_full)  # zeros (and the densification slot)
     run(counter, True)
     assert int(counter.item()) > 0  # the colour plane's gradient reaches dL/dalpha, SH and geometry: counted
+
+
+def test_split_sh_forward_reads_the_two_tensors_and_equals_the_concatenated_one():
+    """gigs_ctx_set_split_sh (gigs-hip extension): `shs` = the optimizer's degree-0 tensor [P,1,3], coefficients 1..M-1 read
+    from its _features_rest tensor [P,M-1,3] -- every output plane and the per-Gaussian colours bit for bit those of the
+    concatenated [P,M,3] input (SH degree 3 and 1; P not a multiple of the 256-Gaussian block); its backward is the
+    materials-only one, any other is refused."""
+    import gigs_lib
+    dgr = _dgr()
+    for deg, P in ((3, 5003), (1, 4097)):
+        sc = scenes.surface_scene(P=P, sh_degree=deg, seed=6, scale_mu=0.04)
+        cam = scenes.orbit_camera(1, 6, 160, 128, radius=3.4)
+        st = settings(dgr, cam, deg)
+        t = {k: tt(sc[k]) for k in GAUSS_KEYS}
+        dc, rest = t["shs"][:, :1, :].contiguous(), t["shs"][:, 1:, :].contiguous()
+
+        def fwd(shs, **ctx_kw):
+            a = {k: v.clone().requires_grad_(True) for k, v in t.items() if k != "shs"}
+            with gigs_lib.use(gigs_lib.current().derive(**ctx_kw)):
+                out = dgr.GaussianRasterizer(st)(a["means3D"], torch.zeros_like(a["means3D"], requires_grad=True), a["opacities"],
+                                                 a["normal"], a["albedo"], a["roughness"], a["metallic"], shs=shs,
+                                                 scales=a["scales"], rotations=a["rotations"])
+            torch.cuda.synchronize()
+            return out, a
+
+        ref, _ = fwd(t["shs"])
+        counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+        got, a = fwd(dc, sh_rest=rest, materials_only=counter)
+        for i, (x, y) in enumerate(zip(ref, got)):
+            assert torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0)), (deg, i)
+        (got[7].sum() + got[8].sum() + got[9].sum()).backward()
+        torch.cuda.synchronize()
+        assert int(counter.item()) == 0 and float(a["albedo"].grad.abs().sum()) > 0 and a["opacities"].grad is None
+        bad, _ = fwd(dc, sh_rest=rest)  # split SH without the materials-only declaration: the forward is fine ...
+        with pytest.raises(Exception, match="materials-only"):
+            bad[7].sum().backward()     # ... a complete backward is refused (it would have to read and write SH)
+        torch.cuda.synchronize()
