@@ -1,4 +1,6 @@
 # does a node on the launch stream after the backward graph's join shorten the graph exit when the side branch finishes last (C4)?
+# (measured once, result in DESIGN.md section 9; the hook it switched -- GIGS_GB_TAIL_NODE=1: one gigs_stream_delay node behind
+# pipeline.WholeStepGraph's backward capture -- was removed afterwards, so this script documents the experiment, it no longer runs it)
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
