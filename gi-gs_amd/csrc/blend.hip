@@ -450,7 +450,7 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   // reduced with DPP, bounced through 80 bytes of LDS so that lane k holds sum k, and leave as ONE
   // global_atomic_add_f32 wave-instruction over the contiguous 80-byte gradient record (non-zero lanes only).
   __shared__ float4 s_rec[4][3 * 64];            // per wave, [k][slot], k = 0..2 (mean2D, conic/opacity, rgb)
-  __shared__ __align__(16) float s_sum[4][GIGS_GREC];  // per wave: the reduced sums of the current instance
+  __shared__ __align__(16) float s_sum[4][2][GIGS_GREC];  // per wave: the reduced sums of the current instance (two when paired)
 
   const unsigned tile = tile_order[blockIdx.x];  // longest lists first (binning.hip::tile_order_kernel)
   const unsigned ty = tile / gx, tx = tile - ty * gx;
@@ -466,7 +466,8 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
   const int n = (int)(range.y - range.x);
   if (n > kLongTile) __builtin_amdgcn_s_setprio(3);
   float4* sw = s_rec[wave];
-  float* ssum = s_sum[wave];
+  float* ssum = s_sum[wave][0];
+  float* ssum2 = s_sum[wave][1];
   const uint8_t* hit = hit_mask + (size_t)wave * hit_stride + range.x;
 
   const float T_final = inside ? final_Ts[pix_id] : 0;
@@ -521,7 +522,13 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
     for (int k = 0; k < 3; k++) rec[k] = src[k];
   }
 
-  if (lane < GIGS_GREC) ssum[lane] = 0.0f;
+  if (lane < GIGS_GREC) { ssum[lane] = 0.0f; ssum2[lane] = 0.0f; }
+  // Material gradients only (every stage-2 step): the per-instance work is one reduction of five sums and one atomic
+  // instruction, each a chain of dependent steps (six DPP stages with their wait states, LDS bounce, atomic) that a lone wave
+  // cannot hide.  Two surviving instances are then taken per iteration: their ten sums share ONE interleaved reduction
+  // (wave_sum_n<10>: the same DPP tree per value, so every sum keeps its bits), one LDS bounce and one atomic instruction
+  // (lanes 0-19 the first record, lanes 32-51 the second); the T recurrence stays in list order.
+  const bool mat_only = any_mat && !any_geo && !any_nrm && !any_dep;
   for (int base = 0; base < n; base += 64) {
     unsigned long long m = __ballot(h_cur);
     const uint32_t my_id = id_cur;
@@ -540,6 +547,49 @@ blend_bwd_kernel(int W, int H, unsigned gx, const uint2* __restrict__ ranges,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    while (mat_only && (m & (m - 1ull)) != 0ull) {  // at least two survivors left in this chunk
+      const int bitA = __builtin_ctzll(m);
+      m &= m - 1ull;
+      const int bitB = __builtin_ctzll(m);
+      m &= m - 1ull;
+      float dcc[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {  // in list order: the second instance sees the first one's T
+        const int bit = q == 0 ? bitA : bitB;
+        const int contributor = n - 1 - (base + bit);
+        const float4 r0 = sw[bit];
+        const float4 r1 = sw[64 + bit];
+        const float dx = r0.x - pixfx, dy = r0.y - pixfy;
+        const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+        const float G = blend_exp(power);
+        const float alpha = fminf(0.99f, r1.w * G);
+        const bool act = inside && (contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        dcc[q] = 0.0f;
+        if (act) {
+          T = T / (1.f - alpha);
+          dcc[q] = alpha * T;
+        }
+      }
+      float v[10] = {dcc[0] * da0, dcc[0] * da1, dcc[0] * da2, dcc[0] * drg, dcc[0] * dmt,
+                     dcc[1] * da0, dcc[1] * da1, dcc[1] * da2, dcc[1] * drg, dcc[1] * dmt};
+      wave_sum_n<10>(v);
+      if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) { ssum[13 + k] = v[k]; ssum2[13 + k] = v[5 + k]; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t gidA = (uint32_t)__builtin_amdgcn_readlane((int)my_id, bitA);
+      const uint32_t gidB = (uint32_t)__builtin_amdgcn_readlane((int)my_id, bitB);
+      {
+        const int k = lane & 31, second = lane >> 5;
+        if (k < GIGS_GREC) {
+          const float val = second ? ssum2[k] : ssum[k];
+          if (val != 0.0f) atomicAdd(grec + (size_t)(second ? gidB : gidA) * GIGS_GREC + k, val);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     while (m != 0ull) {
       const int bit = __builtin_ctzll(m);
       m &= m - 1ull;
